@@ -1,0 +1,164 @@
+"""ctypes binding of libflow2gan_hip.so (the C ABI in include/flow2gan_hip.h).
+
+The product path has no CPU fallback: importing this module without the built library, or calling
+an op with tensors that are not on an MI355X, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflow2gan_hip.so")
+
+c_float_p = C.c_void_p  # raw device pointers travel as integers
+
+
+class Operand(C.Structure):
+    _fields_ = [
+        ("base", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+        ("P1", C.c_int32), ("P0", C.c_int32), ("seglen", C.c_int32),
+        ("step1", C.c_int32), ("pad1", C.c_int32), ("L1", C.c_int32),
+        ("step0", C.c_int32), ("pad0", C.c_int32), ("unit", C.c_int32), ("L0u", C.c_int32),
+        ("seq_stride", C.c_int64), ("line_stride", C.c_int64),
+        ("reflect", C.c_int32), ("_pad", C.c_int32),
+        ("alpha", C.c_void_p), ("lrelu_src", C.c_void_p),
+        ("lrelu_slope", C.c_float), ("_pad2", C.c_int32),
+    ]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("P0o", C.c_int32), ("_pad", C.c_int32),
+        ("seq_stride_o", C.c_int64), ("row_stride_o", C.c_int64), ("off_o", C.c_int64),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int64), ("gamma", C.c_void_p),
+        ("aux", C.c_void_p), ("ldaux", C.c_int64), ("alpha_n", C.c_void_p),
+        ("colsum_alpha", C.c_void_p), ("colsum", C.c_void_p),
+        ("lrelu_slope", C.c_float), ("scale", C.c_float),
+        ("accumulate", C.c_int32), ("atomic", C.c_int32),
+    ]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", Operand), ("B", Operand), ("E", Epilogue), ("form", C.c_int32),
+                ("split_k", C.c_int32)]
+
+
+class DwnormFwd(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64), ("z", C.c_void_p), ("ldz", C.c_int64),
+        ("B", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("K", C.c_int32),
+        ("lens", C.c_void_p), ("w_dw", C.c_void_p), ("b_dw", C.c_void_p), ("beta", C.c_void_p),
+        ("log_scale", C.c_void_p), ("cproj", C.c_void_p), ("ldcp", C.c_int64),
+        ("Fc", C.c_int32), ("up", C.c_int32), ("te", C.c_void_p), ("ldte", C.c_int64),
+        ("rstd", C.c_void_p),
+    ]
+
+
+class DwnormBwd(C.Structure):
+    _fields_ = [
+        ("f", DwnormFwd), ("gz", C.c_void_p), ("ldgz", C.c_int64), ("du", C.c_void_p),
+        ("lddu", C.c_int64), ("g_cproj", C.c_void_p), ("g_te", C.c_void_p),
+        ("g_beta", C.c_void_p), ("g_log_scale", C.c_void_p),
+    ]
+
+
+class DwconvBwd(C.Structure):
+    _fields_ = [
+        ("du", C.c_void_p), ("lddu", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("gx", C.c_void_p), ("ldgx", C.c_int64),
+        ("B", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("K", C.c_int32),
+        ("lens", C.c_void_p), ("w_dw", C.c_void_p), ("gres", C.c_void_p), ("ldgres", C.c_int64),
+        ("gamma", C.c_void_p), ("g_w", C.c_void_p), ("g_b", C.c_void_p), ("g_gamma", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (stream appended automatically)
+_SIGS = {
+    "f2g_gemm": [C.POINTER(GemmDesc)],
+    "f2g_dwnorm_fwd": [C.POINTER(DwnormFwd)],
+    "f2g_dwnorm_bwd": [C.POINTER(DwnormBwd)],
+    "f2g_dwconv_bwd": [C.POINTER(DwconvBwd)],
+    "f2g_biasnorm_fwd": [_P, _L, _P, _L, _I, _I, _P, _P],
+    "f2g_biasnorm_bwd": [_P, _L, _P, _L, _P, _L, _I, _I, _P, _P, _P, _P],
+    "f2g_istft_ola": [_P, _L, _P, _I, _I, _I, _I, _I, _P, _P, _F, _I],
+    "f2g_istft_ola_bwd": [_P, _P, _L, _I, _I, _I, _I, _I, _P, _P, _F],
+    "f2g_frames_fold": [_P, _L, _P, _I, _I, _I, _I, _I, _I],
+    "f2g_axpby_rows": [_P, _P, _P, _P, _P, _F, _F, _I, _I],
+    "f2g_clamp": [_P, _P, _F, _F, _L],
+    "f2g_silu": [_P, _P, _L],
+    "f2g_silu_bwd": [_P, _P, _P, _L],
+    "f2g_time_embedding": [_P, _P, _I, _I, _F],
+    "f2g_mask_rows": [_P, _L, _I, _I, _I, _P],
+    "f2g_colsum": [_P, _P, _L, _P, _L, _I, _I],
+    "f2g_rows_fold_up": [_P, _L, _P, _L, _I, _I, _I, _I, _I],
+    "f2g_bct_to_rows": [_P, _L, _P, _I, _I, _I],
+    "f2g_rows_to_bct": [_P, _P, _L, _I, _I, _I],
+    "f2g_permute4": [_P, _P, _I, _I, _I, _I, _L, _L, _L, _L],
+    "f2g_limit_grad": [_P, _P, _F, _F, _L],
+    "f2g_copy3": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _I],
+    "f2g_spec_power": [_P, _L, _P, _L, _I, _I, _I],
+    "f2g_spec_power_bwd": [_P, _L, _P, _L, _P, _I, _I, _I],
+    "f2g_fm_spec_loss": [_P, _P, _P, _P, _I, _I, _I, _P, _F, _F, _F, _F, _F],
+    "f2g_l1_loss": [_P, _P, _P, _P, _L, _F, _F],
+    "f2g_hinge_loss": [_P, _P, _P, _L, _F, _F],
+    "f2g_peaknorm_fwd": [_P, _P, _P, _I, _I],
+    "f2g_peaknorm_bwd": [_P, _P, _P, _P, _I, _I],
+    "f2g_lrelu_bwd": [_P, _P, _P, _F, _F, _L],
+    "f2g_period_fold": [_P, _P, _I, _I, _I, _I],
+    "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
+    "f2g_fill": [_P, _F, _L],
+    "f2g_log_clip": [_P, _L, _F],
+}
+EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error"])
+
+
+class F2GError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C flow2gan_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = list(args) + [C.c_void_p]
+        fn.restype = C.c_int
+    lib.f2g_version.restype = C.c_char_p
+    lib.f2g_last_error.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def version() -> str:
+    return lib.f2g_version().decode()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a tensor (None stays NULL).  Refuses host tensors: no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise F2GError("flow2gan_amd ops need tensors on an MI355X (got a CPU tensor)")
+    if t.dtype not in (torch.float32, torch.int32):
+        raise F2GError(f"unsupported dtype {t.dtype}")
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    rc = getattr(lib, name)(*args, stream_ptr())
+    if rc != 0:
+        raise F2GError(f"{name} failed with code {rc}: {lib.f2g_last_error().decode()}")

@@ -1,0 +1,32 @@
+// Shared helpers for libflow2gan_hip.so (gfx950 only; no portability layer on purpose).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/flow2gan_hip.h"
+
+int f2g_check_launch();
+void f2g_set_error(const char* msg);
+
+#define F2G_WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+static inline int f2g_grid_for(int64_t n, int block, int cap = 2048 * 4) {
+  int64_t g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}

@@ -1,0 +1,663 @@
+"""Fused forward/backward schedules of the Flow2GAN generator on the HIP kernels.
+
+Each `torch.autograd.Function` below is one coarse node (condition encoder, per-branch condition
+path, one model evaluation = 3 branches, the stage-1 loss) whose forward and backward are explicit
+kernel sequences over channels-last buffers; PyTorch supplies memory, streams and the autograd
+graph between the nodes only.  Math and reference line numbers: SURVEY.md appendix A.
+
+Layout: a reference tensor (B, C, F) is a rows matrix (B*F, C); audio stays (B, T).
+"""
+from __future__ import annotations
+
+import random
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .models.modules import dft_matrices
+from .ops import gemm, mat, win1d
+
+LIMIT_PROB = 0.6  # reference modules.py:260
+
+
+def _limit_draw(training: bool) -> bool:
+    """One Python-RNG draw per BiasNorm / ChannelScale call, as the reference does
+    (modules.py:259-270), so that seeded runs make the same choices in the same order."""
+    return bool(training and random.random() < LIMIT_PROB)
+
+
+def frames_lens(audio_lens_cpu: Optional[List[int]], hop: int, device):
+    if audio_lens_cpu is None:
+        return None
+    return torch.tensor([1 + int(l) // hop for l in audio_lens_cpu], dtype=torch.int32,
+                        device=device)
+
+
+# =====================================================================================
+# ConvNeXt block (shared by the condition encoder and the three decoders)
+# =====================================================================================
+BLOCK_KEYS = ("dwconv.weight", "dwconv.bias", "norm.log_scale", "norm.bias", "pwconv1.weight",
+              "pwconv1.bias", "act.weight", "pwconv2.weight", "pwconv2.bias",
+              "residual_scale.scale")
+
+
+def block_params(blk) -> list:
+    return [blk.dwconv.weight, blk.dwconv.bias, blk.norm.log_scale, blk.norm.bias,
+            blk.pwconv1.weight, blk.pwconv1.bias, blk.act.weight, blk.pwconv2.weight,
+            blk.pwconv2.bias, blk.residual_scale.scale]
+
+
+class _Blk:
+    """Plain view of one block's parameter tensors + sizes."""
+
+    __slots__ = ("w_dw", "b_dw", "log_scale", "beta", "w1", "b1", "alpha", "w2", "b2", "gamma",
+                 "C", "H", "K")
+
+    def __init__(self, p: list):
+        (self.w_dw, self.b_dw, self.log_scale, self.beta, self.w1, self.b1, self.alpha, self.w2,
+         self.b2, self.gamma) = p
+        self.C = self.w_dw.shape[0]
+        self.K = self.w_dw.shape[2]
+        self.H = self.w1.shape[0]
+
+
+def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0, te=None, ldte=0,
+              te_off=0, keep: bool = True):
+    """x (B*F, C) -> new x.  Returns (x_out, z, a) (z, a kept for backward)."""
+    dev = x.device
+    rows, Cc, Hh = B * F, bp.C, bp.H
+    z = ops.empty(rows, Cc, device=dev)
+    ops.dwnorm_fwd(x, z, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta, bp.log_scale.reshape(1),
+                   cproj, ldcp, Fc, up, cp_off, te, ldte, te_off)
+    a = ops.empty(rows, Hh, device=dev)
+    gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1)
+    out = ops.empty(rows, Cc, device=dev)
+    gemm(mat(a, rows, Hh, alpha=bp.alpha), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
+         gamma=bp.gamma.reshape(Cc))
+    return out, z, a
+
+
+def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale: bool,
+              cproj=None, ldcp=0, Fc=0, up=1, cp_off=0, te=None, ldte=0, te_off=0, g_cproj=None,
+              g_te=None):
+    """Backward of block_fwd.  Destroys z and a (reused as gradient buffers).
+    Returns (gx, grads) with grads ordered like BLOCK_KEYS."""
+    dev = x.device
+    rows, Cc, Hh = B * F, bp.C, bp.H
+    g_w2 = ops.zeros(Cc, Hh, device=dev)
+    g_b2 = ops.zeros(Cc, device=dev)
+    g_alpha = ops.zeros(Hh, device=dev)
+    g_w1 = ops.zeros(Hh, Cc, device=dev)
+    g_b1 = ops.zeros(Hh, device=dev)
+    g_beta = ops.zeros(Cc, device=dev)
+    g_ls = ops.zeros(1, device=dev)
+    g_wdw = ops.zeros(Cc, 1, bp.K, device=dev)
+    g_bdw = ops.zeros(Cc, device=dev)
+    g_gamma = ops.zeros(Cc, 1, device=dev)
+    # pwconv2: out = W2 prelu(a) + b2 + gamma*x
+    ops.colsum(g_b2, gout, rows, Cc)
+    ops.wgrad(gout, Cc, gout.stride(0), mat(a, rows, Hh, alpha=bp.alpha), g_w2)
+    # da = (gout W2) * prelu'(a)   (in place over a), d alpha, d b1
+    gemm(mat(gout, rows, Cc), mat(bp.w2.reshape(Cc, Hh)), a, form=1, aux=a, alpha_n=bp.alpha,
+         colsum_alpha=g_alpha, colsum=g_b1)
+    ops.wgrad(a, Hh, a.stride(0), mat(z, rows, Cc), g_w1)
+    # dz = da W1  (z is dead after the weight gradient above: reuse it)
+    gemm(mat(a, rows, Hh), mat(bp.w1.reshape(Hh, Cc)), z, form=1)
+    du = ops.empty(rows, Cc, device=dev)
+    ops.dwnorm_bwd(x, z, du, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta,
+                   bp.log_scale.reshape(1), cproj, ldcp, Fc, up, cp_off, te, ldte, te_off,
+                   g_cproj=g_cproj, g_te=g_te, g_beta=g_beta, g_log_scale=g_ls)
+    gx = ops.empty(rows, Cc, device=dev)
+    ops.dwconv_bwd(du, x, gx, B, F, Cc, bp.K, lens, bp.w_dw, gres=gout, gamma=bp.gamma.reshape(Cc),
+                   g_w=g_wdw, g_b=g_bdw, g_gamma=g_gamma)
+    if limit_norm:
+        ops.limit_grad(g_ls, bp.log_scale.reshape(1), -1.5, 1.5)
+    if limit_scale:
+        ops.limit_grad(g_gamma, bp.gamma, 0.5, 1.0)
+    grads = [g_wdw, g_bdw, g_ls.reshape(()), g_beta, g_w1.reshape(Hh, Cc, 1), g_b1, g_alpha,
+             g_w2.reshape(Cc, Hh, 1), g_b2, g_gamma]
+    return gx, grads
+
+
+# =====================================================================================
+# Condition encoder  (reference modules.py:498-542; called without mask, generator.py:312,348)
+# =====================================================================================
+def cond_encoder_params(enc) -> list:
+    p = [enc.in_proj.weight, enc.in_proj.bias, enc.in_norm.log_scale, enc.in_norm.bias]
+    for blk in enc.blocks:
+        p += block_params(blk)
+    return p
+
+
+class CondEncoderFn(torch.autograd.Function):
+    """mel (B, n_mels, Fm) -> condition rows (B*Fm, channels)."""
+
+    @staticmethod
+    def forward(ctx, mel, training: bool, *params):
+        dev = mel.device
+        B, nm, Fm = mel.shape
+        w_in, b_in, ls_in, beta_in = params[:4]
+        Cc = w_in.shape[0]
+        nblk = (len(params) - 4) // len(BLOCK_KEYS)
+        blks = [_Blk(list(params[4 + i * 10: 14 + i * 10])) for i in range(nblk)]
+        rows = B * Fm
+        melr = ops.empty(rows, nm, device=dev)
+        ops.bct_to_rows(melr, mel.contiguous(), B, nm, Fm)
+        # (Cout, Cin, 3) -> [Cout][tap][Cin] so that the window of a frame is contiguous
+        wp = ops.empty(Cc, 3 * nm, device=dev)
+        ops.permute4(wp, w_in, (Cc, 3, nm, 1), (nm * 3, 1, 3, 0))
+        h0 = ops.empty(rows, Cc, device=dev)
+        gemm(win1d(melr, B, Fm, nm, Fm, 1, 1, 3), mat(wp), h0, bias=b_in)
+        flags = [_limit_draw(training)]
+        x = ops.empty(rows, Cc, device=dev)
+        ops.biasnorm_fwd(h0, x, rows, Cc, beta_in, ls_in.reshape(1))
+        saved = []
+        for bp in blks:
+            fn = _limit_draw(training)
+            y, z, a = block_fwd(bp, x, B, Fm, None)
+            flags.append((fn, _limit_draw(training)))
+            saved.append((x, z, a))
+            x = y
+        if any(ctx.needs_input_grad):
+            ctx.saved = (melr, wp, h0, saved)
+            ctx.params = params
+            ctx.dims = (B, nm, Fm, Cc)
+            ctx.flags = flags
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        melr, wp, h0, saved = ctx.saved
+        params = ctx.params
+        B, nm, Fm, Cc = ctx.dims
+        dev = g.device
+        rows = B * Fm
+        w_in, b_in, ls_in, beta_in = params[:4]
+        nblk = len(saved)
+        blks = [_Blk(list(params[4 + i * 10: 14 + i * 10])) for i in range(nblk)]
+        g = g.contiguous()
+        grads_blocks = [None] * nblk
+        for i in reversed(range(nblk)):
+            x, z, a = saved[i]
+            fn, fs = ctx.flags[1 + i]
+            g, gb = block_bwd(blks[i], x, z, a, g, B, Fm, None, fn, fs)
+            grads_blocks[i] = gb
+        g_beta = ops.zeros(Cc, device=dev)
+        g_ls = ops.zeros(1, device=dev)
+        gh0 = ops.empty(rows, Cc, device=dev)
+        ops.biasnorm_bwd(h0, g, gh0, rows, Cc, beta_in, ls_in.reshape(1), g_beta, g_ls)
+        if ctx.flags[0]:
+            ops.limit_grad(g_ls, ls_in.reshape(1), -1.5, 1.5)
+        g_bin = ops.zeros(Cc, device=dev)
+        ops.colsum(g_bin, gh0, rows, Cc)
+        g_wp = ops.zeros(Cc, 3 * nm, device=dev)
+        ops.wgrad(gh0, Cc, gh0.stride(0), win1d(melr, B, Fm, nm, Fm, 1, 1, 3), g_wp)
+        g_win = ops.empty(Cc, nm, 3, device=dev)
+        ops.permute4(g_win, g_wp, (Cc, nm, 3, 1), (3 * nm, 1, nm, 0))
+        out = [None, None, g_win, g_bin, g_ls.reshape(()), g_beta]
+        for gb in grads_blocks:
+            out += gb
+        ctx.saved = None
+        return tuple(out)
+
+
+# =====================================================================================
+# Per-branch condition path: cond_mlp + the 8 stacked cond_proj (modules.py:576-580,448,482,620)
+# computed at the condition frame rate (pointwise ops commute with repeat-interleave; rows past
+# the condition length are zero rows, exactly what convert_length pads, modules.py:679).
+# =====================================================================================
+def cond_path_params(dec) -> list:
+    p = [dec.cond_mlp[0].weight, dec.cond_mlp[0].bias, dec.cond_mlp[1].weight,
+         dec.cond_mlp[2].weight, dec.cond_mlp[2].bias]
+    for blk in dec.blocks:
+        p += [blk.cond_proj.weight, blk.cond_proj.bias]
+    return p
+
+
+def _stack_rows(ws, cols, dev):
+    """Stack L tensors of shape (C, cols[,1]) into (L*C, cols)."""
+    Cc = ws[0].shape[0]
+    out = ops.empty(len(ws) * Cc, cols, device=dev)
+    for j, w in enumerate(ws):
+        ops.copy3(out, 0, cols, w, 0, cols, 1, Cc, cols, out_offset=j * Cc * cols)
+    return out
+
+
+def _stack_vecs(bs, dev):
+    Cc = bs[0].shape[0]
+    out = ops.empty(len(bs) * Cc, device=dev)
+    for j, b in enumerate(bs):
+        ops.copy3(out, 0, 0, b, 0, 0, 1, 1, Cc, out_offset=j * Cc)
+    return out
+
+
+class CondPathFn(torch.autograd.Function):
+    """cond rows (B*Fc, Dc) -> cproj_all (B*Fce, nblk*C) with Fce = ceil(F/up) rows per item."""
+
+    @staticmethod
+    def forward(ctx, cond, B: int, Fc: int, Fce: int, *params):
+        dev = cond.device
+        w0, b0, alpha, w2, b2 = params[:5]
+        wcs, bcs = list(params[5::2]), list(params[6::2])
+        Dc, Hc = w0.shape[1], w0.shape[0]
+        Cc, nblk = wcs[0].shape[0], len(wcs)
+        if Fce == Fc:
+            cext = cond
+        else:
+            cext = ops.zeros(B * Fce, Dc, device=dev)
+            n = min(Fc, Fce)
+            ops.copy3(cext, Fce * Dc, Dc, cond, Fc * Dc, Dc, B, n, Dc)
+        rows = B * Fce
+        a = ops.empty(rows, Hc, device=dev)
+        gemm(mat(cext, rows, Dc), mat(w0.reshape(Hc, Dc)), a, bias=b0)
+        cm = ops.empty(rows, Dc, device=dev)
+        gemm(mat(a, rows, Hc, alpha=alpha), mat(w2.reshape(Dc, Hc)), cm, bias=b2)
+        wstack = _stack_rows(wcs, Dc, dev)
+        bstack = _stack_vecs(bcs, dev)
+        cproj = ops.empty(rows, nblk * Cc, device=dev)
+        gemm(mat(cm, rows, Dc), mat(wstack), cproj, bias=bstack)
+        if any(ctx.needs_input_grad):
+            ctx.saved = (cext, a, cm, wstack)
+            ctx.params = params
+            ctx.dims = (B, Fc, Fce, Dc, Hc, Cc, nblk)
+        return cproj
+
+    @staticmethod
+    def backward(ctx, g):
+        cext, a, cm, wstack = ctx.saved
+        params = ctx.params
+        B, Fc, Fce, Dc, Hc, Cc, nblk = ctx.dims
+        w0, b0, alpha, w2, b2 = params[:5]
+        dev = g.device
+        rows = B * Fce
+        g = g.contiguous()
+        NC = nblk * Cc
+        g_wstack = ops.zeros(NC, Dc, device=dev)
+        g_bstack = ops.zeros(NC, device=dev)
+        ops.colsum(g_bstack, g, rows, NC)
+        ops.wgrad(g, NC, g.stride(0), mat(cm, rows, Dc), g_wstack)
+        g_cm = ops.empty(rows, Dc, device=dev)
+        gemm(mat(g, rows, NC), mat(wstack), g_cm, form=1)
+        g_b2 = ops.zeros(Dc, device=dev)
+        ops.colsum(g_b2, g_cm, rows, Dc)
+        g_w2 = ops.zeros(Dc, Hc, device=dev)
+        ops.wgrad(g_cm, Dc, g_cm.stride(0), mat(a, rows, Hc, alpha=alpha), g_w2)
+        g_alpha = ops.zeros(Hc, device=dev)
+        g_b0 = ops.zeros(Hc, device=dev)
+        gemm(mat(g_cm, rows, Dc), mat(w2.reshape(Dc, Hc)), a, form=1, aux=a, alpha_n=alpha,
+             colsum_alpha=g_alpha, colsum=g_b0)
+        g_w0 = ops.zeros(Hc, Dc, device=dev)
+        ops.wgrad(a, Hc, a.stride(0), mat(cext, rows, Dc), g_w0)
+        g_cond = None
+        if ctx.needs_input_grad[0]:
+            g_cext = ops.empty(rows, Dc, device=dev)
+            gemm(mat(a, rows, Hc), mat(w0.reshape(Hc, Dc)), g_cext, form=1)
+            if Fce == Fc:
+                g_cond = g_cext
+            else:
+                g_cond = ops.zeros(B * Fc, Dc, device=dev)
+                n = min(Fc, Fce)
+                ops.copy3(g_cond, Fc * Dc, Dc, g_cext, Fce * Dc, Dc, B, n, Dc)
+        out = [g_cond, None, None, None, g_w0.reshape(Hc, Dc, 1), g_b0, g_alpha,
+               g_w2.reshape(Dc, Hc, 1), g_b2]
+        for j in range(nblk):
+            out.append(g_wstack[j * Cc:(j + 1) * Cc].reshape(Cc, Dc, 1))
+            out.append(g_bstack[j * Cc:(j + 1) * Cc])
+        ctx.saved = None
+        return tuple(out)
+
+
+# =====================================================================================
+# One model evaluation = three AudioConvNeXt branches, averaged (generator.py:129-170,
+# modules.py:682-721): STFT (windowed-DFT GEMM) -> in_proj -> in_norm -> 8 blocks -> out_proj ->
+# mask -> inverse DFT GEMM -> overlap-add, accumulated into one (B, T) prediction.
+# =====================================================================================
+def branch_params(est) -> list:
+    d = est.decoder
+    p = [d.in_proj.weight, d.in_proj.bias, d.in_norm.log_scale, d.in_norm.bias,
+         d.time_mlp[0].weight, d.time_mlp[0].bias, d.time_mlp[2].weight, d.time_mlp[2].bias,
+         d.out_proj.weight, d.out_proj.bias]
+    for blk in d.blocks:
+        p += block_params(blk) + [blk.time_embed_proj.weight, blk.time_embed_proj.bias]
+    return p
+
+
+N_BRANCH_HEAD = 10
+N_PER_BLOCK = 12
+
+
+class _BranchView:
+    def __init__(self, params: list):
+        (self.w_in, self.b_in, self.ls_in, self.beta_in, self.tw0, self.tb0, self.tw2, self.tb2,
+         self.w_out, self.b_out) = params[:N_BRANCH_HEAD]
+        rest = params[N_BRANCH_HEAD:]
+        self.nblk = len(rest) // N_PER_BLOCK
+        self.blks = [_Blk(list(rest[i * N_PER_BLOCK: i * N_PER_BLOCK + 10]))
+                     for i in range(self.nblk)]
+        self.tew = [rest[i * N_PER_BLOCK + 10] for i in range(self.nblk)]
+        self.teb = [rest[i * N_PER_BLOCK + 11] for i in range(self.nblk)]
+        self.C = self.w_in.shape[0]
+        self.Cin = self.w_in.shape[1]
+        self.Dt = self.tw0.shape[1]
+        self.Ht = self.tw0.shape[0]
+
+
+def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pred, accumulate,
+                    lens_f, training, keep):
+    n_fft, hop, up, window = meta
+    dev = x.device
+    B, T = x.shape
+    N = n_fft
+    F = 1 + T // hop
+    rows = B * F
+    Cc, Cin = bv.C, bv.Cin
+    Wd, Wi = dft_matrices(N, dev)
+    ldp = ops.pad4(Cin)
+    packed = ops.empty(rows, ldp, device=dev)
+    gemm(win1d(x, B, T, 1, F, hop, N // 2, N, reflect=True), mat(Wd), packed)
+    h0 = ops.empty(rows, Cc, device=dev)
+    gemm(mat(packed, rows, Cin), mat(bv.w_in.reshape(Cc, Cin)), h0, bias=bv.b_in)
+    flags = [_limit_draw(training)]
+    xcur = ops.empty(rows, Cc, device=dev)
+    ops.biasnorm_fwd(h0, xcur, rows, Cc, bv.beta_in, bv.ls_in.reshape(1))
+    # time path (modules.py:569-573,451,485)
+    Dt, Ht = bv.Dt, bv.Ht
+    emb = ops.empty(B, Dt, device=dev)
+    ops.time_embedding(emb, t, Dt)
+    th = ops.empty(B, Ht, device=dev)
+    gemm(mat(emb), mat(bv.tw0), th, bias=bv.tb0)
+    ts = ops.empty(B, Ht, device=dev)
+    ops.silu(ts, th)
+    te = ops.empty(B, Dt, device=dev)
+    gemm(mat(ts), mat(bv.tw2), te, bias=bv.tb2)
+    tew = _stack_rows(bv.tew, Dt, dev)
+    teb = _stack_vecs(bv.teb, dev)
+    NC = bv.nblk * Cc
+    te_all = ops.empty(B, NC, device=dev)
+    gemm(mat(te), mat(tew), te_all, bias=teb)
+    Fce = cproj.shape[0] // B
+    saved_blocks = []
+    for j, bp in enumerate(bv.blks):
+        fn = _limit_draw(training)
+        y, z, a = block_fwd(bp, xcur, B, F, lens_f, cproj, NC, Fce, up, j * Cc, te_all, NC,
+                            j * Cc)
+        flags.append((fn, _limit_draw(training)))
+        if keep:
+            saved_blocks.append((xcur, z, a))
+        xcur = y
+    yspec = ops.empty(rows, ldp, device=dev)
+    gemm(mat(xcur, rows, Cc), mat(bv.w_out.reshape(Cin, Cc)), yspec, bias=bv.b_out)
+    if lens_f is not None:
+        ops.mask_rows(yspec, B, F, Cin, lens_f)
+    frames = ops.empty(rows, N, device=dev)
+    gemm(mat(yspec, rows, Cin), mat(Wi), frames)
+    ops.istft_ola(frames, pred, B, F, N, hop, T, window, wbranch_row, wscale, accumulate)
+    if keep:
+        return dict(packed=packed, h0=h0, blocks=saved_blocks, x_last=xcur, emb=emb, th=th, ts=ts,
+                    te=te, tew=tew, te_all=te_all, flags=flags, F=F)
+    return None
+
+
+def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_row, wscale,
+                     lens_f, g_x, accumulate_gx, g_cproj, need_gx):
+    n_fft, hop, up, window = meta
+    dev = g_pred.device
+    B, T = x_shape
+    N = n_fft
+    F = sv["F"]
+    rows = B * F
+    Cc, Cin = bv.C, bv.Cin
+    NC = bv.nblk * Cc
+    Wd, Wi = dft_matrices(N, dev)
+    ldp = ops.pad4(Cin)
+    Fce = cproj.shape[0] // B
+    gfr = ops.empty(rows, N, device=dev)
+    ops.istft_ola_bwd(g_pred, gfr, B, F, N, hop, T, window, wbranch_row, wscale)
+    gy = ops.empty(rows, ldp, device=dev)
+    gemm(mat(gfr, rows, N), mat(Wi), gy, form=1)
+    if lens_f is not None:
+        ops.mask_rows(gy, B, F, Cin, lens_f)
+    g_wout = ops.zeros(Cin, Cc, device=dev)
+    g_bout = ops.zeros(Cin, device=dev)
+    ops.colsum(g_bout, gy, rows, Cin)
+    x_last = sv["x_last"]
+    ops.wgrad(gy, Cin, ldp, mat(x_last, rows, Cc), g_wout)
+    g = ops.empty(rows, Cc, device=dev)
+    gemm(mat(gy, rows, Cin), mat(bv.w_out.reshape(Cin, Cc)), g, form=1)
+    g_te_all = ops.zeros(B, NC, device=dev)
+    block_grads = [None] * bv.nblk
+    flags = sv["flags"]
+    for j in reversed(range(bv.nblk)):
+        xj, z, a = sv["blocks"][j]
+        fn, fs = flags[1 + j]
+        g, gb = block_bwd(bv.blks[j], xj, z, a, g, B, F, lens_f, fn, fs, cproj, NC, Fce, up,
+                          j * Cc, sv["te_all"], NC, j * Cc, g_cproj=g_cproj, g_te=g_te_all)
+        block_grads[j] = gb
+    # in_norm / in_proj / STFT
+    g_beta = ops.zeros(Cc, device=dev)
+    g_ls = ops.zeros(1, device=dev)
+    gh0 = ops.empty(rows, Cc, device=dev)
+    ops.biasnorm_bwd(sv["h0"], g, gh0, rows, Cc, bv.beta_in, bv.ls_in.reshape(1), g_beta, g_ls)
+    if flags[0]:
+        ops.limit_grad(g_ls, bv.ls_in.reshape(1), -1.5, 1.5)
+    g_bin = ops.zeros(Cc, device=dev)
+    ops.colsum(g_bin, gh0, rows, Cc)
+    g_win = ops.zeros(Cc, Cin, device=dev)
+    ops.wgrad(gh0, Cc, gh0.stride(0), mat(sv["packed"], rows, Cin), g_win)
+    if need_gx:
+        gpacked = ops.empty(rows, ldp, device=dev)
+        gemm(mat(gh0, rows, Cc), mat(bv.w_in.reshape(Cc, Cin)), gpacked, form=1)
+        gxf = ops.empty(rows, N, device=dev)
+        gemm(mat(gpacked, rows, Cin), mat(Wd), gxf, form=1)
+        ops.frames_fold(gxf, g_x, B, F, N, hop, T, accumulate_gx)
+    # time path
+    Dt, Ht = bv.Dt, bv.Ht
+    g_tew = ops.zeros(NC, Dt, device=dev)
+    g_teb = ops.zeros(NC, device=dev)
+    ops.colsum(g_teb, g_te_all, B, NC)
+    ops.wgrad(g_te_all, NC, NC, mat(sv["te"], B, Dt), g_tew)
+    g_te = ops.empty(B, Dt, device=dev)
+    gemm(mat(g_te_all, B, NC), mat(sv["tew"]), g_te, form=1)
+    g_tb2 = ops.zeros(Dt, device=dev)
+    ops.colsum(g_tb2, g_te, B, Dt)
+    g_tw2 = ops.zeros(Dt, Ht, device=dev)
+    ops.wgrad(g_te, Dt, Dt, mat(sv["ts"], B, Ht), g_tw2)
+    g_ts = ops.empty(B, Ht, device=dev)
+    gemm(mat(g_te, B, Dt), mat(bv.tw2), g_ts, form=1)
+    g_th = ops.empty(B, Ht, device=dev)
+    ops.silu_bwd(g_th, g_ts, sv["th"])
+    g_tb0 = ops.zeros(Ht, device=dev)
+    ops.colsum(g_tb0, g_th, B, Ht)
+    g_tw0 = ops.zeros(Ht, Dt, device=dev)
+    ops.wgrad(g_th, Ht, Ht, mat(sv["emb"], B, Dt), g_tw0)
+    out = [g_win.reshape(Cc, Cin, 1), g_bin, g_ls.reshape(()), g_beta, g_tw0, g_tb0, g_tw2, g_tb2,
+           g_wout.reshape(Cin, Cc, 1), g_bout]
+    for j in range(bv.nblk):
+        out += block_grads[j]
+        out.append(g_tew[j * Cc:(j + 1) * Cc])
+        out.append(g_teb[j * Cc:(j + 1) * Cc])
+    return out
+
+
+class ModelEvalFn(torch.autograd.Function):
+    """pred (B, T) = mean_i w[i,b] * branch_i(x, cond, t)."""
+
+    @staticmethod
+    def forward(ctx, x, t, wbranch, metas, lens_cpu, training: bool, nparams, *args):
+        nb = len(metas)
+        cprojs = list(args[:nb])
+        flat = args[nb:]
+        dev = x.device
+        x = x.contiguous()
+        B, T = x.shape
+        pred = ops.empty(B, T, device=dev)
+        keep = any(ctx.needs_input_grad)
+        saved, views, lens_list = [], [], []
+        off = 0
+        for i in range(nb):
+            bv = _BranchView(list(flat[off: off + nparams[i]]))
+            off += nparams[i]
+            lens_f = frames_lens(lens_cpu, metas[i][1], dev)
+            wrow = None if wbranch is None else wbranch[i]
+            sv = _branch_forward(bv, metas[i], x, t, cprojs[i], wrow, 1.0 / nb, pred, i > 0, lens_f,
+                                 training, keep)
+            saved.append(sv)
+            views.append(bv)
+            lens_list.append(lens_f)
+        if keep:
+            ctx.saved = saved
+            ctx.views = views
+            ctx.lens = lens_list
+            ctx.x_shape = (B, T)
+            ctx.cprojs = cprojs
+            ctx.wbranch = wbranch
+            ctx.metas = metas
+            ctx.nparams = nparams
+        return pred
+
+    @staticmethod
+    def backward(ctx, g_pred):
+        nb = len(ctx.metas)
+        dev = g_pred.device
+        g_pred = g_pred.contiguous()
+        B, T = ctx.x_shape
+        need_gx = ctx.needs_input_grad[0]
+        g_x = ops.empty(B, T, device=dev) if need_gx else None
+        g_cprojs, g_flat = [], []
+        for i in range(nb):
+            cproj = ctx.cprojs[i]
+            need_gc = ctx.needs_input_grad[7 + i]
+            g_cp = ops.zeros(cproj.shape[0], cproj.shape[1], device=dev) if need_gc else None
+            wrow = None if ctx.wbranch is None else ctx.wbranch[i]
+            g_flat += _branch_backward(ctx.views[i], ctx.metas[i], ctx.saved[i], (B, T), cproj,
+                                       g_pred, wrow, 1.0 / nb, ctx.lens[i], g_x, i > 0, g_cp,
+                                       need_gx)
+            g_cprojs.append(g_cp)
+        ctx.saved = None
+        return tuple([g_x, None, None, None, None, None, None] + g_cprojs + g_flat)
+
+
+# =====================================================================================
+# Euler / interpolation steps as autograd nodes (generator.py:217,263-264)
+# =====================================================================================
+class AxpbyFn(torch.autograd.Function):
+    """y = a*x0 + b*x1 (scalars)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, a: float, b: float):
+        ctx.ab = (a, b)
+        y = torch.empty_like(x0)
+        return ops.axpby_rows(y, x0.contiguous(), x1.contiguous(), sa=a, sb=b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.ab
+        g = g.contiguous()
+        g0 = g1 = None
+        if ctx.needs_input_grad[0]:
+            g0 = ops.axpby_rows(torch.empty_like(g), g, None, sa=a)
+        if ctx.needs_input_grad[1]:
+            g1 = ops.axpby_rows(torch.empty_like(g), g, None, sa=b)
+        return g0, g1, None, None
+
+
+# =====================================================================================
+# Spectrogram helpers + stage-1 loss (generator.py:172-200, modules.py:146-214, A.7)
+# =====================================================================================
+def stft_packed(x, n_fft: int, hop: int):
+    """(B, T) -> packed rows (B*F, pad4(n_fft+2)), F = 1 + T//hop (bit-exact frame indexing:
+    frame m covers reflect-padded samples [m*hop, m*hop + n_fft))."""
+    dev = x.device
+    B, T = x.shape
+    F = 1 + T // hop
+    Wd, _ = dft_matrices(n_fft, dev)
+    packed = ops.empty(B * F, ops.pad4(n_fft + 2), device=dev)
+    gemm(win1d(x, B, T, 1, F, hop, n_fft // 2, n_fft, reflect=True), mat(Wd), packed)
+    return packed, F
+
+
+def filterbank_spec(x, n_fft: int, hop: int, fb, power: int):
+    """|STFT|^power @ fb: returns (S (B*F, n_filt), packed, spec, F)."""
+    dev = x.device
+    packed, F = stft_packed(x, n_fft, hop)
+    rows = packed.shape[0]
+    nb = n_fft // 2 + 1
+    spec = ops.empty(rows, ops.pad4(nb), device=dev)
+    ops.spec_power(spec, packed, rows, nb, power)
+    nf = fb.shape[1]
+    S = ops.empty(rows, nf, device=dev)
+    gemm(mat(spec, rows, nb), mat(fb), S, form=1)
+    return S, packed, spec, F
+
+
+def filterbank_spec_bwd(gS, packed, n_fft: int, hop: int, fb, power: int, B: int, T: int, F: int,
+                        g_x, accumulate: bool):
+    dev = gS.device
+    rows = packed.shape[0]
+    nb = n_fft // 2 + 1
+    gspec = ops.empty(rows, ops.pad4(nb), device=dev)
+    gemm(mat(gS, rows, fb.shape[1]), mat(fb), gspec, form=0)
+    gpacked = ops.empty(rows, packed.shape[1], device=dev)
+    ops.spec_power_bwd(gpacked, gspec, packed, rows, nb, power)
+    Wd, _ = dft_matrices(n_fft, dev)
+    gfr = ops.empty(rows, n_fft, device=dev)
+    gemm(mat(gpacked, rows, n_fft + 2), mat(Wd), gfr, form=1)
+    ops.frames_fold(gfr, g_x, B, F, n_fft, hop, T, accumulate)
+
+
+@torch.no_grad()
+def log_mel_forward(mel_mod, waveform):
+    """LogMelSpectrogram.forward (modules.py:140-143): (B, T) -> (B, n_mels, F)."""
+    x = waveform.contiguous()
+    squeeze = x.dim() == 1
+    if squeeze:
+        x = x[None]
+    B, T = x.shape
+    S, _, _, F = filterbank_spec(x, mel_mod.n_fft, mel_mod.hop_length, mel_mod.mel_scale.fb, 1)
+    # log(clip(., 1e-7)) fused with the transpose back to (B, n_mels, F)
+    n = mel_mod.n_mels
+    ops.log_clip_(S, 1e-7)
+    out = ops.empty(B, n, F, device=x.device)
+    ops.rows_to_bct(out, S, B, n, F)
+    return out[0] if squeeze else out
+
+
+class FmLossFn(torch.autograd.Function):
+    """Stage-1 spectrally scaled endpoint loss (generator.py:172-200)."""
+
+    @staticmethod
+    def forward(ctx, pred, x1, lens_cpu, n_fft, hop, fb, eps, power, lo, hi):
+        dev = pred.device
+        B, T = pred.shape
+        err = torch.empty_like(pred)
+        ops.axpby_rows(err, pred.contiguous(), x1.contiguous(), sa=1.0, sb=-1.0)
+        S_gt, _, _, F = filterbank_spec(x1.contiguous(), n_fft, hop, fb, 2)
+        S_err, packed_err, _, _ = filterbank_spec(err, n_fft, hop, fb, 2)
+        nf = fb.shape[1]
+        lens_f = frames_lens(lens_cpu, hop, dev)
+        if lens_cpu is not None:
+            assert F == max(1 + int(l) // hop for l in lens_cpu)
+            nmask = sum(1 + int(l) // hop for l in lens_cpu)
+        else:
+            nmask = B * F
+        loss = ops.zeros(1, device=dev)
+        w = ops.empty(B * F, nf, device=dev)
+        ops.fm_spec_loss(loss, w, S_err, S_gt, B, F, nf, lens_f, eps, power, lo, hi,
+                         1.0 / (nmask * nf))
+        ctx.saved = (w, packed_err)
+        ctx.meta = (n_fft, hop, fb, B, T, F)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        w, packed_err = ctx.saved
+        n_fft, hop, fb, B, T, F = ctx.meta
+        dev = w.device
+        g_err = ops.empty(B, T, device=dev)
+        filterbank_spec_bwd(w, packed_err, n_fft, hop, fb, 2, B, T, F, g_err, False)
+        # chain the incoming scalar on the device (no host sync)
+        flat = g_err.view(1, -1)
+        ops.axpby_rows(flat, flat, None, ca=g.reshape(1).contiguous())
+        ctx.saved = None
+        return g_err, None, None, None, None, None, None, None, None, None

@@ -1,0 +1,358 @@
+"""Thin Python wrappers over the C ABI: build descriptors, launch on the current stream.
+
+Tensors are channels-last "rows" matrices: a 2-D contiguous fp32 tensor (rows, ld) whose first
+`cols` columns are meaningful.  Nothing here computes on the host or falls back to ATen.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import DwconvBwd, DwnormBwd, DwnormFwd, Epilogue, GemmDesc, Operand, call, ptr
+
+
+def empty(*shape, device, dtype=torch.float32):
+    return torch.empty(*shape, device=device, dtype=dtype)
+
+
+def zeros(*shape, device):
+    t = torch.empty(*shape, device=device, dtype=torch.float32)
+    fill_(t, 0.0)
+    return t
+
+
+def fill_(t, v: float):
+    call("f2g_fill", ptr(t), float(v), t.numel())
+    return t
+
+
+def pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+# ------------------------------------------------------------------ operands
+def mat(t, rows: Optional[int] = None, cols: Optional[int] = None, ld: Optional[int] = None,
+        alpha=None, lrelu_src=None, slope: float = 0.0, offset: int = 0) -> Operand:
+    """Plain row-major matrix view of `t` starting `offset` floats in."""
+    if rows is None:
+        rows = t.shape[0]
+    if ld is None:
+        ld = t.stride(0) if t.dim() == 2 else (cols if cols is not None else t.shape[-1])
+    if cols is None:
+        cols = t.shape[-1]
+    o = Operand()
+    o.base = ptr(t) + 4 * offset
+    o.rows, o.cols = rows, cols
+    o.P1 = o.P0 = 1
+    o.seglen = cols
+    o.step1, o.pad1, o.L1 = 0, 0, 1
+    o.step0, o.pad0, o.unit, o.L0u = 0, 0, 1, cols
+    o.seq_stride, o.line_stride = ld, 0
+    o.reflect = 0
+    o.alpha = ptr(alpha)
+    o.lrelu_src = None if lrelu_src is None else ptr(lrelu_src) + 4 * offset
+    o.lrelu_slope = slope
+    o._keep = (t, alpha, lrelu_src)
+    return o
+
+
+def win1d(t, nseq: int, L_in: int, unit: int, L_out: int, step: int, pad: int, taps: int,
+          reflect: bool = False, seq_stride: Optional[int] = None, lrelu_src=None,
+          slope: float = 0.0, offset: int = 0) -> Operand:
+    """rows = (seq, out position); cols = taps*unit contiguous floats starting at
+    (pos*step - pad)*unit inside a sequence of L_in*unit floats (zero / reflect outside)."""
+    o = Operand()
+    o.base = ptr(t) + 4 * offset
+    o.rows, o.cols = nseq * L_out, taps * unit
+    o.P1, o.P0 = 1, L_out
+    o.seglen = taps * unit
+    o.step1, o.pad1, o.L1 = 0, 0, 1
+    o.step0, o.pad0, o.unit, o.L0u = step, pad, unit, L_in * unit
+    o.seq_stride = seq_stride if seq_stride is not None else L_in * unit
+    o.line_stride = 0
+    o.reflect = 1 if reflect else 0
+    o.alpha = None
+    o.lrelu_src = None if lrelu_src is None else ptr(lrelu_src) + 4 * offset
+    o.lrelu_slope = slope
+    o._keep = (t, lrelu_src)
+    return o
+
+
+def win2d(t, nseq: int, H: int, W: int, Cin: int, W_out: int, kh: int, kw: int, stride_w: int,
+          pad_h: int, pad_w: int, line_stride: Optional[int] = None,
+          seq_stride: Optional[int] = None, offset: int = 0, lrelu_src=None,
+          slope: float = 0.0) -> Operand:
+    """rows = (seq, h, w_out); cols = kh segments of kw*Cin contiguous floats (conv (kh,kw),
+    stride (1, stride_w)) over a channels-last image (seq, H, W, Cin)."""
+    o = Operand()
+    o.base = ptr(t) + 4 * offset
+    o.rows, o.cols = nseq * H * W_out, kh * kw * Cin
+    o.P1, o.P0 = H, W_out
+    o.seglen = kw * Cin
+    o.step1, o.pad1, o.L1 = 1, pad_h, H
+    o.step0, o.pad0, o.unit, o.L0u = stride_w, pad_w, Cin, W * Cin
+    o.line_stride = line_stride if line_stride is not None else W * Cin
+    o.seq_stride = seq_stride if seq_stride is not None else H * o.line_stride
+    o.reflect = 0
+    o.alpha = None
+    o.lrelu_src = None if lrelu_src is None else ptr(lrelu_src) + 4 * offset
+    o.lrelu_slope = slope
+    o._keep = (t, lrelu_src)
+    return o
+
+
+def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None, *, bias=None,
+         res=None, ldres: Optional[int] = None, gamma=None, aux=None, ldaux: Optional[int] = None,
+         alpha_n=None, colsum_alpha=None, colsum=None, lrelu: float = 0.0, scale: float = 0.0,
+         accumulate: bool = False, atomic: bool = False, split_k: int = 1, out_offset: int = 0,
+         rowmap=None):
+    """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None."""
+    d = GemmDesc()
+    d.A, d.B = A, Bm
+    e = Epilogue()
+    e.C = ptr(out) + 4 * out_offset
+    e.ldc = ldc if ldc is not None else out.stride(0)
+    if rowmap is not None:
+        e.P0o, e.seq_stride_o, e.row_stride_o, e.off_o = rowmap
+    else:
+        e.P0o = 0
+    e.bias = ptr(bias)
+    e.res = ptr(res)
+    e.ldres = ldres if ldres is not None else (res.stride(0) if res is not None else 0)
+    e.gamma = ptr(gamma)
+    e.aux = ptr(aux)
+    e.ldaux = ldaux if ldaux is not None else (aux.stride(0) if aux is not None else 0)
+    e.alpha_n = ptr(alpha_n)
+    e.colsum_alpha = ptr(colsum_alpha)
+    e.colsum = ptr(colsum)
+    e.lrelu_slope = lrelu
+    e.scale = scale
+    e.accumulate = 1 if accumulate else 0
+    e.atomic = 1 if atomic else 0
+    d.E = e
+    d.form = form
+    d.split_k = split_k
+    call("f2g_gemm", C.byref(d))
+    return out
+
+
+def split_for(reduction_rows: int, out_tiles: int) -> int:
+    """Split-K factor for weight-gradient GEMMs: fill ~2 waves of the 256 CUs."""
+    want = max(1, 512 // max(1, out_tiles))
+    return max(1, min(want, reduction_rows // 256 if reduction_rows >= 256 else 1))
+
+
+def wgrad(dY, M: int, ldy: int, X: Operand, g_out, ldg: Optional[int] = None, out_offset: int = 0,
+          dy_lrelu_src=None, slope: float = 0.0):
+    """g_out[m, c] += sum_r dY[r, m] * X[r, c]   (atomic split-K; g_out must be initialised)."""
+    rows = X.rows
+    A = mat(dY, rows, M, ldy, lrelu_src=dy_lrelu_src, slope=slope)
+    tiles = ((M + 127) // 128) * ((X.cols + 127) // 128)
+    gemm(A, X, g_out, form=2, ldc=ldg, atomic=True, split_k=split_for(rows, tiles),
+         out_offset=out_offset)
+
+
+# ------------------------------------------------------------------ fused block kernels
+def _dw_desc(x, ldx, z, ldz, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj, ldcp, Fc, up,
+             cp_off, te, ldte, te_off, rstd) -> DwnormFwd:
+    f = DwnormFwd()
+    f.x, f.ldx = ptr(x), ldx
+    f.z, f.ldz = ptr(z), ldz
+    f.B, f.F, f.C, f.K = B, F, Cc, K
+    f.lens = ptr(lens)
+    f.w_dw, f.b_dw, f.beta, f.log_scale = ptr(w_dw), ptr(b_dw), ptr(beta), ptr(log_scale)
+    f.cproj = None if cproj is None else ptr(cproj) + 4 * cp_off
+    f.ldcp, f.Fc, f.up = ldcp, Fc, up
+    f.te = None if te is None else ptr(te) + 4 * te_off
+    f.ldte = ldte
+    f.rstd = ptr(rstd)
+    return f
+
+
+def dwnorm_fwd(x, z, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=None, ldcp=0, Fc=0,
+               up=1, cp_off=0, te=None, ldte=0, te_off=0, rstd=None):
+    f = _dw_desc(x, x.stride(0), z, z.stride(0), B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale,
+                 cproj, ldcp, Fc, up, cp_off, te, ldte, te_off, rstd)
+    call("f2g_dwnorm_fwd", C.byref(f))
+    return z
+
+
+def dwnorm_bwd(x, gz, du, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=None, ldcp=0,
+               Fc=0, up=1, cp_off=0, te=None, ldte=0, te_off=0, g_cproj=None, g_te=None,
+               g_beta=None, g_log_scale=None):
+    d = DwnormBwd()
+    d.f = _dw_desc(x, x.stride(0), None, 0, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj,
+                   ldcp, Fc, up, cp_off, te, ldte, te_off, None)
+    d.gz, d.ldgz = ptr(gz), gz.stride(0)
+    d.du, d.lddu = ptr(du), du.stride(0)
+    d.g_cproj = None if g_cproj is None else ptr(g_cproj) + 4 * cp_off
+    d.g_te = None if g_te is None else ptr(g_te) + 4 * te_off
+    d.g_beta, d.g_log_scale = ptr(g_beta), ptr(g_log_scale)
+    call("f2g_dwnorm_bwd", C.byref(d))
+    return du
+
+
+def dwconv_bwd(du, x, gx, B, F, Cc, K, lens, w_dw, gres=None, gamma=None, g_w=None, g_b=None,
+               g_gamma=None):
+    d = DwconvBwd()
+    d.du, d.lddu = ptr(du), du.stride(0)
+    d.x, d.ldx = ptr(x), x.stride(0)
+    d.gx, d.ldgx = ptr(gx), gx.stride(0)
+    d.B, d.F, d.C, d.K = B, F, Cc, K
+    d.lens = ptr(lens)
+    d.w_dw = ptr(w_dw)
+    d.gres = ptr(gres)
+    d.ldgres = gres.stride(0) if gres is not None else 0
+    d.gamma = ptr(gamma)
+    d.g_w, d.g_b, d.g_gamma = ptr(g_w), ptr(g_b), ptr(g_gamma)
+    call("f2g_dwconv_bwd", C.byref(d))
+    return gx
+
+
+def biasnorm_fwd(x, y, rows, Cc, beta, log_scale):
+    call("f2g_biasnorm_fwd", ptr(x), x.stride(0), ptr(y), y.stride(0), rows, Cc, ptr(beta),
+         ptr(log_scale))
+    return y
+
+
+def biasnorm_bwd(x, gy, gx, rows, Cc, beta, log_scale, g_beta, g_log_scale):
+    call("f2g_biasnorm_bwd", ptr(x), x.stride(0), ptr(gy), gy.stride(0), ptr(gx), gx.stride(0),
+         rows, Cc, ptr(beta), ptr(log_scale), ptr(g_beta), ptr(g_log_scale))
+    return gx
+
+
+# ------------------------------------------------------------------ signal / elementwise
+def istft_ola(frames, out, B, F, n_fft, hop, T, window, wbranch, wscale, accumulate):
+    call("f2g_istft_ola", ptr(frames), frames.stride(0), ptr(out), B, F, n_fft, hop, T,
+         ptr(window), ptr(wbranch), float(wscale), 1 if accumulate else 0)
+
+
+def istft_ola_bwd(gout, gframes, B, F, n_fft, hop, T, window, wbranch, wscale):
+    call("f2g_istft_ola_bwd", ptr(gout), ptr(gframes), gframes.stride(0), B, F, n_fft, hop, T,
+         ptr(window), ptr(wbranch), float(wscale))
+
+
+def frames_fold(gframes, gx, B, F, n_fft, hop, T, accumulate):
+    call("f2g_frames_fold", ptr(gframes), gframes.stride(0), ptr(gx), B, F, n_fft, hop, T,
+         1 if accumulate else 0)
+
+
+def axpby_rows(y, x0, x1, ca=None, cb=None, sa=1.0, sb=1.0):
+    rows = x0.shape[0]
+    cols = x0.numel() // rows
+    call("f2g_axpby_rows", ptr(y), ptr(x0), ptr(x1), ptr(ca), ptr(cb), float(sa), float(sb), rows,
+         cols)
+    return y
+
+
+def clamp(y, x, lo, hi):
+    call("f2g_clamp", ptr(y), ptr(x), float(lo), float(hi), x.numel())
+    return y
+
+
+def silu(y, x):
+    call("f2g_silu", ptr(y), ptr(x), x.numel())
+    return y
+
+
+def silu_bwd(gx, gy, x):
+    call("f2g_silu_bwd", ptr(gx), ptr(gy), ptr(x), x.numel())
+    return gx
+
+
+def time_embedding(out, t, dim, scale=1000.0):
+    call("f2g_time_embedding", ptr(out), ptr(t), t.numel(), dim, float(scale))
+    return out
+
+
+def mask_rows(x, B, F, Cc, lens):
+    call("f2g_mask_rows", ptr(x), x.stride(0), B, F, Cc, ptr(lens))
+    return x
+
+
+def colsum(out, a, rows, cols, b=None, out_offset=0):
+    call("f2g_colsum", ptr(out) + 4 * out_offset, ptr(a), a.stride(0), ptr(b),
+         b.stride(0) if b is not None else 0, rows, cols)
+    return out
+
+
+def bct_to_rows(out, x, B, Cc, F):
+    call("f2g_bct_to_rows", ptr(out), out.stride(0), ptr(x), B, Cc, F)
+    return out
+
+
+def rows_to_bct(out, x, B, Cc, F):
+    call("f2g_rows_to_bct", ptr(out), ptr(x), x.stride(0), B, Cc, F)
+    return out
+
+
+def permute4(out, x, dims, strides, in_offset=0):
+    n0, n1, n2, n3 = dims
+    s0, s1, s2, s3 = strides
+    call("f2g_permute4", ptr(out), ptr(x) + 4 * in_offset, n0, n1, n2, n3, s0, s1, s2, s3)
+    return out
+
+
+def copy3(out, so0, so1, x, si0, si1, n0, n1, n2, accumulate=False, out_offset=0, in_offset=0):
+    call("f2g_copy3", ptr(out) + 4 * out_offset, so0, so1, ptr(x) + 4 * in_offset, si0, si1, n0,
+         n1, n2, 1 if accumulate else 0)
+    return out
+
+
+def spec_power(out, packed, rows, nb, power):
+    call("f2g_spec_power", ptr(out), out.stride(0), ptr(packed), packed.stride(0), rows, nb, power)
+    return out
+
+
+def spec_power_bwd(gpacked, gout, packed, rows, nb, power):
+    call("f2g_spec_power_bwd", ptr(gpacked), gpacked.stride(0), ptr(gout), gout.stride(0),
+         ptr(packed), rows, nb, power)
+    return gpacked
+
+
+def fm_spec_loss(loss, g_err, s_err, s_gt, B, F, nf, lens, eps, power, lo, hi, inv_denom):
+    call("f2g_fm_spec_loss", ptr(loss), ptr(g_err), ptr(s_err), ptr(s_gt), B, F, nf, ptr(lens),
+         float(eps), float(power), float(lo), float(hi), float(inv_denom))
+
+
+def l1_loss(loss, gb, a, b, n, w, clip=0.0, loss_offset=0):
+    call("f2g_l1_loss", ptr(loss) + 4 * loss_offset, ptr(gb), ptr(a), ptr(b), n, float(w),
+         float(clip))
+
+
+def hinge_loss(loss, gs, s, n, sgn, w, loss_offset=0):
+    call("f2g_hinge_loss", ptr(loss) + 4 * loss_offset, ptr(gs), ptr(s), n, float(sgn), float(w))
+
+
+def peaknorm_fwd(y, stats, x, rows, T):
+    call("f2g_peaknorm_fwd", ptr(y), ptr(stats), ptr(x), rows, T)
+
+
+def peaknorm_bwd(gx, gy, x, stats, rows, T):
+    call("f2g_peaknorm_bwd", ptr(gx), ptr(gy), ptr(x), ptr(stats), rows, T)
+
+
+def lrelu_bwd(g, y_act, f_real, w, slope, n, g_off=0, y_off=0, r_off=0):
+    call("f2g_lrelu_bwd", ptr(g) + 4 * g_off, ptr(y_act) + 4 * y_off,
+         None if f_real is None else ptr(f_real) + 4 * r_off, float(w), float(slope), n)
+
+
+def period_fold(out, x, B, T, p, H):
+    call("f2g_period_fold", ptr(out), ptr(x), B, T, p, H)
+
+
+def period_fold_bwd(gx, gout, B, T, p, H, accumulate):
+    call("f2g_period_fold_bwd", ptr(gx), ptr(gout), B, T, p, H, 1 if accumulate else 0)
+
+
+def limit_grad(g, p, lo, hi):
+    call("f2g_limit_grad", ptr(g), ptr(p), float(lo), float(hi), g.numel())
+    return g
+
+
+def log_clip_(x, clip=1e-7):
+    call("f2g_log_clip", ptr(x), x.numel(), float(clip))
+    return x

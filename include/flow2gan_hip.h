@@ -1,0 +1,298 @@
+/*
+ * flow2gan_hip.h -- C ABI of libflow2gan_hip.so (gfx950 / MI355X).
+ *
+ * The reference (k2-fsa/Flow2GAN) has no FFI layer: its hot path is Python calling ATen
+ * ops.  This header is the boundary a maintainer would bind instead (ctypes stub in
+ * INTEGRATION.md).  Every entry point
+ *   - takes raw DEVICE pointers + explicit sizes, no torch types;
+ *   - enqueues on the caller's hipStream_t and returns immediately (no allocation, no sync);
+ *   - returns 0 on success, a negative F2G_E* code otherwise (never throws);
+ *   - computes in fp32 (the reference's precision, run_libritts.sh:152 `--use-fp16 0`).
+ *
+ * Activation layout is CHANNELS-LAST: a (batch, channels, frames) tensor of the reference is
+ * held as rows = batch*frames, cols = channels (row stride `ld` floats).  Audio is (batch, T)
+ * and the mel condition is (batch, n_mels, frames) exactly as the reference passes them.
+ *
+ * Each declaration cites the reference code (file:line under /root/reference) it replaces.
+ */
+#ifndef FLOW2GAN_HIP_H
+#define FLOW2GAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* f2g_stream_t; /* hipStream_t */
+
+enum {
+  F2G_OK = 0,
+  F2G_EINVAL = -1,  /* bad argument / unsupported shape */
+  F2G_ELAUNCH = -2, /* hipGetLastError() after launch was not hipSuccess */
+};
+
+/* Library identification: "flow2gan_hip <version> gfx950". */
+const char* f2g_version(void);
+/* Text of the last hip error seen by this library (thread-unsafe, diagnostics only). */
+const char* f2g_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM operand: a matrix whose rows are "pixels" and whose columns are a contiguous
+ * window of the channels-last source -- i.e. an im2col view that is never materialised.
+ *   row r  -> (s, p1, p0) with r = (s*P1 + p1)*P0 + p0
+ *   col c  -> (seg, o)    with seg = c / seglen, o = c % seglen
+ *   line   l1 = p1*step1 - pad1 + seg          valid iff 0 <= l1 < L1
+ *   offset e  = (p0*step0 - pad0)*unit + o     valid iff 0 <= e < L0u   (or reflected)
+ *   addr   = base + s*seq_stride + l1*line_stride + e
+ * Invalid elements read as 0.  A plain row-major matrix is {P1=P0=1, seglen=cols, L1=1,
+ * L0u=cols, seq_stride=ld}.  With `alpha` set, PReLU(alpha[c]) is applied on load
+ * (modules.py:444,488); with `lrelu_src` set the element is multiplied by the leaky-ReLU
+ * derivative of lrelu_src at the same address (discriminators.py:94,205 backward).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* base;
+  int32_t rows, cols;
+  int32_t P1, P0;
+  int32_t seglen;
+  int32_t step1, pad1, L1;
+  int32_t step0, pad0, unit, L0u;
+  int64_t seq_stride, line_stride;
+  int32_t reflect;
+  int32_t _pad;
+  const float* alpha;
+  const float* lrelu_src;
+  float lrelu_slope;
+  int32_t _pad2;
+} f2g_operand;
+
+/* Epilogue of f2g_gemm: v = acc (+bias[n]) (+gamma[n]*res[r,n]); optional PReLU-derivative
+ * against `aux` with column sums for d(alpha); optional leaky-ReLU; optional column sums of
+ * the stored value (bias gradient); store / accumulate / atomic-add into C with the row map
+ *   r -> (P0o ? (r / P0o)*seq_stride_o + (r % P0o)*row_stride_o + off_o : r*ldc). */
+typedef struct {
+  float* C;
+  int64_t ldc;
+  int32_t P0o, _pad;
+  int64_t seq_stride_o, row_stride_o, off_o;
+  const float* bias;
+  const float* res;
+  int64_t ldres;
+  const float* gamma;
+  const float* aux; /* pre-activation a[r,n]: v *= (a > 0 ? 1 : alpha_n[n]) */
+  int64_t ldaux;
+  const float* alpha_n;
+  float* colsum_alpha; /* += sum_r acc * min(a, 0)   (d PReLU slope) */
+  float* colsum;       /* += sum_r v                 (d bias) */
+  float lrelu_slope;   /* != 0: v = v > 0 ? v : slope*v */
+  float scale;         /* v *= scale before everything else if != 0 (0 means 1) */
+  int32_t accumulate;  /* C += v */
+  int32_t atomic;      /* atomicAdd(C, v) (split-K / shared gradients) */
+} f2g_epilogue;
+
+/* form: 0 = C[r,n] = sum_k A[r,k] * B[n,k]   (forward; B = weights [n][k])
+ *       1 = C[r,n] = sum_k A[r,k] * B[k,n]   (data gradient; B = weights [k][n])
+ *       2 = C[m,n] = sum_r A[r,m] * B[r,n]   (weight gradient; reduction over rows, split_k>=1)
+ * Replaces torch conv1d/conv2d/matmul/linear + their backward on the hot path
+ * (modules.py:443-451,487-489,511,563,576-580,593; discriminators.py:65-76,171-184;
+ *  modules.py:69-78,106-115 as DFT matrices; modules.py:213, gan.py:47-54 filterbanks). */
+typedef struct {
+  f2g_operand A, B;
+  f2g_epilogue E;
+  int32_t form;
+  int32_t split_k;
+} f2g_gemm_desc;
+
+int f2g_gemm(const f2g_gemm_desc* d, f2g_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused depthwise-conv(k=7) + BiasNorm + cond add + time scale  (modules.py:473-485, A.4):
+ *   u = dwconv7(x * mask) + b_dw ; v = u * mean_c((u-beta)^2)^-1/2 * exp(log_scale)
+ *   z = (v + cproj[row/up, :]) * (1 + te[b, :])
+ * x, z: (B*F rows, C) channels-last.  lens (int32, per batch item, frames) may be NULL (no mask).
+ * cproj (may be NULL): rows B*Fc, frame f reads row min(f/up, ...) and 0 beyond Fc*up.
+ * te (may be NULL): (B, ld_te).   w_dw: (C,1,7) as in the checkpoint, b_dw: (C).
+ * rinv (optional out, B*F): the per-row normaliser s, saved for backward.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x;
+  int64_t ldx;
+  float* z;
+  int64_t ldz;
+  int32_t B, F, C, K; /* K = taps (odd, <= 7) */
+  const int32_t* lens;
+  const float* w_dw;
+  const float* b_dw;
+  const float* beta;
+  const float* log_scale;
+  const float* cproj;
+  int64_t ldcp;
+  int32_t Fc, up;
+  const float* te;
+  int64_t ldte;
+  float* rstd; /* (B*F) out: s = r^-1/2 * exp(log_scale) */
+} f2g_dwnorm_fwd_desc;
+int f2g_dwnorm_fwd(const f2g_dwnorm_fwd_desc* d, f2g_stream_t stream);
+
+/* Backward of the above (A.3/A.4).  Given gz = dL/dz:
+ *   g_cproj[row/up,:] += gz*(1+te)       (atomic; may be NULL)
+ *   g_te[b,:]        += sum_f gz*(v+cproj)   (atomic; may be NULL)
+ *   du (out, B*F x C): gradient w.r.t. the dwconv output u
+ *   g_beta[C], g_log_scale[1] += ...      (atomic)
+ * then f2g_dwconv_bwd turns du into dx (+= into gx with the residual path) and dw/db. */
+typedef struct {
+  f2g_dwnorm_fwd_desc f; /* same tensors as forward (z unused) */
+  const float* gz;
+  int64_t ldgz;
+  float* du;
+  int64_t lddu;
+  float* g_cproj;
+  float* g_te;
+  float* g_beta;
+  float* g_log_scale;
+} f2g_dwnorm_bwd_desc;
+int f2g_dwnorm_bwd(const f2g_dwnorm_bwd_desc* d, f2g_stream_t stream);
+
+/* dx[c,t] (+)= mask * sum_j w[c,j] du[c,t-j+pad] (+ gamma[c]*gres[c,t]);
+ * g_w[c,j] += sum du[c,t]*xm[c,t+j-pad]; g_b[c] += sum du; g_gamma[c] += sum gres*x. */
+typedef struct {
+  const float* du;
+  int64_t lddu;
+  const float* x;
+  int64_t ldx;
+  float* gx;
+  int64_t ldgx;
+  int32_t B, F, C, K;
+  const int32_t* lens;
+  const float* w_dw;
+  const float* gres; /* gradient of the block output (residual path), may be NULL */
+  int64_t ldgres;
+  const float* gamma; /* ChannelScale (C), may be NULL */
+  float* g_w;
+  float* g_b;
+  float* g_gamma;
+} f2g_dwconv_bwd_desc;
+int f2g_dwconv_bwd(const f2g_dwconv_bwd_desc* d, f2g_stream_t stream);
+
+/* BiasNorm alone (modules.py:286-416), channels-last, in place allowed (y may equal x). */
+int f2g_biasnorm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows, int32_t C,
+                     const float* beta, const float* log_scale, f2g_stream_t stream);
+/* gx = BiasNorm'(x)^T gy; g_beta, g_log_scale accumulated atomically. */
+int f2g_biasnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy, float* gx,
+                     int64_t ldgx, int32_t rows, int32_t C, const float* beta,
+                     const float* log_scale, float* g_beta, float* g_log_scale,
+                     f2g_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * iSTFT tail (modules.py:106-115,719 + generator.py:165-168,263-264): overlap-add of windowed
+ * inverse-DFT frames (B*F rows of n_fft samples, produced by f2g_gemm with the inverse-DFT
+ * matrix), divide by the window envelope, trim n_fft/2, fit to T, then
+ *   out[b,t] (=|+=) wbranch[b] * y[b,t]
+ * so that the three branches accumulate their mean (and branch dropout weights) in place.
+ * ---------------------------------------------------------------------------------------- */
+int f2g_istft_ola(const float* frames, int64_t ldf, float* out, int32_t B, int32_t F,
+                  int32_t n_fft, int32_t hop, int32_t T, const float* window,
+                  const float* wbranch, float wscale, int32_t accumulate, f2g_stream_t stream);
+/* Backward: gframes[b,m,n] = gout[b, m*hop+n-n_fft/2] / env * wbranch[b]*wscale (the synthesis
+ * window itself is folded into the inverse-DFT matrix). */
+int f2g_istft_ola_bwd(const float* gout, float* gframes, int64_t ldf, int32_t B, int32_t F,
+                      int32_t n_fft, int32_t hop, int32_t T, const float* window,
+                      const float* wbranch, float wscale, f2g_stream_t stream);
+/* Fold the gradient of reflect-padded STFT frames back onto the signal (A.1 backward):
+ * gx[b,t] (+)= sum over frames/taps of gframes[b,m,n] mapped through the reflect padding. */
+int f2g_frames_fold(const float* gframes, int64_t ldf, float* gx, int32_t B, int32_t F,
+                    int32_t n_fft, int32_t hop, int32_t T, int32_t accumulate,
+                    f2g_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / reductions used by the flow-matching step and the losses.
+ * ---------------------------------------------------------------------------------------- */
+/* y = a*x0 + b*x1 with per-row (per batch item) coefficients: a = ca[i] or sa, b = cb[i] or sb
+ * (generator.py:217 interpolation, :263-264 Euler update). */
+int f2g_axpby_rows(float* y, const float* x0, const float* x1, const float* ca, const float* cb,
+                   float sa, float sb, int32_t rows, int32_t cols, f2g_stream_t stream);
+/* y = clamp(x, lo, hi) (generator.py:268-269) */
+int f2g_clamp(float* y, const float* x, float lo, float hi, int64_t n, f2g_stream_t stream);
+/* SiLU forward / backward (modules.py:571) */
+int f2g_silu(float* y, const float* x, int64_t n, f2g_stream_t stream);
+int f2g_silu_bwd(float* gx, const float* gy, const float* x, int64_t n, f2g_stream_t stream);
+/* Sinusoidal time embedding (modules.py:217-232): out (B, dim) = [sin | cos](scale*t*f_k). */
+int f2g_time_embedding(float* out, const float* t, int32_t B, int32_t dim, float scale,
+                       f2g_stream_t stream);
+/* Zero frames >= lens[b] of a channels-last tensor (modules.py:714-715). */
+int f2g_mask_rows(float* x, int64_t ld, int32_t B, int32_t F, int32_t C, const int32_t* lens,
+                  f2g_stream_t stream);
+/* out[c] (+)= sum_r a[r,c] (* b[r,c] if b) */
+int f2g_colsum(float* out, const float* a, int64_t lda, const float* b, int64_t ldb, int32_t rows,
+               int32_t cols, f2g_stream_t stream);
+/* out[(b*Fc + f/up), c] += g[(b*F+f), c]  (gradient of the repeat-interleave, modules.py:676-678) */
+int f2g_rows_fold_up(float* out, int64_t ldo, const float* g, int64_t ldg, int32_t B, int32_t F,
+                     int32_t Fc, int32_t up, int32_t C, f2g_stream_t stream);
+/* (B, C, F) <-> (B*F, C) transposes at the boundary (mel condition in, features out). */
+int f2g_bct_to_rows(float* out, int64_t ldo, const float* in, int32_t B, int32_t C, int32_t F,
+                    f2g_stream_t stream);
+int f2g_rows_to_bct(float* out, const float* in, int64_t ldi, int32_t B, int32_t C, int32_t F,
+                    f2g_stream_t stream);
+/* Generic strided 4-d permutation copy: out[i0,i1,i2,i3] (contiguous) = in[sum i_k*stride_k]
+ * (weight re-layout (Cout,Cin,kh,kw) <-> [Cout][kh][kw][Cin], einops rearrange at
+ * discriminators.py:193). */
+int f2g_permute4(float* out, const float* in, int32_t n0, int32_t n1, int32_t n2, int32_t n3,
+                 int64_t s0, int64_t s1, int64_t s2, int64_t s3, f2g_stream_t stream);
+
+/* LimitParamValue backward (modules.py:236-256): g = -g where (g>0 & p<lo), then where (g<0 & p>hi). */
+int f2g_limit_grad(float* g, const float* p, float lo, float hi, int64_t n, f2g_stream_t stream);
+/* Strided 3-d block copy / accumulate: out[b*so0 + r*so1 + c] (+)= in[b*si0 + r*si1 + c]
+ * (condition rows fitted to the branch frame count, modules.py:679; stacking per-block weights). */
+int f2g_copy3(float* out, int64_t so0, int64_t so1, const float* in, int64_t si0, int64_t si1,
+              int32_t n0, int32_t n1, int32_t n2, int32_t accumulate, f2g_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss kernels.
+ * ---------------------------------------------------------------------------------------- */
+/* Spectrogram magnitude from packed DFT rows [Re(0..nb-1) | Im(0..nb-1)] (ld):
+ * out[r,k] = (re^2+im^2)^(power/2), power in {1,2}  (torchaudio Spectrogram, modules.py:180-192,
+ * gan.py:47-54).  Backward: gpacked = gout * d|.|^p. */
+int f2g_spec_power(float* out, int64_t ldo, const float* packed, int64_t ldp, int32_t rows,
+                   int32_t nb, int32_t power, f2g_stream_t stream);
+int f2g_spec_power_bwd(float* gpacked, int64_t ldp, const float* gout, int64_t ldo,
+                       const float* packed, int32_t rows, int32_t nb, int32_t power,
+                       f2g_stream_t stream);
+/* Stage-1 loss (generator.py:186-199, A.7): given S_err, S_gt (rows=B*F, n_filt cols) and lens
+ * (frames): loss += sum mask * S_err * clamp((S_gt+eps)^-p, lo, hi) * inv_denom;
+ * g_err = mask * clamp(...) * inv_denom * gscale (optional). */
+int f2g_fm_spec_loss(float* loss, float* g_err, const float* s_err, const float* s_gt, int32_t B,
+                     int32_t F, int32_t n_filt, const int32_t* lens, float eps, float power,
+                     float lo, float hi, float inv_denom, f2g_stream_t stream);
+/* loss += w * sum |log(max(a,clip)) - log(max(b,clip))| ; gb = -w*sign(.)/max(b,clip) where b>clip
+ * (gan.py:89-99 with utils.py:221-232).  clip <= 0 means plain L1 |a-b| (gan.py:77-87). */
+int f2g_l1_loss(float* loss, float* gb, const float* a, const float* b, int64_t n, float w,
+                float clip, f2g_stream_t stream);
+/* Hinge terms (gan.py:57-75): loss += w * sum relu(1 + sgn*s); gs = w*sgn where active. */
+int f2g_hinge_loss(float* loss, float* gs, const float* s, int64_t n, float sgn, float w,
+                   f2g_stream_t stream);
+/* DiscriminatorR input conditioning (discriminators.py:186-190): y = 0.8*(x-mean)/(max|x-mean|+1e-9)
+ * per row; stats (rows,3) = {mean, peak, argmax index} kept for backward. */
+int f2g_peaknorm_fwd(float* y, float* stats, const float* x, int32_t rows, int32_t T,
+                     f2g_stream_t stream);
+int f2g_peaknorm_bwd(float* gx, const float* gy, const float* x, const float* stats, int32_t rows,
+                     int32_t T, f2g_stream_t stream);
+/* y[r, c] = x[r, c] * (y_act[r,c] > 0 ? 1 : slope)  (leaky-ReLU backward, in place allowed)
+ * plus optional feature-matching term: g += w * sign(f_fake - f_real) before the mask. */
+int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w, float slope,
+                  int64_t n, f2g_stream_t stream);
+/* MPD input shaping (discriminators.py:82-90): right reflect-pad to a multiple of p and lay the
+ * (B,1,T'/p,p) image out channels-last per column: out[((b*p + w)*H + h)] = x[b, h*p + w].
+ * Backward folds it back (gx +=). */
+int f2g_period_fold(float* out, const float* x, int32_t B, int32_t T, int32_t p, int32_t H,
+                    f2g_stream_t stream);
+int f2g_period_fold_bwd(float* gx, const float* gout, int32_t B, int32_t T, int32_t p, int32_t H,
+                        int32_t accumulate, f2g_stream_t stream);
+/* x = log(max(x, clip)) in place (utils.py:221-232 safe_log) */
+int f2g_log_clip(float* x, int64_t n, float clip, f2g_stream_t stream);
+/* fill */
+int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOW2GAN_HIP_H */

@@ -1,0 +1,434 @@
+"""GPU parity of every C-ABI kernel against plain PyTorch fp32/fp64 references on CPU.
+
+Tolerances: the GEMMs use exact-fp32 MFMA (k-ordered fmaf chains), so results differ from a
+CPU fp32 reference only by summation order: relative 2e-5 of the result scale is the bar.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from flow2gan_amd import ops as o
+    return o
+
+
+DEV = "cuda"
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+def close(got, want, rtol=2e-5, name=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale + 1e-30, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ------------------------------------------------------------------ GEMM forms
+@pytest.mark.parametrize("R,K,N", [(300, 514, 96), (128, 32, 128), (1000, 48, 24), (77, 130, 130),
+                                   (5, 512, 1536), (2050, 72, 40)])
+def test_gemm_forward_plain(ops, R, K, N):
+    A, W, b = rnd(R, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    out = torch.empty(R, N, device=DEV)
+    ops.gemm(ops.mat(g(A)), ops.mat(g(W)), out, bias=g(b))
+    close(out, A.double() @ W.double().t() + b.double(), name="fwd")
+
+
+def test_gemm_forward_epilogues(ops):
+    R, K, N = 257, 96, 160
+    A, W, b = rnd(R, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    res, gam, alpha = rnd(R, N, seed=4), rnd(N, seed=5), rnd(K, seed=6) * 0.3
+    out = torch.empty(R, N, device=DEV)
+    ops.gemm(ops.mat(g(A), alpha=g(alpha)), ops.mat(g(W)), out, bias=g(b), res=g(res), gamma=g(gam))
+    Ap = torch.where(A > 0, A, A * alpha[None])
+    close(out, Ap.double() @ W.double().t() + b.double() + gam.double() * res.double(), name="res")
+    out2 = torch.empty(R, N, device=DEV)
+    ops.gemm(ops.mat(g(A)), ops.mat(g(W)), out2, bias=g(b), lrelu=0.1)
+    close(out2, F.leaky_relu(A.double() @ W.double().t() + b.double(), 0.1), name="lrelu")
+    # padded leading dimension on input and output
+    Ap4 = torch.zeros(R, K + 4)
+    Ap4[:, :K] = A
+    out3 = torch.full((R, N + 4), 7.0, device=DEV)
+    ops.gemm(ops.mat(g(Ap4), R, K), ops.mat(g(W)), out3)
+    close(out3[:, :N], A.double() @ W.double().t(), name="ld")
+    assert float(out3[:, N:].min()) == 7.0
+
+
+@pytest.mark.parametrize("R,K,N", [(300, 96, 514), (64, 1536, 512), (1000, 24, 72)])
+def test_gemm_dgrad_with_prelu_grad(ops, R, K, N):
+    G, W = rnd(R, K, seed=1), rnd(K, N, seed=2)
+    aux, alpha = rnd(R, N, seed=3), rnd(N, seed=4) * 0.3
+    out = torch.empty(R, N, device=DEV)
+    cs_a = torch.zeros(N, device=DEV)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm(ops.mat(g(G)), ops.mat(g(W)), out, form=1, aux=g(aux), alpha_n=g(alpha),
+             colsum_alpha=cs_a, colsum=cs)
+    dp = G.double() @ W.double()
+    want = dp * torch.where(aux > 0, torch.ones_like(aux), alpha[None].expand_as(aux)).double()
+    close(out, want, name="dgrad")
+    close(cs, want.sum(0), rtol=1e-4, name="colsum")
+    close(cs_a, (dp * aux.clamp(max=0).double()).sum(0), rtol=1e-4, name="colsum_alpha")
+    # in place over aux
+    auxd = g(aux)
+    ops.gemm(ops.mat(g(G)), ops.mat(g(W)), auxd, form=1, aux=auxd, alpha_n=g(alpha))
+    close(auxd, want, name="dgrad-inplace")
+
+
+@pytest.mark.parametrize("R,M,N", [(3000, 96, 40), (700, 514, 48), (5000, 32, 864), (130, 1536, 512)])
+def test_gemm_wgrad_splitk(ops, R, M, N):
+    dY, X = rnd(R, M, seed=1), rnd(R, N, seed=2)
+    alpha = rnd(N, seed=3) * 0.3
+    out = torch.zeros(M, N, device=DEV)
+    ops.wgrad(g(dY), M, M, ops.mat(g(X), alpha=g(alpha)), out)
+    Xp = torch.where(X > 0, X, X * alpha[None])
+    close(out, dY.double().t() @ Xp.double(), rtol=1e-4, name="wgrad")
+
+
+# ------------------------------------------------------------------ windowed operands
+@pytest.mark.parametrize("n_fft,hop,T", [(512, 256, 6000), (128, 64, 4097), (1024, 256, 6000),
+                                         (32, 8, 1000), (2048, 512, 6000)])
+def test_stft_as_windowed_gemm(ops, n_fft, hop, T):
+    from flow2gan_amd.fused import stft_packed
+    x = rnd(3, T, seed=5, scale=0.1)
+    packed, Fr = stft_packed(g(x), n_fft, hop)
+    spec = torch.stft(x.double(), n_fft, hop, n_fft, torch.hann_window(n_fft).double(), center=True,
+                      return_complex=True)  # (B, nb, F)
+    assert Fr == spec.shape[2] == 1 + T // hop  # frame indexing is exact
+    nb = n_fft // 2 + 1
+    want = torch.cat([spec.real, spec.imag], 1).permute(0, 2, 1).reshape(3 * Fr, 2 * nb)
+    close(packed[:, :2 * nb], want, rtol=3e-5, name="stft")
+
+
+def test_conv1d_k3_windowed(ops):
+    B, Cin, Fm, Cout = 3, 100, 37, 64
+    x, w, b = rnd(B, Cin, Fm, seed=1), rnd(Cout, Cin, 3, seed=2), rnd(Cout, seed=3)
+    rows = torch.empty(B * Fm, Cin, device=DEV)
+    ops.bct_to_rows(rows, g(x), B, Cin, Fm)
+    close(rows, x.permute(0, 2, 1).reshape(B * Fm, Cin), name="bct_to_rows")
+    wp = torch.empty(Cout, 3 * Cin, device=DEV)
+    ops.permute4(wp, g(w), (Cout, 3, Cin, 1), (Cin * 3, 1, 3, 0))
+    out = torch.empty(B * Fm, Cout, device=DEV)
+    ops.gemm(ops.win1d(rows, B, Fm, Cin, Fm, 1, 1, 3), ops.mat(wp), out, bias=g(b))
+    want = F.conv1d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 1).reshape(B * Fm, Cout)
+    close(out, want, name="conv1d")
+    back = torch.empty(B, Cout, Fm, device=DEV)
+    ops.rows_to_bct(back, out, B, Cout, Fm)
+    close(back, F.conv1d(x.double(), w.double(), b.double(), padding=1), name="rows_to_bct")
+
+
+@pytest.mark.parametrize("Cin,Cout,H,stride", [(1, 32, 100, 3), (32, 128, 67, 3), (16, 8, 40, 1)])
+def test_conv_period_stride3(ops, Cin, Cout, H, stride):
+    """MPD (5,1) conv, stride (3,1): sequences = (batch, column) pairs."""
+    S = 6
+    Hout = (H + 4 - 5) // stride + 1
+    x, w, b = rnd(S, H, Cin, seed=1), rnd(Cout, Cin, 5, seed=2), rnd(Cout, seed=3)
+    wp = torch.empty(Cout, 5 * Cin, device=DEV)
+    ops.permute4(wp, g(w), (Cout, 5, Cin, 1), (Cin * 5, 1, 5, 0))
+    out = torch.empty(S * Hout, Cout, device=DEV)
+    ops.gemm(ops.win1d(g(x), S, H, Cin, Hout, stride, 2, 5), ops.mat(wp), out, bias=g(b), lrelu=0.1)
+    want = F.leaky_relu(F.conv1d(x.permute(0, 2, 1).double(), w.double(), b.double(), stride=stride,
+                                 padding=2), 0.1).permute(0, 2, 1).reshape(S * Hout, Cout)
+    close(out, want, name="mpd-conv")
+
+
+@pytest.mark.parametrize("Cin,Cout,kw,sw", [(2, 32, 9, 1), (32, 32, 9, 2), (32, 32, 3, 1), (32, 1, 3, 1)])
+def test_conv2d_band_windowed(ops, Cin, Cout, kw, sw):
+    """MRD (3,kw) conv over (time, freq) with stride (1,sw) on a frequency slice of a wider image."""
+    B, H, Wtot, lo, hi = 2, 11, 50, 7, 41
+    W = hi - lo
+    pw = kw // 2
+    Wout = (W + 2 * pw - kw) // sw + 1
+    img = rnd(B, H, Wtot, Cin, seed=1)
+    w, b = rnd(Cout, Cin, 3, kw, seed=2), rnd(Cout, seed=3)
+    wp = torch.empty(Cout, 3 * kw * Cin, device=DEV)
+    ops.permute4(wp, g(w), (Cout, 3 * kw, Cin, 1), (Cin * 3 * kw, 1, 3 * kw, 0))
+    out = torch.empty(B * H * Wout, Cout, device=DEV)
+    A = ops.win2d(g(img), B, H, W, Cin, Wout, 3, kw, sw, 1, pw, line_stride=Wtot * Cin,
+                  seq_stride=H * Wtot * Cin, offset=lo * Cin)
+    ops.gemm(A, ops.mat(wp), out, bias=g(b))
+    xin = img[:, :, lo:hi].permute(0, 3, 1, 2).double()
+    want = F.conv2d(xin, w.double(), b.double(), stride=(1, sw), padding=(1, pw))
+    close(out, want.permute(0, 2, 3, 1).reshape(B * H * Wout, Cout), name="mrd-conv")
+
+
+# ------------------------------------------------------------------ ConvNeXt block kernels
+def _block_ref(x, lens, w_dw, b_dw, beta, ls, cproj, up, te):
+    """x (B,C,F) -> z (B,C,F) in fp64: dwconv(x*mask) -> BiasNorm -> +cond -> *(1+te)."""
+    B, C, Fr = x.shape
+    mask = (torch.arange(Fr)[None] < lens[:, None]).double()[:, None]
+    u = F.conv1d(x * mask, w_dw, b_dw, padding=w_dw.shape[-1] // 2, groups=C)
+    s = ((u - beta[None, :, None]) ** 2).mean(1, keepdim=True) ** -0.5 * ls.exp()
+    v = u * s
+    if cproj is not None:
+        cu = torch.repeat_interleave(cproj, up, dim=2)[:, :, :Fr]
+        v = v + cu
+    if te is not None:
+        v = v * (1 + te[:, :, None])
+    return v
+
+
+@pytest.mark.parametrize("C,Fr,up,K", [(48, 47, 2, 7), (24, 94, 4, 7), (768, 24, 1, 7), (32, 33, 1, 5)])
+def test_dwnorm_fwd_bwd(ops, C, Fr, up, K):
+    B = 3
+    Fc = (Fr + up - 1) // up
+    x = rnd(B, C, Fr, seed=1).double().requires_grad_()
+    lens = torch.tensor([Fr, Fr - 5, max(1, Fr // 2)])
+    w_dw = (rnd(C, 1, K, seed=2) * 0.3).double().requires_grad_()
+    b_dw = (rnd(C, seed=3) * 0.1).double().requires_grad_()
+    beta = (rnd(C, seed=4) * 0.1).double().requires_grad_()
+    ls = torch.tensor(0.7, dtype=torch.double, requires_grad=True)
+    cproj = rnd(B, C, Fc, seed=5).double().requires_grad_()
+    te = (rnd(B, C, seed=6) * 0.3).double().requires_grad_()
+    z = _block_ref(x, lens, w_dw, b_dw, beta, ls, cproj, up, te)
+    gz = rnd(B, C, Fr, seed=7).double()
+    z.backward(gz)
+
+    def rows(t):  # (B,C,F) -> (B*F, C) fp32 on device
+        return g(t.detach().float().permute(0, 2, 1).reshape(-1, t.shape[1]))
+
+    xr, lens_d = rows(x), g(lens.int())
+    NC = 2 * C  # place this block's slice in the middle of a wider stacked buffer
+    cp_all = torch.zeros(B * Fc, NC, device=DEV)
+    cp_all[:, C // 2: C // 2 + C] = rows(cproj)
+    te_all = torch.zeros(B, NC, device=DEV)
+    te_all[:, C // 2: C // 2 + C] = g(te.detach().float())
+    zr = torch.empty(B * Fr, C, device=DEV)
+    args = (B, Fr, C, K, lens_d, g(w_dw.detach().float()), g(b_dw.detach().float()),
+            g(beta.detach().float()), g(ls.detach().float().reshape(1)))
+    ops.dwnorm_fwd(xr, zr, *args, cp_all, NC, Fc, up, C // 2, te_all, NC, C // 2)
+    close(zr, z.detach().permute(0, 2, 1).reshape(-1, C), name="dwnorm_fwd")
+
+    du = torch.empty(B * Fr, C, device=DEV)
+    g_cp = torch.zeros(B * Fc, NC, device=DEV)
+    g_te = torch.zeros(B, NC, device=DEV)
+    g_beta = torch.zeros(C, device=DEV)
+    g_ls = torch.zeros(1, device=DEV)
+    ops.dwnorm_bwd(xr, rows(gz), du, *args, cp_all, NC, Fc, up, C // 2, te_all, NC, C // 2,
+                   g_cproj=g_cp, g_te=g_te, g_beta=g_beta, g_log_scale=g_ls)
+    close(g_cp[:, C // 2: C // 2 + C], cproj.grad.permute(0, 2, 1).reshape(-1, C), rtol=1e-4, name="g_cproj")
+    assert float(g_cp[:, :C // 2].abs().max()) == 0.0
+    close(g_te[:, C // 2: C // 2 + C], te.grad, rtol=1e-4, name="g_te")
+    close(g_beta, beta.grad, rtol=2e-4, name="g_beta")
+    close(g_ls, ls.grad.reshape(1), rtol=2e-4, name="g_log_scale")
+    gx = torch.empty(B * Fr, C, device=DEV)
+    gres = rnd(B * Fr, C, seed=8)
+    gam = rnd(C, seed=9)
+    g_w = torch.zeros(C, 1, K, device=DEV)
+    g_b = torch.zeros(C, device=DEV)
+    g_gam = torch.zeros(C, device=DEV)
+    ops.dwconv_bwd(du, xr, gx, B, Fr, C, K, lens_d, args[5], gres=g(gres), gamma=g(gam), g_w=g_w,
+                   g_b=g_b, g_gamma=g_gam)
+    want_gx = x.grad.permute(0, 2, 1).reshape(-1, C) + gam.double()[None] * gres.double()
+    close(gx, want_gx, rtol=1e-4, name="dwconv gx")
+    close(g_w, w_dw.grad, rtol=2e-4, name="g_w_dw")
+    close(g_b, b_dw.grad, rtol=2e-4, name="g_b_dw")
+    close(g_gam, (gres.double() * x.detach().permute(0, 2, 1).reshape(-1, C)).sum(0), rtol=2e-4,
+          name="g_gamma")
+
+
+@pytest.mark.parametrize("rows,C", [(100, 48), (33, 768), (257, 24)])
+def test_biasnorm(ops, rows, C):
+    x = rnd(rows, C, seed=1).double().requires_grad_()
+    beta = (rnd(C, seed=2) * 0.1).double().requires_grad_()
+    ls = torch.tensor(1.2, dtype=torch.double, requires_grad=True)
+    y = x * (((x - beta) ** 2).mean(1, keepdim=True) ** -0.5 * ls.exp())
+    gy = rnd(rows, C, seed=3).double()
+    y.backward(gy)
+    xd, bd, ld = g(x.detach().float()), g(beta.detach().float()), g(ls.detach().float().reshape(1))
+    yd = torch.empty(rows, C, device=DEV)
+    ops.biasnorm_fwd(xd, yd, rows, C, bd, ld)
+    close(yd, y, name="biasnorm fwd")
+    gx = torch.empty(rows, C, device=DEV)
+    gb, gl = torch.zeros(C, device=DEV), torch.zeros(1, device=DEV)
+    ops.biasnorm_bwd(xd, g(gy.float()), gx, rows, C, bd, ld, gb, gl)
+    close(gx, x.grad, rtol=1e-4, name="biasnorm gx")
+    close(gb, beta.grad, rtol=2e-4, name="biasnorm gbeta")
+    close(gl, ls.grad.reshape(1), rtol=2e-4, name="biasnorm gls")
+
+
+# ------------------------------------------------------------------ iSTFT / folds
+@pytest.mark.parametrize("n_fft,hop,T", [(512, 256, 6000), (256, 128, 6000), (128, 64, 6000),
+                                         (128, 64, 1024)])
+def test_istft_gemm_ola_fwd_bwd(ops, n_fft, hop, T):
+    from flow2gan_amd.models.modules import dft_matrices
+    B = 2
+    Fr = 1 + T // hop
+    nb = n_fft // 2 + 1
+    packed = rnd(B, 2 * nb, Fr, seed=1).double().requires_grad_()
+    win = torch.hann_window(n_fft).double()
+    spec = torch.complex(packed[:, :nb], packed[:, nb:])
+    y = torch.istft(spec, n_fft, hop, n_fft, win, center=True)
+    y = F.pad(y, (0, T - y.shape[-1])) if y.shape[-1] < T else y[..., :T]
+    gy = rnd(B, T, seed=2).double()
+    y.backward(gy)
+    wb = torch.tensor([0.5, 1.5])
+    _, Wi = dft_matrices(n_fft, DEV)
+    pr = torch.zeros(B * Fr, 2 * nb + 2, device=DEV)
+    pr[:, :2 * nb] = g(packed.detach().float().permute(0, 2, 1).reshape(B * Fr, 2 * nb))
+    frames = torch.empty(B * Fr, n_fft, device=DEV)
+    ops.gemm(ops.mat(pr, B * Fr, 2 * nb), ops.mat(Wi), frames)
+    out = torch.full((B, T), 1.0, device=DEV)
+    ops.istft_ola(frames, out, B, Fr, n_fft, hop, T, g(win.float()), g(wb), 1.0 / 3, True)
+    close(out, 1.0 + y.detach() * wb.double()[:, None] / 3, name="istft")
+    gfr = torch.empty(B * Fr, n_fft, device=DEV)
+    ops.istft_ola_bwd(g(gy.float()), gfr, B, Fr, n_fft, hop, T, g(win.float()), g(wb), 1.0 / 3)
+    gp = torch.empty(B * Fr, 2 * nb + 2, device=DEV)
+    ops.gemm(ops.mat(gfr), ops.mat(Wi), gp, form=1)
+    want = (packed.grad * wb.double()[:, None, None] / 3).permute(0, 2, 1).reshape(B * Fr, 2 * nb)
+    close(gp[:, :2 * nb], want, rtol=1e-4, name="istft bwd")
+
+
+@pytest.mark.parametrize("n_fft,hop,T", [(512, 256, 6000), (128, 32, 999), (1024, 256, 6000)])
+def test_stft_backward_fold(ops, n_fft, hop, T):
+    from flow2gan_amd.models.modules import dft_matrices
+    B = 2
+    x = rnd(B, T, seed=1).double().requires_grad_()
+    win = torch.hann_window(n_fft).double()
+    spec = torch.stft(x, n_fft, hop, n_fft, win, center=True, return_complex=True)
+    nb, Fr = spec.shape[1], spec.shape[2]
+    packed = torch.cat([spec.real, spec.imag], 1)
+    gp = rnd(B, 2 * nb, Fr, seed=2).double()
+    packed.backward(gp)
+    Wd, _ = dft_matrices(n_fft, DEV)
+    gpr = g(gp.float().permute(0, 2, 1).reshape(B * Fr, 2 * nb))
+    gfr = torch.empty(B * Fr, n_fft, device=DEV)
+    ops.gemm(ops.mat(gpr), ops.mat(Wd), gfr, form=1)
+    gx = torch.full((B, T), 2.0, device=DEV)
+    ops.frames_fold(gfr, gx, B, Fr, n_fft, hop, T, True)
+    close(gx, 2.0 + x.grad, rtol=1e-4, name="stft bwd")
+
+
+# ------------------------------------------------------------------ elementwise / losses
+def test_elementwise_small_kernels(ops):
+    x0, x1 = rnd(4, 1000, seed=1), rnd(4, 1000, seed=2)
+    ca, cb = rnd(4, seed=3), rnd(4, seed=4)
+    y = torch.empty(4, 1000, device=DEV)
+    ops.axpby_rows(y, g(x0), g(x1), ca=g(ca), cb=g(cb))
+    close(y, ca[:, None] * x0 + cb[:, None] * x1, name="axpby")
+    ops.axpby_rows(y, g(x0), g(x1), sa=0.25, sb=-2.0)
+    close(y, 0.25 * x0 - 2.0 * x1, name="axpby scalar")
+    ops.clamp(y, g(x0), -0.5, 0.5)
+    close(y, x0.clamp(-0.5, 0.5), name="clamp")
+    s = torch.empty(4, 1000, device=DEV)
+    ops.silu(s, g(x0))
+    close(s, F.silu(x0.double()), name="silu")
+    xx = x0.double().requires_grad_()
+    F.silu(xx).backward(x1.double())
+    ops.silu_bwd(s, g(x1), g(x0))
+    close(s, xx.grad, name="silu bwd")
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import flow2gan_oracle as O
+    t = torch.tensor([0.0, 0.25, 0.5, 0.999])
+    emb = torch.empty(4, 512, device=DEV)
+    ops.time_embedding(emb, g(t), 512)
+    close(emb, O.sinusoid_embedding(t, 512), rtol=2e-4, name="time embedding")
+    cs = torch.zeros(1000, device=DEV)
+    ops.colsum(cs, g(x0), 4, 1000, b=g(x1))
+    close(cs, (x0.double() * x1.double()).sum(0), name="colsum")
+    p, gr = torch.tensor([0.3, 0.7, 1.2, 0.4, 1.1]), torch.tensor([1.0, 1.0, -1.0, -1.0, 1.0])
+    gd = g(gr)
+    ops.limit_grad(gd, g(p), 0.5, 1.0)
+    close(gd, torch.tensor([-1.0, 1.0, 1.0, -1.0, 1.0]), name="limit_grad")
+
+
+def test_loss_kernels(ops):
+    a, b = rnd(5000, seed=1).abs() + 1e-9, rnd(5000, seed=2).abs() + 1e-9
+    a[:10] = 1e-9
+    b[5:15] = 1e-9
+    bb = b.double().requires_grad_()
+    want = (torch.log(a.double().clamp(min=1e-7)) - torch.log(bb.clamp(min=1e-7))).abs().mean() * 3.0
+    want.backward()
+    loss = torch.zeros(1, device=DEV)
+    gb = torch.empty(5000, device=DEV)
+    ops.l1_loss(loss, gb, g(a), g(b), 5000, 3.0 / 5000, clip=1e-7)
+    close(loss, want.detach().reshape(1), name="log l1")
+    close(gb, bb.grad, rtol=1e-4, name="log l1 grad")
+    s = rnd(3000, seed=3)
+    ss = s.double().requires_grad_()
+    w = (torch.clamp(1 + ss, min=0).mean())
+    w.backward()
+    loss = torch.zeros(1, device=DEV)
+    gs = torch.empty(3000, device=DEV)
+    ops.hinge_loss(loss, gs, g(s), 3000, 1.0, 1.0 / 3000)
+    close(loss, w.detach().reshape(1), name="hinge")
+    close(gs, ss.grad, name="hinge grad")
+    x = rnd(3, 4000, seed=4) * 0.1 + 0.02
+    xx = x.double().requires_grad_()
+    c = xx - xx.mean(-1, keepdim=True)
+    y = 0.8 * c / (c.abs().max(-1, keepdim=True)[0] + 1e-9)
+    gy = rnd(3, 4000, seed=5).double()
+    y.backward(gy)
+    yd, st = torch.empty(3, 4000, device=DEV), torch.empty(3, 3, device=DEV)
+    ops.peaknorm_fwd(yd, st, g(x), 3, 4000)
+    close(yd, y, name="peaknorm")
+    gx = torch.empty(3, 4000, device=DEV)
+    ops.peaknorm_bwd(gx, g(gy.float()), g(x), st, 3, 4000)
+    close(gx, xx.grad, rtol=2e-4, name="peaknorm bwd")
+
+
+@pytest.mark.parametrize("p,T", [(2, 6000), (3, 6000), (7, 6001), (11, 6000)])
+def test_period_fold(ops, p, T):
+    B = 2
+    x = rnd(B, T, seed=1).double().requires_grad_()
+    xp = x
+    if T % p:
+        xp = F.pad(x[:, None], (0, p - T % p), "reflect")[:, 0]
+    H = xp.shape[-1] // p
+    img = xp.view(B, H, p)  # [b, h, w]
+    want = img.permute(0, 2, 1).reshape(-1)  # [b][w][h]
+    gw = rnd(B * p * H, seed=2).double()
+    (want * gw).sum().backward()
+    out = torch.empty(B * p * H, device=DEV)
+    ops.period_fold(out, g(x.detach().float()), B, T, p, H)
+    close(out, want, name="period fold")
+    gx = torch.empty(B, T, device=DEV)
+    ops.period_fold_bwd(gx, g(gw.float()), B, T, p, H, False)
+    close(gx, x.grad, name="period fold bwd")
+
+
+def test_spec_power_and_fm_loss(ops):
+    rows, nb = 50, 33
+    packed = rnd(rows, 2 * nb + 2, seed=1)
+    pk = packed.double().requires_grad_()
+    for power in (1, 2):
+        mag = (pk[:, :nb] ** 2 + pk[:, nb:2 * nb] ** 2)
+        out_ref = mag if power == 2 else mag.sqrt()
+        go = rnd(rows, nb, seed=2).double()
+        pk.grad = None
+        out_ref.backward(go)
+        out = torch.empty(rows, nb + 3, device=DEV)
+        ops.spec_power(out, g(packed), rows, nb, power)
+        close(out[:, :nb], out_ref, name=f"spec_power{power}")
+        gp = torch.zeros(rows, 2 * nb + 2, device=DEV)
+        god = torch.zeros(rows, nb + 3, device=DEV)
+        god[:, :nb] = g(go.float())
+        ops.spec_power_bwd(gp, god, g(packed), rows, nb, power)
+        close(gp[:, :2 * nb], pk.grad[:, :2 * nb], rtol=1e-4, name=f"spec_power{power} bwd")
+    B, Fr, nf = 2, 25, 16
+    s_err, s_gt = rnd(B * Fr, nf, seed=3).abs(), rnd(B * Fr, nf, seed=4).abs() * 1e-3
+    lens = torch.tensor([25, 17])
+    mask = (torch.arange(Fr)[None] < lens[:, None]).double().reshape(B * Fr, 1)
+    sc = ((s_gt.double() + 1e-7) ** -0.5).clamp(1e-2, 1e2)
+    inv = 1.0 / (float(lens.sum()) * nf)
+    want = (s_err.double() * sc * mask).sum() * inv
+    loss = torch.zeros(1, device=DEV)
+    w = torch.empty(B * Fr, nf, device=DEV)
+    ops.fm_spec_loss(loss, w, g(s_err), g(s_gt), B, Fr, nf, g(lens.int()), 1e-7, 0.5, 1e-2, 1e2, inv)
+    close(loss, want.reshape(1), name="fm loss")
+    close(w, sc * mask * inv, rtol=1e-4, name="fm loss weights")
