@@ -278,13 +278,18 @@ __global__ __launch_bounds__(256) void fm_spec_loss_kernel(float* loss, float* g
 }
 
 __global__ __launch_bounds__(256) void l1_loss_kernel(float* loss, float* gb, const float* a,
-                                                      const float* b, long long n, float w,
-                                                      float clip) {
+                                                      const float* b, int rows, int cols,
+                                                      long long ld, float w, float clip,
+                                                      const float* wdev) {
   __shared__ float sh[4];
   float acc = 0.f;
+  const float wg = w * (wdev ? wdev[0] : 1.f);
+  const long long n = (long long)rows * cols;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    float av = a[i], bv = b[i];
+    const long long r = i / cols;
+    const long long off = r * ld + (i - r * cols);
+    float av = a[off], bv = b[off];
     float d, gscale = 1.f;
     if (clip > 0.f) {
       const bool live = bv > clip;  // d/db log(max(b,clip)) = 1/b above the clip, 0 below
@@ -296,40 +301,51 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(float* loss, float* gb, co
     acc += fabsf(d);
     if (gb) {
       const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-      gb[i] = -w * sg * gscale;
+      gb[off] = -wg * sg * gscale;
     }
   }
-  acc = block_sum256(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(loss, w * acc);
+  if (loss) {
+    acc = block_sum256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(loss, w * acc);
+  }
 }
 
 __global__ __launch_bounds__(256) void hinge_loss_kernel(float* loss, float* gs, const float* s,
-                                                         long long n, float sgn, float w) {
+                                                         long long n, float sgn, float w,
+                                                         const float* wdev) {
   __shared__ float sh[4];
   float acc = 0.f;
+  const float wg = w * (wdev ? wdev[0] : 1.f);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const float v = 1.f + sgn * s[i];
     const bool live = v > 0.f;
     if (live) acc += v;
-    if (gs) gs[i] = live ? w * sgn : 0.f;
+    if (gs) gs[i] = live ? wg * sgn : 0.f;
   }
-  acc = block_sum256(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(loss, w * acc);
+  if (loss) {
+    acc = block_sum256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(loss, w * acc);
+  }
 }
 
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(float* g, const float* y_act,
-                                                        const float* f_real, float w, float slope,
-                                                        long long n) {
+                                                        const float* f_real, float w,
+                                                        const float* wdev, float slope, int rows,
+                                                        int cols, long long ld) {
+  const float wg = w * (wdev ? wdev[0] : 1.f);
+  const long long n = (long long)rows * cols;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    const float y = y_act[i];
-    float gv = g[i];
+    const long long r = i / cols;
+    const long long off = r * ld + (i - r * cols);
+    const float y = y_act[off];
+    float gv = g[off];
     if (f_real) {
-      const float d = y - f_real[i];
-      gv += w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      const float d = y - f_real[off];
+      gv += wg * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
     }
-    g[i] = gv * (y > 0.f ? 1.f : slope);
+    g[off] = gv * (y > 0.f ? 1.f : slope);
   }
 }
 
@@ -509,29 +525,31 @@ extern "C" int f2g_fm_spec_loss(float* loss, float* g_err, const float* s_err, c
   return f2g_check_launch();
 }
 
-extern "C" int f2g_l1_loss(float* loss, float* gb, const float* a, const float* b, int64_t n,
-                           float w, float clip, f2g_stream_t stream) {
-  if (!loss || !a || !b) return F2G_EINVAL;
-  if (n <= 0) return F2G_OK;
-  hipLaunchKernelGGL(l1_loss_kernel, dim3(f2g_grid_for(n, 256, 1024)), dim3(256), 0, ST, loss, gb,
-                     a, b, (long long)n, w, clip);
+extern "C" int f2g_l1_loss(float* loss, float* gb, const float* a, const float* b, int32_t rows,
+                           int32_t cols, int64_t ld, float w, float clip, const float* wdev,
+                           f2g_stream_t stream) {
+  if (!a || !b || (!loss && !gb)) return F2G_EINVAL;
+  if (rows <= 0 || cols <= 0) return F2G_OK;
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(f2g_grid_for((int64_t)rows * cols, 256, 1024)),
+                     dim3(256), 0, ST, loss, gb, a, b, rows, cols, (long long)ld, w, clip, wdev);
   return f2g_check_launch();
 }
 
 extern "C" int f2g_hinge_loss(float* loss, float* gs, const float* s, int64_t n, float sgn, float w,
-                              f2g_stream_t stream) {
-  if (!loss || !s) return F2G_EINVAL;
+                              const float* wdev, f2g_stream_t stream) {
+  if (!s || (!loss && !gs)) return F2G_EINVAL;
   if (n <= 0) return F2G_OK;
   hipLaunchKernelGGL(hinge_loss_kernel, dim3(f2g_grid_for(n, 256, 1024)), dim3(256), 0, ST, loss,
-                     gs, s, (long long)n, sgn, w);
+                     gs, s, (long long)n, sgn, w, wdev);
   return f2g_check_launch();
 }
 
 extern "C" int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w,
-                             float slope, int64_t n, f2g_stream_t stream) {
+                             const float* wdev, float slope, int32_t rows, int32_t cols,
+                             int64_t ld, f2g_stream_t stream) {
   if (!g || !y_act) return F2G_EINVAL;
-  if (n <= 0) return F2G_OK;
-  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(f2g_grid_for(n, 256)), dim3(256), 0, ST, g, y_act,
-                     f_real, w, slope, (long long)n);
+  if (rows <= 0 || cols <= 0) return F2G_OK;
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(f2g_grid_for((int64_t)rows * cols, 256)), dim3(256), 0,
+                     ST, g, y_act, f_real, w, wdev, slope, rows, cols, (long long)ld);
   return f2g_check_launch();
 }

@@ -12,6 +12,11 @@
 // lane's operands for 4 consecutive MFMAs are one ds_read_b128 (row-major LDS tile) or four
 // conflict-free ds_read_b32 (k-major tile).  Global->register->LDS double buffering, one
 // barrier per K slab.
+//
+// Loaders are specialised at compile time: PLAIN operands (a row-major matrix: every pointwise
+// GEMM, i.e. ~95 % of the FLOPs) keep one pointer per staged chunk and add a constant per K slab;
+// GENERIC operands (windowed im2col views) decode rows once before the K loop and columns once
+// per slab.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,6 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDR = BK + 4;  // row-major LDS tile leading dim (conflict-free ds_read_b128)
 
+// ------------------------------------------------------------------------------------------
+// generic (windowed) element access
+// ------------------------------------------------------------------------------------------
 struct RowCtx {
   long long base;
   int l1b, e0;
@@ -70,18 +78,16 @@ __device__ __forceinline__ float load_elem(const f2g_operand& S, const RowCtx& r
   return fix_elem(S, S.base[off], off, c);
 }
 
-// 4 consecutive window columns c..c+3 of row r (zero outside the operand).
-__device__ __forceinline__ float4 load_chunk(const f2g_operand& S, int r, int c) {
+// 4 consecutive window columns c..c+3 of a decoded row; (seg, o) = decode of column c.
+__device__ __forceinline__ float4 load_chunk_generic(const f2g_operand& S, const RowCtx& rc, int c,
+                                                     int seg, int o) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (r >= S.rows || c >= S.cols) return v;
-  RowCtx rc = decode_row(S, r);
-  int seglen = S.seglen < S.cols ? S.seglen : S.cols;
-  int seg = 0, o = c;
-  if (S.seglen < S.cols) { seg = c / S.seglen; o = c - seg * S.seglen; }
-  int l1 = rc.l1b + seg;
-  int e = rc.e0 + o;
+  if (c >= S.cols) return v;
+  const int seglen = S.seglen < S.cols ? S.seglen : S.cols;
+  const int l1 = rc.l1b + seg;
+  const int e = rc.e0 + o;
   if (o + 3 < seglen && (unsigned)l1 < (unsigned)S.L1 && e >= 0 && e + 3 < S.L0u) {
-    long long off = rc.base + (long long)l1 * S.line_stride + e;
+    const long long off = rc.base + (long long)l1 * S.line_stride + e;
     const float* p = S.base + off;
     if ((((uintptr_t)p) & 15) == 0) {
       v = *reinterpret_cast<const float4*>(p);
@@ -103,33 +109,183 @@ __device__ __forceinline__ float4 load_chunk(const f2g_operand& S, int r, int c)
   return v;
 }
 
-// Tile staging: TROWS x TCOLS floats, 256 threads, float4 chunks along the contiguous axis.
-template <int TROWS, int TCOLS>
-struct Stage {
+__device__ __forceinline__ float prelu1(float v, float a) { return v > 0.f ? v : a * v; }
+
+// ------------------------------------------------------------------------------------------
+// Tile loaders.  A tile is TROWS x TCOLS floats in memory orientation, staged by 256 threads as
+// float4 chunks: chunk idx = tid + 256*q -> (row = idx / CH, ch = idx % CH).  CH divides 256,
+// so `ch` is the same for all of a thread's chunks and rows advance by 256/CH.
+//   KM = false: rows are the tile's m/n index (fixed), cols walk K   -> advance along columns
+//   KM = true : rows walk K (the reduction), cols are m/n (fixed)    -> advance along rows
+// MODE (chosen on the host from the operand descriptor):
+//   PF  plain matrix, 16-byte aligned rows, reduction extent % BK == 0: every chunk is ONE
+//       unconditional global_load_dwordx4 through a clamped pointer; masks + PReLU in store().
+//   GF  windowed operand whose offsets are all multiples of 4 floats: one clamped vector load
+//       per chunk + a validity bit; leaky-ReLU derivative / PReLU applied in store().
+//   SL  anything else (misaligned, reflect padding, odd extents): element-wise predicated.
+// store() runs after the slab's MFMAs, so the transforms never wait on the load latency.
+// ------------------------------------------------------------------------------------------
+enum { PF = 0, GF = 1, SL = 2 };
+
+template <int MODE, bool KM, int TROWS, int TCOLS>
+struct Loader {
   static constexpr int CH = TCOLS / 4;
   static constexpr int NLD = (TROWS * CH) / 256;
-  static_assert((TROWS * CH) % 256 == 0, "tile must divide among 256 threads");
+  static constexpr int RSTEP = 256 / CH;
+  static_assert((TROWS * CH) % 256 == 0 && 256 % CH == 0, "tile must divide among 256 threads");
+
   float4 r[NLD];
-  __device__ __forceinline__ void load(const f2g_operand& S, int row0, int col0, int tid) {
+  float4 r2[MODE == GF ? NLD : 1];      // lrelu_src values of the chunk
+  float4 a4;                            // PReLU slopes of the staged chunk's 4 columns
+  unsigned vmask;                       // bit q: chunk q holds valid data
+  unsigned cmask;                       // PF/KM: valid columns of the thread's fixed chunk
+  unsigned rokm;                        // RM: bit q: row in range
+  const float* p[MODE == PF ? NLD : 1];  // PF: chunk pointers, advanced per slab
+  long long pstep;                      // PF: pointer advance per slab
+  int c0;                               // first window column (RM: + k0 per slab; KM: fixed)
+  int row0;                             // KM: first reduction row of this thread
+  RowCtx rc[(MODE != PF && !KM) ? NLD : 1];  // generic RM: decoded rows
+  int seg, o;                           // generic KM: decoded fixed column
+
+  __device__ __forceinline__ void init(const f2g_operand& S, int tr0, int tc0, int kbeg, int tid) {
+    const int ch = tid % CH, rr = tid / CH;
+    rokm = 0; cmask = 0; vmask = 0;
+    a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == PF) {
+      const long long ld = S.seq_stride;
+      if (!KM) {
+        c0 = ch * 4;
+        pstep = BK;
 #pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      int idx = tid + 256 * q;
-      int row = idx / CH, ch = idx - row * CH;
-      r[q] = load_chunk(S, row0 + row, col0 + ch * 4);
+        for (int q = 0; q < NLD; ++q) {
+          const int row = tr0 + rr + RSTEP * q;
+          const bool ok = row < S.rows;
+          rokm |= (ok ? 1u : 0u) << q;
+          p[q] = S.base + (long long)(ok ? row : 0) * ld + ch * 4 + kbeg;
+        }
+      } else {
+        c0 = tc0 + ch * 4;
+        row0 = rr;
+        pstep = (long long)BK * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cmask |= (c0 + j < S.cols ? 1u : 0u) << j;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)
+          p[q] = S.base + (long long)(kbeg + rr + RSTEP * q) * ld + (cmask ? c0 : 0);
+        if (S.alpha) {
+          if (cmask & 1) a4.x = S.alpha[c0];
+          if (cmask & 2) a4.y = S.alpha[c0 + 1];
+          if (cmask & 4) a4.z = S.alpha[c0 + 2];
+          if (cmask & 8) a4.w = S.alpha[c0 + 3];
+        }
+      }
+    } else {
+      if (!KM) {
+        c0 = ch * 4;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+          const int row = tr0 + rr + RSTEP * q;
+          const bool ok = row < S.rows;
+          rokm |= (ok ? 1u : 0u) << q;
+          rc[q] = decode_row(S, ok ? row : 0);
+        }
+      } else {
+        c0 = tc0 + ch * 4;
+        row0 = rr;
+        seg = 0; o = c0;
+        if (S.seglen < S.cols) { seg = c0 / S.seglen; o = c0 - seg * S.seglen; }
+        if (MODE == GF && S.alpha) {
+          if (c0 < S.cols) a4.x = S.alpha[c0];
+          if (c0 + 1 < S.cols) a4.y = S.alpha[c0 + 1];
+          if (c0 + 2 < S.cols) a4.z = S.alpha[c0 + 2];
+          if (c0 + 3 < S.cols) a4.w = S.alpha[c0 + 3];
+        }
+      }
     }
   }
-  __device__ __forceinline__ void store(float* lds, int ld, int tid) const {
+
+  __device__ __forceinline__ void gchunk(const f2g_operand& S, int q, bool rowok, const RowCtx& rcx,
+                                         int c, int sg, int oo) {
+    if (MODE == GF) {
+      const int l1 = rcx.l1b + sg, e = rcx.e0 + oo;
+      const bool v = rowok && c < S.cols && (unsigned)l1 < (unsigned)S.L1 && e >= 0 &&
+                     e + 3 < S.L0u;
+      const long long off = v ? rcx.base + (long long)l1 * S.line_stride + e : 0;
+      r[q] = *reinterpret_cast<const float4*>(S.base + off);
+      if (S.lrelu_src) r2[q] = *reinterpret_cast<const float4*>(S.lrelu_src + off);
+      vmask |= (v ? 1u : 0u) << q;
+    } else {
+      r[q] = rowok ? load_chunk_generic(S, rcx, c, sg, oo) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vmask |= 1u << q;
+    }
+  }
+
+  __device__ __forceinline__ void load(const f2g_operand& S, int k0) {
+    if (MODE == PF) {
+      if (!KM && S.alpha) {
+        const int c = c0 + k0;  // full slabs only: c+3 < cols
+        a4 = *reinterpret_cast<const float4*>(S.alpha + c);
+      }
+#pragma unroll
+      for (int q = 0; q < NLD; ++q) {
+        r[q] = *reinterpret_cast<const float4*>(p[q]);
+        p[q] += pstep;
+      }
+      vmask = KM ? (cmask ? ~0u : 0u) : rokm;
+    } else {
+      vmask = 0;
+      if (!KM) {
+        const int c = c0 + k0;
+        int sg = 0, oo = c;
+        if (S.seglen < S.cols) { sg = c / S.seglen; oo = c - sg * S.seglen; }
+        if (MODE == GF && S.alpha) {
+          a4.x = c < S.cols ? S.alpha[c] : 0.f;
+          a4.y = c + 1 < S.cols ? S.alpha[c + 1] : 0.f;
+          a4.z = c + 2 < S.cols ? S.alpha[c + 2] : 0.f;
+          a4.w = c + 3 < S.cols ? S.alpha[c + 3] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) gchunk(S, q, (rokm >> q) & 1, rc[q], c, sg, oo);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+          const int row = k0 + row0 + RSTEP * q;
+          const bool ok = row < S.rows;
+          RowCtx rcx = decode_row(S, ok ? row : 0);
+          gchunk(S, q, ok, rcx, c0, seg, o);
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(const f2g_operand& S, float* lds, int ld, int tid) const {
+    const int ch = tid % CH, rr = tid / CH;
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
-      int idx = tid + 256 * q;
-      int row = idx / CH, ch = idx - row * CH;
-      *reinterpret_cast<float4*>(lds + row * ld + ch * 4) = r[q];
+      float4 v = r[q];
+      if (!((vmask >> q) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == PF && KM) {  // column tail of the fixed chunk
+        if (!(cmask & 1)) v.x = 0.f;
+        if (!(cmask & 2)) v.y = 0.f;
+        if (!(cmask & 4)) v.z = 0.f;
+        if (!(cmask & 8)) v.w = 0.f;
+      }
+      if (MODE == GF && S.lrelu_src) {
+        const float sl = S.lrelu_slope;
+        v.x *= r2[q].x > 0.f ? 1.f : sl; v.y *= r2[q].y > 0.f ? 1.f : sl;
+        v.z *= r2[q].z > 0.f ? 1.f : sl; v.w *= r2[q].w > 0.f ? 1.f : sl;
+      }
+      if (MODE != SL && S.alpha) {  // SL applied it element-wise on load
+        v.x = prelu1(v.x, a4.x); v.y = prelu1(v.y, a4.y);
+        v.z = prelu1(v.z, a4.z); v.w = prelu1(v.w, a4.w);
+      }
+      *reinterpret_cast<float4*>(lds + (rr + RSTEP * q) * ld + ch * 4) = v;
     }
   }
 };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K,
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K,
                                                    int kchunk) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -145,7 +301,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const f2g_gemm_desc d, int M,
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
   const int li = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles with
+  // the n index fastest so that the tiles sharing an A panel hit the same private L2.
+  const int tiles_n = gridDim.y, tiles_m = gridDim.x;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.y * tiles_m + blockIdx.x;
+  {
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = blockIdx.z * kchunk;
   int kend = kbeg + kchunk;
   if (kend > K) kend = K;
@@ -159,29 +325,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const f2g_gemm_desc d, int M,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  using SA = typename std::conditional<AKM, Stage<BK, BM>, Stage<BM, BK>>::type;
-  using SB = typename std::conditional<BKM, Stage<BK, BN>, Stage<BN, BK>>::type;
+  using SA = typename std::conditional<AKM, Loader<AMODE, true, BK, BM>,
+                                       Loader<AMODE, false, BM, BK>>::type;
+  using SB = typename std::conditional<BKM, Loader<BMODE, true, BK, BN>,
+                                       Loader<BMODE, false, BN, BK>>::type;
   SA sa;
   SB sb;
-
-  auto gload = [&](int k0) {
-    if (AKM) sa.load(d.A, k0, m0, tid); else sa.load(d.A, m0, k0, tid);
-    if (BKM) sb.load(d.B, k0, n0, tid); else sb.load(d.B, n0, k0, tid);
-  };
-  auto lstore = [&](int buf) {
-    sa.store(As + buf * ASZ, LDA, tid);
-    sb.store(Bs + buf * BSZ, LDB, tid);
-  };
+  if (AKM) sa.init(d.A, 0, m0, kbeg, tid); else sa.init(d.A, m0, 0, kbeg, tid);
+  if (BKM) sb.init(d.B, 0, n0, kbeg, tid); else sb.init(d.B, n0, 0, kbeg, tid);
 
   if (nt > 0) {
-    gload(kbeg);
-    lstore(0);
+    sa.load(d.A, kbeg);
+    sb.load(d.B, kbeg);
+    sa.store(d.A, As, LDA, tid);
+    sb.store(d.B, Bs, LDB, tid);
   }
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) gload(kbeg + (t + 1) * BK);
+    if (t + 1 < nt) {
+      sa.load(d.A, kbeg + (t + 1) * BK);
+      sb.load(d.B, kbeg + (t + 1) * BK);
+    }
     const float* Ab = As + cur * ASZ;
     const float* Bb = Bs + cur * BSZ;
 #pragma unroll
@@ -219,7 +385,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const f2g_gemm_desc d, int M,
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][q], b[ni][q], acc[mi][ni],
                                                                 0, 0, 0);
     }
-    if (t + 1 < nt) lstore(cur ^ 1);
+    if (t + 1 < nt) {
+      sa.store(d.A, As + (cur ^ 1) * ASZ, LDA, tid);
+      sb.store(d.B, Bs + (cur ^ 1) * BSZ, LDB, tid);
+    }
     __syncthreads();
   }
 
@@ -276,7 +445,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const f2g_gemm_desc d, int M,
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
 int launch(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -289,23 +458,46 @@ int launch(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t s
   if (zs < 1) zs = 1;
   dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, zs);
   if (grid.x == 0 || grid.y == 0) return F2G_OK;
-  auto kern = gemm_kernel<WAVES_M, WAVES_N, TM, TN, AKM, BKM>;
+  auto kern = gemm_kernel<WAVES_M, WAVES_N, TM, TN, AKM, BKM, AMODE, BMODE>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, d, M, N, K, kchunk);
   return f2g_check_launch();
 }
 
-template <bool AKM, bool BKM>
-int dispatch(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
-  if (AKM && M <= 32) return launch<1, 4, 1, 2, AKM, BKM>(d, M, N, K, split, st);  // 32 x 256
-  if (N <= 32) return launch<4, 1, 2, 1, AKM, BKM>(d, M, N, K, split, st);         // 256 x 32
-  if (N <= 64) return launch<4, 1, 1, 2, AKM, BKM>(d, M, N, K, split, st);         // 128 x 64
-  return launch<2, 2, 2, 2, AKM, BKM>(d, M, N, K, split, st);                      // 128 x 128
+template <bool AKM, bool BKM, int AMODE, int BMODE>
+int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+  if (AKM && M <= 32) return launch<1, 4, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
+  if (N <= 32) return launch<4, 1, 2, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
+  if (N <= 64) return launch<4, 1, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
+  return launch<2, 2, 2, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
+}
+
+inline bool host_plain(const f2g_operand& S) {
+  return S.P0 == 1 && S.P1 == 1 && S.seglen >= S.cols && S.L1 == 1 && S.pad0 == 0 &&
+         S.pad1 == 0 && S.L0u >= S.cols && !S.reflect && !S.lrelu_src;
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Loader mode of an operand; `red_is_cols`: the reduction runs along the operand's columns.
+inline int op_mode(const f2g_operand& S, bool red_is_cols) {
+  if (host_plain(S)) {
+    const int red = red_is_cols ? S.cols : S.rows;
+    const bool ok = al16(S.base) && (S.seq_stride & 3) == 0 && S.cols >= 4 && red % BK == 0 &&
+                    (!S.alpha || !red_is_cols || al16(S.alpha));
+    if (ok) return PF;
+  }
+  const long long eu0 = (long long)S.step0 * S.unit, ep0 = (long long)S.pad0 * S.unit;
+  const bool vec = al16(S.base) && (S.seq_stride & 3) == 0 && (S.line_stride & 3) == 0 &&
+                   (S.seglen & 3) == 0 && (eu0 & 3) == 0 && (ep0 & 3) == 0 && (S.L0u & 3) == 0 &&
+                   (S.cols & 3) == 0 && !S.reflect && (!S.lrelu_src || al16(S.lrelu_src)) &&
+                   S.L0u >= 4;
+  return vec ? GF : SL;
 }
 
 }  // namespace
@@ -315,16 +507,30 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   const f2g_gemm_desc& d = *dp;
   hipStream_t st = (hipStream_t)stream;
   int split = d.split_k > 0 ? d.split_k : 1;
-  if (d.form == 0) {
-    if (d.A.cols != d.B.cols) return F2G_EINVAL;
-    return dispatch<false, false>(d, d.A.rows, d.B.rows, d.A.cols, 1, st);
-  } else if (d.form == 1) {
-    if (d.A.cols != d.B.rows) return F2G_EINVAL;
-    return dispatch<false, true>(d, d.A.rows, d.B.cols, d.A.cols, 1, st);
+  if (d.form == 0 || d.form == 1) {
+    const bool f1 = d.form == 1;
+    if (f1 ? d.A.cols != d.B.rows : d.A.cols != d.B.cols) return F2G_EINVAL;
+    if (!host_plain(d.B)) return F2G_EINVAL;
+    const int M = d.A.rows, N = f1 ? d.B.cols : d.B.rows, K = d.A.cols;
+    const int am = op_mode(d.A, true), bm = op_mode(d.B, !f1);
+    if (!f1) {
+      if (am == PF && bm == PF) return dispatch_tile<false, false, PF, PF>(d, M, N, K, 1, st);
+      if (am == GF && bm == PF) return dispatch_tile<false, false, GF, PF>(d, M, N, K, 1, st);
+      return dispatch_tile<false, false, SL, SL>(d, M, N, K, 1, st);
+    }
+    if (am == PF && bm == PF) return dispatch_tile<false, true, PF, PF>(d, M, N, K, 1, st);
+    if (am == GF && bm == PF) return dispatch_tile<false, true, GF, PF>(d, M, N, K, 1, st);
+    return dispatch_tile<false, true, SL, SL>(d, M, N, K, 1, st);
   } else if (d.form == 2) {
     if (d.A.rows != d.B.rows) return F2G_EINVAL;
     if (split > 1 && !d.E.atomic) return F2G_EINVAL;
-    return dispatch<true, true>(d, d.A.cols, d.B.cols, d.A.rows, split, st);
+    const int M = d.A.cols, N = d.B.cols, K = d.A.rows;
+    int am = op_mode(d.A, false), bm = op_mode(d.B, false);
+    // split-K chunks are multiples of BK, so PF only needs the total extent % BK == 0
+    if (am == PF && bm == PF) return dispatch_tile<true, true, PF, PF>(d, M, N, K, split, st);
+    if (am == PF && bm == GF) return dispatch_tile<true, true, PF, GF>(d, M, N, K, split, st);
+    if (am != SL && bm != SL) return dispatch_tile<true, true, GF, GF>(d, M, N, K, split, st);
+    return dispatch_tile<true, true, SL, SL>(d, M, N, K, split, st);
   }
   return F2G_EINVAL;
 }

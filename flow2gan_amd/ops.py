@@ -318,13 +318,25 @@ def fm_spec_loss(loss, g_err, s_err, s_gt, B, F, nf, lens, eps, power, lo, hi, i
          float(eps), float(power), float(lo), float(hi), float(inv_denom))
 
 
-def l1_loss(loss, gb, a, b, n, w, clip=0.0, loss_offset=0):
-    call("f2g_l1_loss", ptr(loss) + 4 * loss_offset, ptr(gb), ptr(a), ptr(b), n, float(w),
-         float(clip))
+def l1_loss(loss, gb, a, b, rows, cols, ld, w, clip=0.0, wdev=None, loss_offset=0, off=0):
+    """a, b, gb are views of the same layout starting `off` floats into their tensors."""
+    call("f2g_l1_loss", None if loss is None else ptr(loss) + 4 * loss_offset,
+         None if gb is None else ptr(gb) + 4 * off, ptr(a) + 4 * off, ptr(b) + 4 * off, rows, cols,
+         ld, float(w), float(clip), ptr(wdev))
 
 
-def hinge_loss(loss, gs, s, n, sgn, w, loss_offset=0):
-    call("f2g_hinge_loss", ptr(loss) + 4 * loss_offset, ptr(gs), ptr(s), n, float(sgn), float(w))
+def l1_loss_ab(loss, gb, a, a_off, b, b_off, rows, cols, ld, w, clip=0.0, wdev=None,
+               loss_offset=0):
+    """Same with independent offsets for a and b (gb follows b)."""
+    call("f2g_l1_loss", None if loss is None else ptr(loss) + 4 * loss_offset,
+         None if gb is None else ptr(gb) + 4 * b_off, ptr(a) + 4 * a_off, ptr(b) + 4 * b_off, rows,
+         cols, ld, float(w), float(clip), ptr(wdev))
+
+
+def hinge_loss(loss, gs, s, n, sgn, w, wdev=None, loss_offset=0, s_off=0):
+    call("f2g_hinge_loss", None if loss is None else ptr(loss) + 4 * loss_offset,
+         None if gs is None else ptr(gs) + 4 * s_off, ptr(s) + 4 * s_off, n, float(sgn), float(w),
+         ptr(wdev))
 
 
 def peaknorm_fwd(y, stats, x, rows, T):
@@ -335,9 +347,10 @@ def peaknorm_bwd(gx, gy, x, stats, rows, T):
     call("f2g_peaknorm_bwd", ptr(gx), ptr(gy), ptr(x), ptr(stats), rows, T)
 
 
-def lrelu_bwd(g, y_act, f_real, w, slope, n, g_off=0, y_off=0, r_off=0):
+def lrelu_bwd(g, y_act, f_real, w, slope, rows, cols, ld, wdev=None, g_off=0, y_off=0, r_off=0):
     call("f2g_lrelu_bwd", ptr(g) + 4 * g_off, ptr(y_act) + 4 * y_off,
-         None if f_real is None else ptr(f_real) + 4 * r_off, float(w), float(slope), n)
+         None if f_real is None else ptr(f_real) + 4 * r_off, float(w), ptr(wdev), float(slope),
+         rows, cols, ld)
 
 
 def period_fold(out, x, B, T, p, H):

@@ -263,23 +263,27 @@ int f2g_spec_power_bwd(float* gpacked, int64_t ldp, const float* gout, int64_t l
 int f2g_fm_spec_loss(float* loss, float* g_err, const float* s_err, const float* s_gt, int32_t B,
                      int32_t F, int32_t n_filt, const int32_t* lens, float eps, float power,
                      float lo, float hi, float inv_denom, f2g_stream_t stream);
-/* loss += w * sum |log(max(a,clip)) - log(max(b,clip))| ; gb = -w*sign(.)/max(b,clip) where b>clip
- * (gan.py:89-99 with utils.py:221-232).  clip <= 0 means plain L1 |a-b| (gan.py:77-87). */
-int f2g_l1_loss(float* loss, float* gb, const float* a, const float* b, int64_t n, float w,
-                float clip, f2g_stream_t stream);
-/* Hinge terms (gan.py:57-75): loss += w * sum relu(1 + sgn*s); gs = w*sgn where active. */
+/* L1 terms over a (rows, cols) view with row stride ld (a, b, gb share the layout):
+ *   loss += w * sum |f(a) - f(b)|,  f = log(max(., clip)) if clip > 0 (gan.py:89-99 with
+ *   utils.py:221-232) else identity (gan.py:77-87);  gb = -(w * wdev[0]) * sign(.) * f'(b).
+ * loss or gb may be NULL; wdev (device scalar, may be NULL = 1) carries the upstream gradient so
+ * that backward never synchronises with the host. */
+int f2g_l1_loss(float* loss, float* gb, const float* a, const float* b, int32_t rows, int32_t cols,
+                int64_t ld, float w, float clip, const float* wdev, f2g_stream_t stream);
+/* Hinge terms (gan.py:57-75): loss += w * sum relu(1 + sgn*s); gs = (w*wdev[0])*sgn where active. */
 int f2g_hinge_loss(float* loss, float* gs, const float* s, int64_t n, float sgn, float w,
-                   f2g_stream_t stream);
+                   const float* wdev, f2g_stream_t stream);
 /* DiscriminatorR input conditioning (discriminators.py:186-190): y = 0.8*(x-mean)/(max|x-mean|+1e-9)
  * per row; stats (rows,3) = {mean, peak, argmax index} kept for backward. */
 int f2g_peaknorm_fwd(float* y, float* stats, const float* x, int32_t rows, int32_t T,
                      f2g_stream_t stream);
 int f2g_peaknorm_bwd(float* gx, const float* gy, const float* x, const float* stats, int32_t rows,
                      int32_t T, f2g_stream_t stream);
-/* y[r, c] = x[r, c] * (y_act[r,c] > 0 ? 1 : slope)  (leaky-ReLU backward, in place allowed)
- * plus optional feature-matching term: g += w * sign(f_fake - f_real) before the mask. */
-int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w, float slope,
-                  int64_t n, f2g_stream_t stream);
+/* Leaky-ReLU backward in place over a (rows, cols, ld) view (discriminators.py:94,205), with the
+ * feature-matching gradient folded in first: g += (w*wdev[0]) * sign(y_act - f_real) (gan.py:77-87);
+ * then g *= (y_act > 0 ? 1 : slope).  f_real may be NULL. */
+int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w, const float* wdev,
+                  float slope, int32_t rows, int32_t cols, int64_t ld, f2g_stream_t stream);
 /* MPD input shaping (discriminators.py:82-90): right reflect-pad to a multiple of p and lay the
  * (B,1,T'/p,p) image out channels-last per column: out[((b*p + w)*H + h)] = x[b, h*p + w].
  * Backward folds it back (gx +=). */

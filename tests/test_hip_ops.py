@@ -356,7 +356,8 @@ def test_loss_kernels(ops):
     want.backward()
     loss = torch.zeros(1, device=DEV)
     gb = torch.empty(5000, device=DEV)
-    ops.l1_loss(loss, gb, g(a), g(b), 5000, 3.0 / 5000, clip=1e-7)
+    ops.l1_loss(loss, gb, g(a), g(b), 1, 5000, 5000, 3.0 / 5000, clip=1e-7, wdev=g(torch.tensor([2.0])))
+    gb = gb / 2.0
     close(loss, want.detach().reshape(1), name="log l1")
     close(gb, bb.grad, rtol=1e-4, name="log l1 grad")
     s = rnd(3000, seed=3)
@@ -366,6 +367,12 @@ def test_loss_kernels(ops):
     loss = torch.zeros(1, device=DEV)
     gs = torch.empty(3000, device=DEV)
     ops.hinge_loss(loss, gs, g(s), 3000, 1.0, 1.0 / 3000)
+    ya, fr, gg = rnd(40, 24, seed=7), rnd(40, 24, seed=8), rnd(40, 24, seed=9)
+    gd = g(gg)
+    ops.lrelu_bwd(gd, g(ya), g(fr), 0.5, 0.1, 40, 16, 24, wdev=g(torch.tensor([3.0])))
+    wantg = gg.clone()
+    wantg[:, :16] = (gg[:, :16] + 1.5 * torch.sign(ya[:, :16] - fr[:, :16])) * torch.where(ya[:, :16] > 0, 1.0, 0.1)
+    close(gd, wantg, name='lrelu_bwd strided')
     close(loss, w.detach().reshape(1), name="hinge")
     close(gs, ss.grad, name="hinge grad")
     x = rnd(3, 4000, seed=4) * 0.1 + 0.02
