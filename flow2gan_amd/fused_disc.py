@@ -1,0 +1,555 @@
+"""Fused forward/backward schedules of the GAN-stage loss stack on the HIP kernels:
+multi-period discriminator (reference discriminators.py:18-107), multi-resolution STFT
+discriminator (discriminators.py:110-219), hinge / feature-matching / multi-scale mel losses
+(gan.py:57-99).  Math: SURVEY.md appendix A.8-A.10.
+
+Real and generated audio are stacked to one (2B, T) batch so that every conv runs once; all
+feature maps are channels-last rows x C and every conv (forward, data gradient by stride residue,
+weight gradient) is an implicit GEMM on the fp32 matrix cores.  Each multi-discriminator is ONE
+autograd node that returns its loss terms; upstream gradients enter the kernels as device scalars
+(no host sync).  D-step: gradients for the discriminator parameters only.  G-step: gradient for
+the generated audio only (the reference also computes, then discards, the discriminator weight
+gradients -- skipping them does not change any generator gradient).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import ops
+from .fused import filterbank_spec, filterbank_spec_bwd
+from .models.modules import dft_matrices
+from .ops import gemm, mat, win1d, win2d
+
+SLOPE = 0.1  # LeakyReLU slope, discriminators.py:94,205
+
+
+def stack_pair(real, fake):
+    B, T = real.shape
+    x2 = ops.empty(2 * B, T, device=real.device)
+    ops.copy3(x2, 0, T, real.contiguous(), 0, T, 1, B, T)
+    ops.copy3(x2, 0, T, fake.contiguous(), 0, T, 1, B, T, out_offset=B * T)
+    return x2
+
+
+def pack_conv_weight(w):
+    """(Cout, Cin, kh, kw) -> (Cout, kh*kw*Cin): window-major, channel-minor."""
+    Cout, Cin, kh, kw = w.shape
+    out = ops.empty(Cout, kh * kw * Cin, device=w.device)
+    ops.permute4(out, w, (Cout, kh * kw, Cin, 1), (Cin * kh * kw, 1, kh * kw, 0))
+    return out
+
+
+def unpack_conv_grad(gp, shape):
+    Cout, Cin, kh, kw = shape
+    out = ops.empty(Cout, Cin, kh, kw, device=gp.device)
+    ops.permute4(out, gp, (Cout, Cin, kh * kw, 1), (Cin * kh * kw, 1, Cin, 0))
+    return out
+
+
+def _residues(k: int, stride: int, pad: int, n_in: int):
+    """Transposed-conv decomposition: for input residue rho, the taps j = j0 + stride*i that reach
+    it, the first source offset and the number of input positions."""
+    out = []
+    for rho in range(stride):
+        j0 = (rho + pad) % stride
+        nt = len(range(j0, k, stride))
+        e0 = (rho + pad - j0) // stride
+        Lq = (n_in - rho + stride - 1) // stride
+        out.append((rho, j0, nt, e0, max(Lq, 0)))
+    return out
+
+
+# =====================================================================================
+# Multi-period discriminator
+# =====================================================================================
+MPD_CH = (1, 32, 128, 512, 1024, 1024)
+MPD_STRIDE = (3, 3, 3, 3, 1)
+
+
+def mpd_params(mpd) -> list:
+    p = []
+    for d in mpd.discriminators:
+        for c in d.convs:
+            p += [c.weight, c.bias]
+        p += [d.conv_post.weight, d.conv_post.bias]
+    return p
+
+
+def _mpd_forward_one(x2, p: int, prm: list):
+    """x2 (2B, T) -> dict with per-layer activations (channels-last), heights, scores."""
+    dev = x2.device
+    S2, T = x2.shape
+    H = (T + p - 1) // p
+    S = S2 * p
+    img = ops.empty(S * H, 1, device=dev)
+    ops.period_fold(img, x2, S2, T, p, H)
+    acts, hs = [img], [H]
+    x = img
+    for l in range(5):
+        w, b = prm[2 * l], prm[2 * l + 1]
+        Cin, Cout, st = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
+        Hout = (H + 4 - 5) // st + 1
+        wp = pack_conv_weight(w)
+        y = ops.empty(S * Hout, Cout, device=dev)
+        gemm(win1d(x, S, H, Cin, Hout, st, 2, 5), mat(wp), y, bias=b, lrelu=SLOPE)
+        acts.append(y)
+        hs.append(Hout)
+        x, H = y, Hout
+    wpost, bpost = prm[10], prm[11]
+    wpp = pack_conv_weight(wpost)
+    scores = ops.empty(S * H, 1, device=dev)
+    gemm(win1d(x, S, H, 1024, H, 1, 1, 3), mat(wpp), scores, bias=bpost)
+    return dict(acts=acts, hs=hs, scores=scores, S=S, p=p)
+
+
+def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0):
+    """g_x (S*Hin, Cin) from g_pre (rows S*Hout starting g_off floats in, Cout)."""
+    Cin, K = w.shape[1], w.shape[2] * w.shape[3]
+    dev = g_pre.device
+    gx = ops.empty(S * Hin, Cin, device=dev)
+    for rho, j0, nt, e0, Lq in _residues(K, stride, pad, Hin):
+        if Lq == 0:
+            continue
+        wq = ops.empty(nt * Cout, Cin, device=dev)
+        ops.permute4(wq, w, (nt, Cout, Cin, 1), (-stride, Cin * K, K, 0),
+                     in_offset=j0 + stride * (nt - 1))
+        A = win1d(g_pre, S, Hout, Cout, Lq, 1, (nt - 1) - e0, nt, offset=g_off)
+        gemm(A, mat(wq), gx, form=1, rowmap=(Lq, Hin * Cin, stride * Cin, rho * Cin))
+    return gx
+
+
+class MPDLossFn(torch.autograd.Function):
+    """(real, fake) -> (loss0, loss1): D-step (hinge_D, 0); G-step (hinge_G, feature matching)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, train_disc: bool, periods, *params):
+        dev = real.device
+        B, T = real.shape
+        x2 = stack_pair(real, fake)
+        losses = ops.zeros(2, device=dev)
+        saved = []
+        for i, p in enumerate(periods):
+            prm = list(params[12 * i: 12 * i + 12])
+            st = _mpd_forward_one(x2, p, prm)
+            S, H5 = st["S"], st["hs"][5]
+            nh = (S // 2) * H5  # elements of one half's score map
+            sc = st["scores"]
+            if train_disc:
+                ops.hinge_loss(losses, None, sc, nh, -1.0, 1.0 / nh)
+                ops.hinge_loss(losses, None, sc, nh, +1.0, 1.0 / nh, s_off=nh)
+            else:
+                ops.hinge_loss(losses, None, sc, nh, -1.0, 1.0 / nh, s_off=nh)
+                for l in range(2, 6):  # fmaps: conv layers 1..4 (discriminators.py:95-96)
+                    y = st["acts"][l]
+                    n = y.numel() // 2
+                    ops.l1_loss_ab(losses, None, y, 0, y, n, 1, n, n, 1.0 / n, loss_offset=1)
+                ops.l1_loss_ab(losses, None, sc, 0, sc, nh, 1, nh, nh, 1.0 / nh, loss_offset=1)
+            saved.append(st)
+        ctx.saved = saved
+        ctx.params = params
+        ctx.meta = (B, T, train_disc, tuple(periods))
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        B, T, train_disc, periods = ctx.meta
+        params = ctx.params
+        dev = g0.device
+        g0 = g0.reshape(1).contiguous()
+        g1 = g1.reshape(1).contiguous()
+        pgrads: List = []
+        g_fake = None if train_disc else ops.zeros(B, T, device=dev)
+        for i, p in enumerate(periods):
+            prm = list(params[12 * i: 12 * i + 12])
+            st = ctx.saved[i]
+            acts, hs, sc, S = st["acts"], st["hs"], st["scores"], st["S"]
+            H5 = hs[5]
+            nh = (S // 2) * H5
+            wpost = prm[10]
+            if train_disc:
+                gs = ops.empty(S * H5, 1, device=dev)
+                ops.hinge_loss(None, gs, sc, nh, -1.0, 1.0 / nh, wdev=g0)
+                ops.hinge_loss(None, gs, sc, nh, +1.0, 1.0 / nh, wdev=g0, s_off=nh)
+                Sx, roff = S, 0            # sequences taking part in backward, row offset (seqs)
+            else:
+                gs = ops.empty(S * H5, 1, device=dev)  # only the fake half is used
+                ops.hinge_loss(None, gs, sc, nh, -1.0, 1.0 / nh, wdev=g0, s_off=nh)
+                ops.lrelu_bwd(gs, sc, sc, 1.0 / nh, 1.0, 1, nh, nh, wdev=g1, g_off=nh, y_off=nh,
+                              r_off=0)
+                Sx, roff = S // 2, S // 2
+            grads_p = [None] * 12
+            # conv_post (1024 -> 1, 3 taps, stride 1)
+            y5 = acts[5]
+            if train_disc:
+                gwp = ops.zeros(1, 3 * 1024, device=dev)
+                ops.wgrad(gs, 1, 1, win1d(y5, S, H5, 1024, H5, 1, 1, 3), gwp)
+                grads_p[10] = unpack_conv_grad(gwp, wpost.shape)
+                gb = ops.zeros(1, device=dev)
+                ops.colsum(gb, gs, S * H5, 1)
+                grads_p[11] = gb
+            g = _conv1d_dgrad(gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5)
+            for l in reversed(range(5)):
+                w = prm[2 * l]
+                Cin, Cout, stv = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
+                Hin, Hout = hs[l], hs[l + 1]
+                y = acts[l + 1]
+                yoff = roff * Hout * Cout
+                n = Sx * Hout * Cout
+                if (not train_disc) and l >= 1:
+                    ops.lrelu_bwd(g, y, y, 1.0 / n, SLOPE, 1, n, n, wdev=g1, y_off=yoff, r_off=0)
+                else:
+                    ops.lrelu_bwd(g, y, None, 0.0, SLOPE, 1, n, n, y_off=yoff)
+                if train_disc:
+                    gwp = ops.zeros(Cout, 5 * Cin, device=dev)
+                    ops.wgrad(g, Cout, Cout, win1d(acts[l], S, Hin, Cin, Hout, stv, 2, 5), gwp)
+                    grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
+                    gb = ops.zeros(Cout, device=dev)
+                    ops.colsum(gb, g, S * Hout, Cout)
+                    grads_p[2 * l + 1] = gb
+                if l > 0 or not train_disc:
+                    g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin)
+            if not train_disc:
+                # g: (B*p*H0, 1) gradient of the folded image of the generated half
+                ops.period_fold_bwd(g_fake, g, B, T, p, hs[0], True)
+            pgrads += grads_p
+        ctx.saved = None
+        return tuple([None, g_fake, None, None] + pgrads)
+
+
+# =====================================================================================
+# Multi-resolution STFT discriminator
+# =====================================================================================
+MRD_BANDS = ((0.0, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0))
+MRD_LAYERS = ((9, 1), (9, 2), (9, 2), (9, 2), (3, 1))  # (kw, stride_w); kh = 3, pad = (1, kw//2)
+MRD_CH = 32
+
+_DFT_INT_CACHE = {}
+
+
+def dft_interleaved(n_fft: int, device):
+    """Analysis matrix with rows [Re0, Im0, Re1, Im1, ...]: the STFT GEMM then writes the
+    (frame, freq, {re,im}) channels-last image of discriminators.py:191-193 directly."""
+    key = (n_fft, str(device))
+    if key not in _DFT_INT_CACHE:
+        wd, _ = dft_matrices(n_fft, device)
+        nb = n_fft // 2 + 1
+        wi = torch.stack([wd[:nb], wd[nb:]], dim=1).reshape(2 * nb, n_fft).contiguous()
+        _DFT_INT_CACHE[key] = wi
+    return _DFT_INT_CACHE[key]
+
+
+def mrd_params(mrd) -> list:
+    p = []
+    for d in mrd.discriminators:
+        for stack in d.band_convs:
+            for c in stack:
+                p += [c.weight, c.bias]
+        p += [d.conv_post.weight, d.conv_post.bias]
+    return p
+
+
+N_MRD_PARAMS = 5 * 5 * 2 + 2
+
+
+def _band_edges(n_fft: int):
+    nb = n_fft // 2 + 1
+    return [(int(lo * nb), int(hi * nb)) for lo, hi in MRD_BANDS]
+
+
+def _mrd_forward_one(x2, win: int, prm: list):
+    dev = x2.device
+    S, T = x2.shape
+    hop = win // 4
+    Ft = 1 + T // hop
+    nb = win // 2 + 1
+    xn = ops.empty(S, T, device=dev)
+    stats = ops.empty(S, 3, device=dev)
+    ops.peaknorm_fwd(xn, stats, x2, S, T)
+    ldp = ops.pad4(2 * nb)
+    packed = ops.empty(S * Ft, ldp, device=dev)
+    gemm(win1d(xn, S, T, 1, Ft, hop, win // 2, win, reflect=True), mat(dft_interleaved(win, dev)),
+         packed)
+    bands = _band_edges(win)
+    # widths per band per layer
+    widths = []
+    for lo, hi in bands:
+        w = [hi - lo]
+        for kw, sw in MRD_LAYERS:
+            w.append((w[-1] + 2 * (kw // 2) - kw) // sw + 1)
+        widths.append(w)
+    Wcat = sum(w[5] for w in widths)
+    cat = ops.empty(S * Ft * Wcat, MRD_CH, device=dev)
+    acts = []
+    foff = 0
+    for bi, (lo, hi) in enumerate(bands):
+        ws = widths[bi]
+        layer_out = []
+        x, x_is_spec = packed, True
+        for l, (kw, sw) in enumerate(MRD_LAYERS):
+            w, b = prm[(bi * 5 + l) * 2], prm[(bi * 5 + l) * 2 + 1]
+            Cin = 2 if l == 0 else MRD_CH
+            Win, Wout = ws[l], ws[l + 1]
+            wp = pack_conv_weight(w)
+            if x_is_spec:
+                A = win2d(x, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2, line_stride=ldp,
+                          seq_stride=Ft * ldp, offset=lo * 2)
+            else:
+                A = win2d(x, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2)
+            if l < 4:
+                y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
+                gemm(A, mat(wp), y, bias=b, lrelu=SLOPE)
+            else:
+                y = None
+                gemm(A, mat(wp), cat, bias=b, lrelu=SLOPE,
+                     rowmap=(Wout, Wcat * MRD_CH, MRD_CH, foff * MRD_CH))
+            layer_out.append(y)
+            x, x_is_spec = y, False
+        acts.append(layer_out)
+        foff += ws[5]
+    wpost, bpost = prm[50], prm[51]
+    scores = ops.empty(S * Ft * Wcat, 1, device=dev)
+    gemm(win2d(cat, S, Ft, Wcat, MRD_CH, Wcat, 3, 3, 1, 1, 1), mat(pack_conv_weight(wpost)), scores,
+         bias=bpost)
+    return dict(xn=xn, stats=stats, packed=packed, ldp=ldp, Ft=Ft, nb=nb, hop=hop, bands=bands,
+                widths=widths, Wcat=Wcat, cat=cat, acts=acts, scores=scores)
+
+
+def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq=None, g_off=0,
+                  x_line=None, x_off=0):
+    """Data gradient of a (3, kw) conv with stride (1, sw), pad (1, kw//2).
+    g_pre: image (S, H, Wout, Cout) starting g_off floats in (line / seq strides optional);
+    gx: destination image with line stride x_line floats (default Win*Cin) starting x_off."""
+    Cin, kh, kw = w.shape[1], w.shape[2], w.shape[3]
+    dev = g_pre.device
+    pw = kw // 2
+    if x_line is None:
+        x_line = Win * Cin
+    for rho, j0, ntw, e0, Lq in _residues(kw, sw, pw, Win):
+        if Lq == 0:
+            continue
+        wq = ops.empty(kh * ntw * Cout, Cin, device=dev)
+        ops.permute4(wq, w, (kh, ntw, Cout, Cin), (-kw, -sw, Cin * kh * kw, kh * kw),
+                     in_offset=(kh - 1) * kw + j0 + sw * (ntw - 1))
+        A = win2d(g_pre, S, H, Wout, Cout, Lq, kh, ntw, 1, 1, (ntw - 1) - e0, line_stride=g_line,
+                  seq_stride=g_seq, offset=g_off)
+        gemm(A, mat(wq), gx, form=1, rowmap=(Lq, x_line, sw * Cin, x_off + rho * Cin))
+    return gx
+
+
+class MRDLossFn(torch.autograd.Function):
+    """(real, fake) -> (loss0, loss1) as MPDLossFn, for the STFT-band discriminators."""
+
+    @staticmethod
+    def forward(ctx, real, fake, train_disc: bool, fft_sizes, *params):
+        dev = real.device
+        B, T = real.shape
+        x2 = stack_pair(real, fake)
+        losses = ops.zeros(2, device=dev)
+        saved = []
+        for i, win in enumerate(fft_sizes):
+            prm = list(params[N_MRD_PARAMS * i: N_MRD_PARAMS * (i + 1)])
+            st = _mrd_forward_one(x2, win, prm)
+            Ft, Wcat = st["Ft"], st["Wcat"]
+            nh = B * Ft * Wcat
+            sc = st["scores"]
+            if train_disc:
+                ops.hinge_loss(losses, None, sc, nh, -1.0, 1.0 / nh)
+                ops.hinge_loss(losses, None, sc, nh, +1.0, 1.0 / nh, s_off=nh)
+            else:
+                ops.hinge_loss(losses, None, sc, nh, -1.0, 1.0 / nh, s_off=nh)
+                foff = 0
+                for bi in range(5):
+                    ws = st["widths"][bi]
+                    for l in range(1, 4):  # band layers 1..3 (contiguous maps)
+                        y = st["acts"][bi][l]
+                        n = y.numel() // 2
+                        ops.l1_loss_ab(losses, None, y, 0, y, n, 1, n, n, 1.0 / n, loss_offset=1)
+                    # layer 4 lives in the concatenated buffer: (B*Ft rows, W4*32 cols) slice
+                    cat = st["cat"]
+                    cols = ws[5] * MRD_CH
+                    ld = Wcat * MRD_CH
+                    half = B * Ft * ld
+                    ops.l1_loss_ab(losses, None, cat, foff * MRD_CH, cat, half + foff * MRD_CH,
+                                   B * Ft, cols, ld, 1.0 / (B * Ft * cols), loss_offset=1)
+                    foff += ws[5]
+                ops.l1_loss_ab(losses, None, sc, 0, sc, nh, 1, nh, nh, 1.0 / nh, loss_offset=1)
+            saved.append(st)
+        ctx.saved = saved
+        ctx.x2 = x2
+        ctx.params = params
+        ctx.meta = (B, T, train_disc, tuple(fft_sizes))
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        B, T, train_disc, fft_sizes = ctx.meta
+        params = ctx.params
+        dev = g0.device
+        g0 = g0.reshape(1).contiguous()
+        g1 = g1.reshape(1).contiguous()
+        pgrads: List = []
+        g_fake = None if train_disc else ops.zeros(B, T, device=dev)
+        C = MRD_CH
+        for i, win in enumerate(fft_sizes):
+            prm = list(params[N_MRD_PARAMS * i: N_MRD_PARAMS * (i + 1)])
+            st = ctx.saved[i]
+            Ft, Wcat, nb, ldp, hop = st["Ft"], st["Wcat"], st["nb"], st["ldp"], st["hop"]
+            sc, cat, packed = st["scores"], st["cat"], st["packed"]
+            S = 2 * B
+            nh = B * Ft * Wcat
+            grads_w = [None] * N_MRD_PARAMS
+            gs = ops.empty(S * Ft * Wcat, 1, device=dev)
+            if train_disc:
+                ops.hinge_loss(None, gs, sc, nh, -1.0, 1.0 / nh, wdev=g0)
+                ops.hinge_loss(None, gs, sc, nh, +1.0, 1.0 / nh, wdev=g0, s_off=nh)
+                Sx, soff = S, 0
+            else:
+                ops.hinge_loss(None, gs, sc, nh, -1.0, 1.0 / nh, wdev=g0, s_off=nh)
+                ops.lrelu_bwd(gs, sc, sc, 1.0 / nh, 1.0, 1, nh, nh, wdev=g1, g_off=nh, y_off=nh,
+                              r_off=0)
+                Sx, soff = B, B   # sequences in backward, first sequence
+            wpost = prm[50]
+            if train_disc:
+                gwp = ops.zeros(1, 9 * C, device=dev)
+                ops.wgrad(gs, 1, 1, win2d(cat, S, Ft, Wcat, C, Wcat, 3, 3, 1, 1, 1), gwp)
+                grads_w[50] = unpack_conv_grad(gwp, wpost.shape)
+                gb = ops.zeros(1, device=dev)
+                ops.colsum(gb, gs, S * Ft * Wcat, 1)
+                grads_w[51] = gb
+            # gradient of the concatenated layer-4 maps (only the sequences in backward)
+            gcat = ops.empty(Sx * Ft * Wcat, C, device=dev)
+            _conv2d_dgrad(gs, Sx, Ft, Wcat, 1, wpost, 1, Wcat, gcat, g_off=soff * Ft * Wcat)
+            g_packed = None
+            if not train_disc:
+                g_packed = ops.empty(B * Ft, ldp, device=dev)
+            foff = 0
+            ldc = Wcat * C
+            for bi, (lo, hi) in enumerate(st["bands"]):
+                ws = st["widths"][bi]
+                # ---- layer 4 (its output is a strided slice of cat / gcat)
+                W4 = ws[5]
+                cols = W4 * C
+                y_off = soff * Ft * ldc + foff * C
+                if train_disc:
+                    ops.lrelu_bwd(gcat, cat, None, 0.0, SLOPE, Sx * Ft, cols, ldc, g_off=foff * C,
+                                  y_off=y_off)
+                else:
+                    ops.lrelu_bwd(gcat, cat, cat, 1.0 / (B * Ft * cols), SLOPE, Sx * Ft, cols, ldc,
+                                  wdev=g1, g_off=foff * C, y_off=y_off, r_off=foff * C)
+                g = None
+                for l in reversed(range(5)):
+                    kw, sw = MRD_LAYERS[l]
+                    w = prm[(bi * 5 + l) * 2]
+                    Cin = 2 if l == 0 else C
+                    Win, Wout = ws[l], ws[l + 1]
+                    if l < 4:
+                        y = st["acts"][bi][l]
+                        n = Sx * Ft * Wout * C
+                        yoff = soff * Ft * Wout * C
+                        if (not train_disc) and l >= 1:
+                            ops.lrelu_bwd(g, y, y, 1.0 / n, SLOPE, 1, n, n, wdev=g1, y_off=yoff,
+                                          r_off=0)
+                        else:
+                            ops.lrelu_bwd(g, y, None, 0.0, SLOPE, 1, n, n, y_off=yoff)
+                    # operands describing this layer's pre-activation gradient image
+                    if l == 4:
+                        dy_line, dy_seq, dy_off, dy_t = ldc, Ft * ldc, foff * C, gcat
+                    else:
+                        dy_line, dy_seq, dy_off, dy_t = None, None, 0, g
+                    if train_disc:
+                        x_in = packed if l == 0 else st["acts"][bi][l - 1]
+                        if l == 0:
+                            X = win2d(x_in, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2,
+                                      line_stride=ldp, seq_stride=Ft * ldp, offset=lo * 2)
+                        else:
+                            X = win2d(x_in, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2)
+                        gwp = ops.zeros(C, 3 * kw * Cin, device=dev)
+                        if l == 4:
+                            dY = win1d(gcat, S * Ft, Wcat, C, W4, 1, -foff, 1)
+                        else:
+                            dY = mat(g, S * Ft * Wout, C)
+                        tiles = ((3 * kw * Cin + 255) // 256)
+                        gemm(dY, X, gwp, form=2, atomic=True,
+                             split_k=ops.split_for(X.rows, tiles))
+                        grads_w[(bi * 5 + l) * 2] = unpack_conv_grad(gwp, w.shape)
+                        gb = ops.zeros(C, device=dev)
+                        if l == 4:
+                            _colsum_strided(gb, gcat, S * Ft, W4, C, ldc, foff * C)
+                        else:
+                            ops.colsum(gb, g, S * Ft * Wout, C)
+                        grads_w[(bi * 5 + l) * 2 + 1] = gb
+                    if l > 0:
+                        gx = ops.empty(Sx * Ft * Win, Cin, device=dev)
+                        _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, gx, g_line=dy_line,
+                                      g_seq=dy_seq, g_off=dy_off)
+                        g = gx
+                    elif not train_disc:
+                        _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, g_packed, g_line=dy_line,
+                                      g_seq=dy_seq, g_off=dy_off, x_line=ldp, x_off=lo * 2)
+                foff += W4
+            if not train_disc:
+                gfr = ops.empty(B * Ft, win, device=dev)
+                gemm(mat(g_packed, B * Ft, 2 * nb), mat(dft_interleaved(win, dev)), gfr, form=1)
+                gxn = ops.empty(B, T, device=dev)
+                ops.frames_fold(gfr, gxn, B, Ft, win, hop, T, False)
+                gx2 = ops.empty(B, T, device=dev)
+                # x2 = [real; fake]: the generated half starts at row B
+                ops.call("f2g_peaknorm_bwd", ops.ptr(gx2), ops.ptr(gxn),
+                         ops.ptr(ctx.x2) + 4 * B * T, ops.ptr(st["stats"]) + 4 * 3 * B, B, T)
+                ops.axpby_rows(g_fake, g_fake, gx2, sa=1.0, sb=1.0)
+            pgrads += grads_w
+        ctx.saved = None
+        return tuple([None, g_fake, None, None] + pgrads)
+
+
+def _colsum_strided(out, a, nrows, W, C, ld, off):
+    """out[c] += sum over (row, w) of a[row*ld + off + w*C + c]: column sums of the (nrows, W*C)
+    slice, then of the resulting (W, C) table."""
+    tmp = ops.zeros(W * C, device=a.device)
+    ops.call("f2g_colsum", ops.ptr(tmp), ops.ptr(a) + 4 * off, ld, None, 0, nrows, W * C)
+    ops.call("f2g_colsum", ops.ptr(out), ops.ptr(tmp), C, None, 0, W, C)
+
+
+# =====================================================================================
+# Multi-scale log-mel reconstruction loss (gan.py:89-99)
+# =====================================================================================
+class MelReconLossFn(torch.autograd.Function):
+    """sum_i mean |log clip(mel_i(real)) - log clip(mel_i(fake))|; gradient to `fake` only."""
+
+    @staticmethod
+    def forward(ctx, real, fake, specs):
+        """specs: tuple of (n_fft, hop, fb (n_freq, n_mels))."""
+        dev = real.device
+        B, T = real.shape
+        x2 = stack_pair(real, fake)
+        loss = ops.zeros(1, device=dev)
+        saved = []
+        for n_fft, hop, fb in specs:
+            S, packed, spec, F = filterbank_spec(x2, n_fft, hop, fb, 1)
+            n = B * F * fb.shape[1]
+            ops.l1_loss_ab(loss, None, S, 0, S, n, 1, n, n, 1.0 / n, clip=1e-7)
+            saved.append((S, packed, F))
+        ctx.saved = saved
+        ctx.specs = specs
+        ctx.dims = (B, T)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T = ctx.dims
+        dev = g.device
+        gw = g.reshape(1).contiguous()
+        g_fake = ops.empty(B, T, device=dev)
+        for i, (n_fft, hop, fb) in enumerate(ctx.specs):
+            S, packed, F = ctx.saved[i]
+            nm = fb.shape[1]
+            n = B * F * nm
+            gS = ops.empty(B * F, nm, device=dev)
+            # gb follows b's layout: write straight into a fake-half-sized buffer via offsets
+            ops.call("f2g_l1_loss", None, ops.ptr(gS), ops.ptr(S), ops.ptr(S) + 4 * n, 1, n, n,
+                     1.0 / n, 1e-7, ops.ptr(gw))
+            filterbank_spec_bwd(gS, packed[B * F:], n_fft, hop, fb, 1, B, T, F, g_fake, i > 0)
+        ctx.saved = None
+        return None, g_fake, None

@@ -1,0 +1,120 @@
+"""GPU parity of the GAN-stage loss stack: discriminator scores / feature maps against the CPU
+oracle, and D-step / G-step losses + gradients against the reference's golden vectors."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+TINY = dict(sampling_rate=24000, n_mels=100, mel_n_fft=1024, mel_hop_length=256,
+            n_ffts=(512, 256, 128), hop_lengths=(256, 128, 64), channels=(48, 32, 24),
+            time_embed_channels=32, hidden_factor=3, num_layers=(2, 2, 2),
+            cond_enc_channels=32, cond_enc_num_layers=1)
+
+
+@pytest.fixture(scope="module")
+def f2g():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import flow2gan_amd
+    return flow2gan_amd
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def relerr(got, want):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    return float((got - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+
+
+def build_gan(f2g, g):
+    from flow2gan_amd.models.gan import GAN
+    gen = f2g.MelAudioGenerator(**TINY)
+    gen.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w/")})
+    gen.branch_dropout = 0.0
+    torch.manual_seed(int(g["d_seed"]))
+    gan = GAN(gen)
+    sd = {k: v for k, v in gan.discriminator.state_dict().items() if "spec_fn" not in k}
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].numpy().astype(np.float32).tobytes())
+    assert h.hexdigest() == bytes(g["d_digest"]).decode(), "discriminator init differs from reference"
+    return gan.to(DEV)
+
+
+def test_discriminator_scores_and_fmaps_vs_oracle(f2g):
+    import flow2gan_oracle as O
+    from flow2gan_amd.models.discriminators import (MultiPeriodDiscriminator,
+                                                    MultiResolutionDiscriminator)
+    torch.manual_seed(5)
+    x = 0.1 * torch.randn(2, 6001)
+    x[1] *= 3.0
+    for Oc, Hc in ((O.MultiPeriodDiscriminator, MultiPeriodDiscriminator),
+                   (O.MultiResolutionDiscriminator, MultiResolutionDiscriminator)):
+        torch.manual_seed(9)
+        do = Oc()
+        dh = Hc()
+        dh.load_state_dict(do.state_dict(), strict=False)
+        dh = dh.to(DEV)
+        with torch.no_grad():
+            sr_o, _, fr_o, _ = do(x, x)
+        sr_h, _, fr_h, _ = dh(x.to(DEV), x.to(DEV))
+        for i, (a, b) in enumerate(zip(sr_h, sr_o)):
+            assert relerr(a.reshape(b.shape), b) < 5e-4, (Oc.__name__, "score", i)
+        for i, (fa, fb) in enumerate(zip(fr_h, fr_o)):
+            assert len(fa) == len(fb)
+            for j, (a, b) in enumerate(zip(fa, fb)):
+                assert a.shape == b.shape, (Oc.__name__, i, j, a.shape, b.shape)
+                assert relerr(a, b) < 5e-4, (Oc.__name__, "fmap", i, j, relerr(a, b))
+
+
+@pytest.mark.parametrize("tag,n", [("n1", 1), ("n2", 2)])
+def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, monkeypatch):
+    g = golden("tiny_stage2")
+    gan = build_gan(f2g, g)
+    monkeypatch.setattr(random, "random", lambda: 0.0)
+    mel, audio, noise = T(g["mel"]).to(DEV), T(g["audio"]).to(DEV), T(g["noise"]).to(DEV)
+    lens = T(g[f"{tag}/lens"])
+    # ---- discriminator step
+    d = gan(mel, audio, lens, n, True, noise=noise)
+    want = g[f"{tag}/D/losses"]
+    assert np.allclose([float(v) for v in d], want, rtol=2e-5, atol=2e-5), ([float(v) for v in d], want)
+    gan.zero_grad()
+    (1.0 * d[0] + 0.1 * d[1]).backward()
+    worst = []
+    for k, p in gan.discriminator.named_parameters():
+        assert p.grad is not None, k
+        st = g[f"{tag}/D/gstat/{k}"]
+        got_abs = float(p.grad.double().abs().sum())
+        worst.append((abs(got_abs - st[1]) / (st[1] + 1e-3), k))
+        key = f"{tag}/D/g/{k}"
+        if key in g:
+            ref = T(g[key])
+            err = float((p.grad.cpu().double() - ref.double()).abs().max())
+            # exactly-zero reference entries (cancelling hinge terms) get an absolute floor
+            assert err < 5e-3 * float(ref.abs().max()) + 2e-5, (k, err)
+    worst.sort(reverse=True)
+    assert worst[0][0] < 5e-3, worst[:5]
+    for p in gan.generator.parameters():
+        assert p.grad is None
+    # ---- generator step
+    gan.zero_grad()
+    ls = gan(mel, audio, lens, n, False, noise=noise)
+    want = g[f"{tag}/G/losses"]
+    assert np.allclose([float(v) for v in ls], want, rtol=5e-5, atol=2e-5), ([float(v) for v in ls], want)
+    total = sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ls))
+    total.backward()
+    worst = []
+    for k, p in gan.generator.named_parameters():
+        ref = T(g[f"{tag}/G/g/{k}"])
+        assert p.grad is not None, k
+        worst.append((relerr(p.grad, ref), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 5e-3, worst[:8]
