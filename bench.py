@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Flow2GAN hot-path benchmark on MI355X (contract: python bench.py --gpus N --steps K --warmup W).
+
+Metric (BASELINE.json): audio-seconds/sec of the GAN-stage train step -- one discriminator step +
+one generator step of `mel_24k_base`, each on its own synthetic batch of B x 1 s of 24 kHz audio
+(reference finetune.py:569-631 alternation, loss weights finetune.py:453-454,478-482), fp32,
+G+D forward/backward + data-parallel gradient all-reduce.  One process per GPU; for N > 1 the
+driver launches this file through torch.distributed.run and the ranks exchange gradients over
+RCCL/xGMI (weak scaling: B per GPU fixed).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fp32-MFMA implicit GEMM,
+timed with HIP events around every launch of one extra, untimed step) and `cpu_baseline` (the CPU
+oracle of the same step timed on the host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+D_WEIGHTS = (1.0, 0.1)                    # finetune.py:453-454
+G_WEIGHTS = (1.0, 0.1, 1.0, 0.1, 45.0)    # finetune.py:478-482
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (items of 1 s)")
+    ap.add_argument("--n-timesteps", type=int, default=1, help="ODE steps unrolled in the GAN stage")
+    ap.add_argument("--workload", default="gan_stage2",
+                    choices=["gan_stage2", "stage1", "infer4"],
+                    help="gan_stage2 = the BASELINE metric; stage1 / infer4 = configs 3 / 2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def synthetic_batch(B, T, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    audio = (0.1 * torch.randn(B, T, generator=g)).clamp_(-1.0, 1.0)
+    return audio.to(device)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torchrun"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import flow2gan_amd
+    from flow2gan_amd import dist as fdist
+    from flow2gan_amd import ops
+    from flow2gan_amd.models.config import get_gan_config, get_generator_config
+    from flow2gan_amd.models.gan import GAN
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        fdist.setup_dist(rank, world, backend="nccl")
+
+    B, T, sr = args.batch, 24000, 24000
+    torch.manual_seed(1234)  # same weights on every rank (pretrain.py:750, finetune.py:868)
+    gen = flow2gan_amd.MelAudioGenerator(**get_generator_config("mel_24k_base"))
+    gen.branch_dropout = 0.0 if args.workload == "gan_stage2" else gen.branch_dropout
+    gan = GAN(gen, **get_gan_config("gan_multi_scale_mel_recon")).to(device)
+    logmel = flow2gan_amd.LogMelSpectrogram(sr, 1024, 256, 100).to(device)
+    reducer = fdist.GradReducer()
+    g_params = list(gan.generator.parameters())
+    d_params = list(gan.discriminator.parameters())
+
+    audio_d = synthetic_batch(B, T, 1234 + rank, device)
+    audio_g = synthetic_batch(B, T, 4321 + rank, device)
+    lens = torch.full((B,), T, dtype=torch.int64)
+    nts = args.n_timesteps
+
+    def zero(params):
+        for p in params:
+            p.grad = None
+
+    def step():
+        if args.workload == "gan_stage2":
+            # discriminator step on its batch
+            zero(d_params)
+            cond = logmel(audio_d)
+            mp, mr = gan(cond, audio_d, lens, nts, True)
+            (D_WEIGHTS[0] * mp + D_WEIGHTS[1] * mr).backward()
+            reducer.reduce(d_params)
+            # generator step on a new batch
+            zero(g_params)
+            cond = logmel(audio_g)
+            ls = gan(cond, audio_g, lens, nts, False)
+            sum(w * l for w, l in zip(G_WEIGHTS, ls)).backward()
+            reducer.reduce(g_params)
+            return 2 * B * (T / sr)
+        if args.workload == "stage1":
+            gen.train()
+            zero(g_params)
+            cond = logmel(audio_g)
+            gen(cond, audio_g, lens).backward()
+            reducer.reduce(g_params)
+            return B * (T / sr)
+        gen.eval()
+        with torch.no_grad():
+            cond = logmel(audio_g[:, :94 * 256])
+            out = gen.infer(cond, None, 4)
+        return B * out.shape[1] / sr
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    audio_s = 0.0
+    for _ in range(args.steps):
+        audio_s += step()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    value = world * audio_s / elapsed
+
+    roofline = None
+    if not args.no_roofline:
+        torch.cuda.synchronize()
+        ops.GEMM_TIMER = ops.GemmTimer()
+        step()
+        torch.cuda.synchronize()
+        n, flops, secs = ops.GEMM_TIMER.summary()
+        ops.GEMM_TIMER = None
+        achieved = flops / secs / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA implicit GEMM, all forms)",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": n,
+                    "gemm_share_of_step": round(secs / (elapsed / args.steps), 3),
+                    "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, nts)
+
+    if rank == 0:
+        line = {
+            "metric": "audio-seconds/sec (train step, G+D fwd/bwd) mel_24k_base",
+            "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (0.1*randn clipped, seeded per rank); seeded random-init weights",
+            "config": {"workload": {"gan_stage2": "mel_24k_base GAN stage-2 train step: D-step + G-step, "
+                                                  "each on its own batch (MPD+MRD+FM+multi-scale mel), "
+                                                  "fwd+bwd+grad all-reduce, no optimizer (metric is fwd/bwd)",
+                                    "stage1": "mel_24k_base flow-matching stage-1 fwd+bwd",
+                                    "infer4": "mel_24k_base 4-step Euler inference"}[args.workload],
+                       "per_gpu_batch": B, "seconds_per_item": T / sr, "n_timesteps": nts,
+                       "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        fdist.cleanup_dist()
+
+
+def cpu_baseline(workload: str, nts: int):
+    """The CPU oracle (oracle/flow2gan_oracle.py, a port validated against the reference) on the
+    host cores, bounded: B=1 x 1 s, one warm-up + one timed step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import flow2gan_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    gen = O.build_generator("mel_24k_base")
+    B, T = 1, 24000
+    audio = (0.1 * torch.randn(B, T)).clamp_(-1, 1)
+    lens = torch.full((B,), T)
+    lm = O.LogMelSpectrogram()
+    if workload == "gan_stage2":
+        gen.branch_dropout = 0.0
+        gan = O.GAN(gen)
+
+        def step():
+            gan.zero_grad()
+            mp, mr = gan(lm(audio), audio, lens, nts, True)
+            (D_WEIGHTS[0] * mp + D_WEIGHTS[1] * mr).backward()
+            gan.zero_grad()
+            ls = gan(lm(audio), audio, lens, nts, False)
+            sum(w * l for w, l in zip(G_WEIGHTS, ls)).backward()
+            return 2 * B * 1.0
+    elif workload == "stage1":
+        gen.train()
+
+        def step():
+            gen.zero_grad()
+            gen(lm(audio), audio, lens).backward()
+            return B * 1.0
+    else:
+        gen.eval()
+
+        def step():
+            with torch.no_grad():
+                gen.infer(lm(audio[:, :94 * 256]), None, 4)
+            return B * 94 * 256 / 24000
+    step()
+    t0 = time.perf_counter()
+    done = step()
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch CPU fp32 restatement), B={B} x 1 s, 1 warm-up + 1 timed step "
+                      f"of the same workload ({dt:.1f} s)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -135,8 +135,41 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.E = e
     d.form = form
     d.split_k = split_k
-    call("f2g_gemm", C.byref(d))
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.launch(d, A, Bm, form)
+    else:
+        call("f2g_gemm", C.byref(d))
     return out
+
+
+class GemmTimer:
+    """bench.py instrumentation: HIP events around every f2g_gemm launch on the launch stream and
+    the launch's algorithmic FLOPs (2 * M * N * K of the implicit GEMM it represents)."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, d, A, Bm, form):
+        if form == 2:
+            flops = 2.0 * A.rows * A.cols * Bm.cols
+        elif form == 1:
+            flops = 2.0 * A.rows * A.cols * Bm.cols
+        else:
+            flops = 2.0 * A.rows * A.cols * Bm.rows
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        call("f2g_gemm", C.byref(d))
+        e.record()
+        self.records.append((s, e, flops))
+
+    def summary(self):
+        """(launches, total flops, total seconds) -- call after a device synchronise."""
+        t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
+        return len(self.records), sum(f for _, _, f in self.records), t
+
+
+GEMM_TIMER = None
 
 
 def split_for(reduction_rows: int, out_tiles: int) -> int:
