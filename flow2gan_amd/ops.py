@@ -148,6 +148,7 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []
+        self.shapes = []
 
     def launch(self, d, A, Bm, form):
         if form == 2:
@@ -162,6 +163,23 @@ class GemmTimer:
         call("f2g_gemm", C.byref(d))
         e.record()
         self.records.append((s, e, flops))
+        nn = Bm.rows if form == 0 else Bm.cols
+        mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
+        self.shapes.append((form, mm, nn, kk))
+
+    def report(self, top: int = 25) -> str:
+        """Per-shape table (form, M, N, K): calls, total ms, TFLOP/s -- after a synchronise."""
+        agg = {}
+        for (s, e, f), shp in zip(self.records, self.shapes):
+            a = agg.setdefault(shp, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+            a[2] += f
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+        out = ["form      M      N      K  calls  total_ms  TFLOP/s"]
+        for (form, m, n, k), (c, ms, f) in rows:
+            out.append(f"{form:4d} {m:6d} {n:6d} {k:6d} {c:6d} {ms:9.3f} {f / (ms * 1e-3) / 1e12:8.1f}")
+        return "\n".join(out)
 
     def summary(self):
         """(launches, total flops, total seconds) -- call after a device synchronise."""
@@ -174,8 +192,16 @@ GEMM_TIMER = None
 
 def split_for(reduction_rows: int, out_tiles: int) -> int:
     """Split-K factor for weight-gradient GEMMs: fill ~2 waves of the 256 CUs."""
-    want = max(1, 512 // max(1, out_tiles))
-    return max(1, min(want, reduction_rows // 256 if reduction_rows >= 256 else 1))
+    slots = 512  # 256 CUs x 2 resident blocks
+    smax = max(1, min(32, reduction_rows // 512))
+    best, best_eff = 1, 0.0
+    for s in range(1, smax + 1):
+        blocks = out_tiles * s
+        eff = blocks / (((blocks + slots - 1) // slots) * slots)
+        # prefer fewer splits (fewer atomics) unless occupancy improves by > 3 %
+        if eff > best_eff + 0.03:
+            best, best_eff = s, eff
+    return best
 
 
 def wgrad(dY, M: int, ldy: int, X: Operand, g_out, ldg: Optional[int] = None, out_offset: int = 0,
