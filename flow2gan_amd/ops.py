@@ -193,13 +193,14 @@ GEMM_TIMER = None
 def split_for(reduction_rows: int, out_tiles: int) -> int:
     """Split-K factor for weight-gradient GEMMs: fill ~2 waves of the 256 CUs."""
     slots = 512  # 256 CUs x 2 resident blocks
-    smax = max(1, min(32, reduction_rows // 512))
+    smax = max(1, min(1024, reduction_rows // 256))
+    cands = set(range(1, 17)) | {(slots * m + out_tiles - 1) // out_tiles for m in (1, 2)}
     best, best_eff = 1, 0.0
-    for s in range(1, smax + 1):
+    for s in sorted(c for c in cands if 1 <= c <= smax):
         blocks = out_tiles * s
         eff = blocks / (((blocks + slots - 1) // slots) * slots)
-        # prefer fewer splits (fewer atomics) unless occupancy improves by > 3 %
-        if eff > best_eff + 0.03:
+        # prefer fewer splits (fewer atomics) unless occupancy improves by > 3 % (relative)
+        if eff > best_eff * 1.03:
             best, best_eff = s, eff
     return best
 
