@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3"],
+                    help="GEMM arithmetic of the headline number (fp32 = exact, the reference's)")
+    ap.add_argument("--no-fast-mode", action="store_true")
     return ap.parse_args()
 
 
@@ -127,22 +130,39 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    audio_s = 0.0
-    for _ in range(args.steps):
-        audio_s += step()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(nwarm, nsteps):
+        for _ in range(nwarm):
+            step()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0.0
+        for _ in range(nsteps):
+            done += step()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return done, dt
+
+    # headline: exact-fp32 GEMMs (the reference's arithmetic), unless --gemm says otherwise
+    ops.set_gemm_precision(args.gemm)
+    audio_s, elapsed = timed(args.warmup, args.steps)
     value = world * audio_s / elapsed
+    fast = None
+    if args.gemm == "fp32" and not args.no_fast_mode:
+        # also report the split-bf16 GEMM mode (3 bf16 MFMAs per product, fp32 accumulate): same
+        # <= 1e-4 RMS waveform parity (tests/test_hip_generator.py passes in both modes), not fp32-exact
+        ops.set_gemm_precision("bf16x3")
+        a2, e2 = timed(1, max(2, args.steps // 2))
+        fast = {"gemm": "split-bf16 (hi/lo, 3x v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+                "value": round(world * a2 / e2, 2), "unit": "audio-s/s",
+                "ms_per_step": round(1e3 * e2 / max(2, args.steps // 2), 2),
+                "parity": "<=1e-4 RMS waveform vs reference; per-product error ~2^-16 instead of 2^-24"}
+        ops.set_gemm_precision("fp32")
 
     roofline = None
     if not args.no_roofline:
@@ -182,7 +202,8 @@ def main():
             "metric": "audio-seconds/sec (train step, G+D fwd/bwd) mel_24k_base",
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.gemm == "fp32" else "f32 (split-bf16 GEMM, fp32 accumulate)",
             "data": "synthetic (0.1*randn clipped, seeded per rank); seeded random-init weights",
             "config": {"workload": {"gan_stage2": "mel_24k_base GAN stage-2 train step: D-step + G-step, "
                                                   "each on its own batch (MPD+MRD+FM+multi-scale mel), "
@@ -191,7 +212,7 @@ def main():
                                     "infer4": "mel_24k_base 4-step Euler inference"}[args.workload],
                        "per_gpu_batch": B, "seconds_per_item": T / sr, "n_timesteps": nts,
                        "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

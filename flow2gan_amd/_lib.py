@@ -43,7 +43,7 @@ class Epilogue(C.Structure):
 
 class GemmDesc(C.Structure):
     _fields_ = [("A", Operand), ("B", Operand), ("E", Epilogue), ("form", C.c_int32),
-                ("split_k", C.c_int32)]
+                ("split_k", C.c_int32), ("precision", C.c_int32), ("_pad3", C.c_int32)]
 
 
 class DwnormFwd(C.Structure):

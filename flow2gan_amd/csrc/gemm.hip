@@ -127,35 +127,57 @@ __device__ __forceinline__ float prelu1(float v, float a) { return v > 0.f ? v :
 // ------------------------------------------------------------------------------------------
 enum { PF = 0, GF = 1, SL = 2 };
 
-template <int MODE, bool KM, int TROWS, int TCOLS>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// v = hi + lo + O(2^-17 |v|): hi = round-to-nearest bf16 of v, lo = bf16 of the remainder
+__device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned short& lo) {
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
+
+template <int MODE, bool KM, int TROWS, int TCOLS, int NT = 256>
 struct Loader {
   static constexpr int CH = TCOLS / 4;
-  static constexpr int NLD = (TROWS * CH) / 256;
-  static constexpr int RSTEP = 256 / CH;
-  static_assert((TROWS * CH) % 256 == 0 && 256 % CH == 0, "tile must divide among 256 threads");
+  static constexpr int NCHUNK = TROWS * CH;
+  static constexpr bool PARTIAL = NCHUNK < NT;  // fewer chunks than threads: the rest idle
+  static constexpr int NLD = PARTIAL ? 1 : NCHUNK / NT;
+  static constexpr int RSTEP = NT / CH;
+  static_assert((PARTIAL || NCHUNK % NT == 0) && NT % CH == 0, "tile must divide among the threads");
+  bool active;
 
-  float4 r[NLD];
-  float4 r2[MODE == GF ? NLD : 1];      // lrelu_src values of the chunk
-  float4 a4;                            // PReLU slopes of the staged chunk's 4 columns
-  unsigned vmask;                       // bit q: chunk q holds valid data
+  // Staging registers of ONE slab.  Kept out of the loader object and declared per loop iteration
+  // in the kernels, so that nothing is loop-carried and the compiler can leave the loads in flight
+  // across the MFMA phase.
+  struct Stg {
+    float4 r[NLD];
+    float4 r2[MODE == GF ? NLD : 1];  // lrelu_src values of the chunk
+    float4 a4;                        // PReLU slopes of the chunk's 4 columns
+    unsigned vmask;                   // bit q: chunk q holds valid data
+  };
+  float4 a4fix;                       // KM: PReLU slopes of the thread's fixed columns
   unsigned cmask;                       // PF/KM: valid columns of the thread's fixed chunk
   unsigned rokm;                        // RM: bit q: row in range
   const float* p[MODE == PF ? NLD : 1];  // PF: chunk pointers, advanced per slab
-  long long pstep;                      // PF: pointer advance per slab
+  long long pstep;                      // PF: floats per unit of k (1 or ld)
+  int kbase;                            // PF: k of the pointers p[]
   int c0;                               // first window column (RM: + k0 per slab; KM: fixed)
   int row0;                             // KM: first reduction row of this thread
   RowCtx rc[(MODE != PF && !KM) ? NLD : 1];  // generic RM: decoded rows
   int seg, o;                           // generic KM: decoded fixed column
 
   __device__ __forceinline__ void init(const f2g_operand& S, int tr0, int tc0, int kbeg, int tid) {
-    const int ch = tid % CH, rr = tid / CH;
-    rokm = 0; cmask = 0; vmask = 0;
-    a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    active = !PARTIAL || tid < NCHUNK;
+    const int ch = tid % CH, rr = active ? tid / CH : 0;
+    rokm = 0; cmask = 0;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == PF) {
       const long long ld = S.seq_stride;
       if (!KM) {
         c0 = ch * 4;
-        pstep = BK;
+        pstep = 1;
+        kbase = kbeg;
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
           const int row = tr0 + rr + RSTEP * q;
@@ -166,12 +188,13 @@ struct Loader {
       } else {
         c0 = tc0 + ch * 4;
         row0 = rr;
-        pstep = (long long)BK * ld;
+        pstep = ld;
+        kbase = kbeg;
 #pragma unroll
         for (int j = 0; j < 4; ++j) cmask |= (c0 + j < S.cols ? 1u : 0u) << j;
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
-          p[q] = S.base + (long long)(kbeg + rr + RSTEP * q) * ld + (cmask ? c0 : 0);
+          p[q] = S.base + (long long)(kbeg + rr * NLD + q) * ld + (cmask ? c0 : 0);
         if (S.alpha) {
           if (cmask & 1) a4.x = S.alpha[c0];
           if (cmask & 2) a4.y = S.alpha[c0 + 1];
@@ -202,198 +225,166 @@ struct Loader {
         }
       }
     }
+    a4fix = a4;
   }
 
-  __device__ __forceinline__ void gchunk(const f2g_operand& S, int q, bool rowok, const RowCtx& rcx,
-                                         int c, int sg, int oo) {
+  __device__ __forceinline__ void gchunk(const f2g_operand& S, Stg& g, int q, bool rowok,
+                                         const RowCtx& rcx, int c, int sg, int oo) {
     if (MODE == GF) {
       const int l1 = rcx.l1b + sg, e = rcx.e0 + oo;
       const bool v = rowok && c < S.cols && (unsigned)l1 < (unsigned)S.L1 && e >= 0 &&
                      e + 3 < S.L0u;
       const long long off = v ? rcx.base + (long long)l1 * S.line_stride + e : 0;
-      r[q] = *reinterpret_cast<const float4*>(S.base + off);
-      if (S.lrelu_src) r2[q] = *reinterpret_cast<const float4*>(S.lrelu_src + off);
-      vmask |= (v ? 1u : 0u) << q;
+      g.r[q] = *reinterpret_cast<const float4*>(S.base + off);
+      if (S.lrelu_src) g.r2[q] = *reinterpret_cast<const float4*>(S.lrelu_src + off);
+      g.vmask |= (v ? 1u : 0u) << q;
     } else {
-      r[q] = rowok ? load_chunk_generic(S, rcx, c, sg, oo) : make_float4(0.f, 0.f, 0.f, 0.f);
-      vmask |= 1u << q;
+      g.r[q] = rowok ? load_chunk_generic(S, rcx, c, sg, oo) : make_float4(0.f, 0.f, 0.f, 0.f);
+      g.vmask |= 1u << q;
     }
   }
 
-  __device__ __forceinline__ void load(const f2g_operand& S, int k0) {
+  __device__ __forceinline__ void load(const f2g_operand& S, int k0, Stg& g) {
+    g.a4 = a4fix;
     if (MODE == PF) {
-      if (!KM && S.alpha) {
-        const int c = c0 + k0;  // full slabs only: c+3 < cols
-        a4 = *reinterpret_cast<const float4*>(S.alpha + c);
+      if (!KM) {
+        // PReLU slopes of this slab's columns (full slabs only: c+3 < cols); unconditional load
+        // through a valid dummy address keeps it off the control-flow / waitcnt path
+        const float* ap = S.alpha ? S.alpha + (c0 + k0) : S.base;
+        g.a4 = *reinterpret_cast<const float4*>(ap);
       }
+      // explicit slab offset (no running pointers): the kernels issue the load unconditionally
+      // with a clamped slab index, which keeps the loaded registers out of any control flow
+      const long long adv = (long long)(k0 - kbase) * pstep;
 #pragma unroll
-      for (int q = 0; q < NLD; ++q) {
-        r[q] = *reinterpret_cast<const float4*>(p[q]);
-        p[q] += pstep;
-      }
-      vmask = KM ? (cmask ? ~0u : 0u) : rokm;
+      for (int q = 0; q < NLD; ++q) g.r[q] = *reinterpret_cast<const float4*>(p[q] + adv);
+      g.vmask = KM ? (cmask ? ~0u : 0u) : rokm;
     } else {
-      vmask = 0;
+      g.vmask = 0;
       if (!KM) {
         const int c = c0 + k0;
         int sg = 0, oo = c;
         if (S.seglen < S.cols) { sg = c / S.seglen; oo = c - sg * S.seglen; }
         if (MODE == GF && S.alpha) {
-          a4.x = c < S.cols ? S.alpha[c] : 0.f;
-          a4.y = c + 1 < S.cols ? S.alpha[c + 1] : 0.f;
-          a4.z = c + 2 < S.cols ? S.alpha[c + 2] : 0.f;
-          a4.w = c + 3 < S.cols ? S.alpha[c + 3] : 0.f;
+          g.a4.x = c < S.cols ? S.alpha[c] : 0.f;
+          g.a4.y = c + 1 < S.cols ? S.alpha[c + 1] : 0.f;
+          g.a4.z = c + 2 < S.cols ? S.alpha[c + 2] : 0.f;
+          g.a4.w = c + 3 < S.cols ? S.alpha[c + 3] : 0.f;
         }
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) gchunk(S, q, (rokm >> q) & 1, rc[q], c, sg, oo);
+        for (int q = 0; q < NLD; ++q) gchunk(S, g, q, (rokm >> q) & 1, rc[q], c, sg, oo);
       } else {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-          const int row = k0 + row0 + RSTEP * q;
+          const int row = k0 + row0 * NLD + q;
           const bool ok = row < S.rows;
           RowCtx rcx = decode_row(S, ok ? row : 0);
-          gchunk(S, q, ok, rcx, c0, seg, o);
+          gchunk(S, g, q, ok, rcx, c0, seg, o);
         }
       }
     }
   }
 
-  __device__ __forceinline__ void store(const f2g_operand& S, float* lds, int ld, int tid) const {
+  // masks + on-load transforms of chunk q (runs after the slab's MFMAs)
+  __device__ __forceinline__ float4 finalize(const f2g_operand& S, const Stg& g, int q) const {
+    float4 v = g.r[q];
+    const float4 a4 = g.a4;
+    if (!((g.vmask >> q) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == PF && KM) {  // column tail of the fixed chunk
+      if (!(cmask & 1)) v.x = 0.f;
+      if (!(cmask & 2)) v.y = 0.f;
+      if (!(cmask & 4)) v.z = 0.f;
+      if (!(cmask & 8)) v.w = 0.f;
+    }
+    if (MODE == GF && S.lrelu_src) {
+      const float sl = S.lrelu_slope;
+      v.x *= g.r2[q].x > 0.f ? 1.f : sl; v.y *= g.r2[q].y > 0.f ? 1.f : sl;
+      v.z *= g.r2[q].z > 0.f ? 1.f : sl; v.w *= g.r2[q].w > 0.f ? 1.f : sl;
+    }
+    if (MODE != SL && S.alpha) {  // SL applied it element-wise on load
+      v.x = prelu1(v.x, a4.x); v.y = prelu1(v.y, a4.y);
+      v.z = prelu1(v.z, a4.z); v.w = prelu1(v.w, a4.w);
+    }
+    return v;
+  }
+
+  // fp32 LDS image in memory orientation: [tile row][tile col]
+  __device__ __forceinline__ void store(const f2g_operand& S, const Stg& g, float* lds, int ld,
+                                        int tid) const {
+    if (PARTIAL && !active) return;
     const int ch = tid % CH, rr = tid / CH;
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
-      float4 v = r[q];
-      if (!((vmask >> q) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (MODE == PF && KM) {  // column tail of the fixed chunk
-        if (!(cmask & 1)) v.x = 0.f;
-        if (!(cmask & 2)) v.y = 0.f;
-        if (!(cmask & 4)) v.z = 0.f;
-        if (!(cmask & 8)) v.w = 0.f;
+      const int row = KM ? rr * NLD + q : rr + RSTEP * q;
+      *reinterpret_cast<float4*>(lds + row * ld + ch * 4) = finalize(S, g, q);
+    }
+  }
+
+  // split-bf16 LDS image, always [m-or-n index][k] (64-byte rows of 32 bf16, 16-byte chunks
+  // XOR-swizzled by (row>>2)&3): hi = bf16(v), lo = bf16(v - hi).  k-major tiles are transposed
+  // here: a thread owns NLD consecutive k of 4 columns and packs them per column.
+  __device__ __forceinline__ void store_split(const f2g_operand& S, const Stg& g, unsigned char* hi,
+                                              unsigned char* lo, int tid) const {
+    if (PARTIAL && !active) return;
+    const int ch = tid % CH, rr = tid / CH;
+    if (!KM) {
+#pragma unroll
+      for (int q = 0; q < NLD; ++q) {
+        const float4 v = finalize(S, g, q);
+        const int row = rr + RSTEP * q;
+        const int k4 = ch * 4;
+        const int off = row * 64 + ((((k4 >> 3) ^ ((row >> 2) & 3))) << 4) + ((k4 >> 2) & 1) * 8;
+        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1);
+        split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+        *reinterpret_cast<uint2*>(hi + off) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+        *reinterpret_cast<uint2*>(lo + off) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
       }
-      if (MODE == GF && S.lrelu_src) {
-        const float sl = S.lrelu_slope;
-        v.x *= r2[q].x > 0.f ? 1.f : sl; v.y *= r2[q].y > 0.f ? 1.f : sl;
-        v.z *= r2[q].z > 0.f ? 1.f : sl; v.w *= r2[q].w > 0.f ? 1.f : sl;
+    } else {
+      unsigned short hs[4][NLD], ls[4][NLD];
+#pragma unroll
+      for (int q = 0; q < NLD; ++q) {
+        const float4 v = finalize(S, g, q);
+        split_bf16(v.x, hs[0][q], ls[0][q]); split_bf16(v.y, hs[1][q], ls[1][q]);
+        split_bf16(v.z, hs[2][q], ls[2][q]); split_bf16(v.w, hs[3][q], ls[3][q]);
       }
-      if (MODE != SL && S.alpha) {  // SL applied it element-wise on load
-        v.x = prelu1(v.x, a4.x); v.y = prelu1(v.y, a4.y);
-        v.z = prelu1(v.z, a4.z); v.w = prelu1(v.w, a4.w);
+      const int k0 = rr * NLD;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int row = ch * 4 + c;
+        const int off = row * 64 + ((((k0 >> 3) ^ ((row >> 2) & 3))) << 4) + (k0 & 7) * 2;
+        if (NLD == 1) {
+          *reinterpret_cast<unsigned short*>(hi + off) = hs[c][0];
+          *reinterpret_cast<unsigned short*>(lo + off) = ls[c][0];
+        } else {
+#pragma unroll
+          for (int q = 0; q < NLD; q += 2) {
+            *reinterpret_cast<unsigned*>(hi + off + q * 2) = hs[c][q] | (hs[c][q + 1 < NLD ? q + 1 : q] << 16);
+            *reinterpret_cast<unsigned*>(lo + off + q * 2) = ls[c][q] | (ls[c][q + 1 < NLD ? q + 1 : q] << 16);
+          }
+        }
       }
-      *reinterpret_cast<float4*>(lds + (rr + RSTEP * q) * ld + ch * 4) = v;
     }
   }
 };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                   int kchunk) {
-  constexpr int BM = WAVES_M * TM * 32;
-  constexpr int BN = WAVES_N * TN * 32;
-  constexpr int LDA = AKM ? BM : LDR;
-  constexpr int LDB = BKM ? BN : LDR;
-  constexpr int ASZ = AKM ? BK * BM : BM * LDR;
-  constexpr int BSZ = BKM ? BK * BN : BN * LDR;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;            // 2 buffers
-  float* Bs = smem + 2 * ASZ;  // 2 buffers
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-  const int li = lane & 31, h = lane >> 5;
-  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles with
-  // the n index fastest so that the tiles sharing an A panel hit the same private L2.
+// XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles with the
+// n index fastest so that the tiles sharing an A panel hit the same private L2.
+__device__ __forceinline__ void tile_of_block(int BM, int BN, int& m0, int& n0) {
   const int tiles_n = gridDim.y, tiles_m = gridDim.x;
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.y * tiles_m + blockIdx.x;
-  {
-    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-  }
+  const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.z * kchunk;
-  int kend = kbeg + kchunk;
-  if (kend > K) kend = K;
-  const int nt = (kend - kbeg + BK - 1) / BK;
+  m0 = tm * BM;
+  n0 = tn * BN;
+}
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  using SA = typename std::conditional<AKM, Loader<AMODE, true, BK, BM>,
-                                       Loader<AMODE, false, BM, BK>>::type;
-  using SB = typename std::conditional<BKM, Loader<BMODE, true, BK, BN>,
-                                       Loader<BMODE, false, BN, BK>>::type;
-  SA sa;
-  SB sb;
-  if (AKM) sa.init(d.A, 0, m0, kbeg, tid); else sa.init(d.A, m0, 0, kbeg, tid);
-  if (BKM) sb.init(d.B, 0, n0, kbeg, tid); else sb.init(d.B, n0, 0, kbeg, tid);
-
-  if (nt > 0) {
-    sa.load(d.A, kbeg);
-    sb.load(d.B, kbeg);
-    sa.store(d.A, As, LDA, tid);
-    sb.store(d.B, Bs, LDB, tid);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) {
-      sa.load(d.A, kbeg + (t + 1) * BK);
-      sb.load(d.B, kbeg + (t + 1) * BK);
-    }
-    const float* Ab = As + cur * ASZ;
-    const float* Bb = Bs + cur * BSZ;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      float a[TM][4], b[TN][4];
-      const int kk = h * 16 + s4 * 4;
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) {
-        const int row = (wm * TM + mi) * 32 + li;
-        if (AKM) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) a[mi][q] = Ab[(kk + q) * LDA + row];
-        } else {
-          float4 tv = *reinterpret_cast<const float4*>(Ab + row * LDA + kk);
-          a[mi][0] = tv.x; a[mi][1] = tv.y; a[mi][2] = tv.z; a[mi][3] = tv.w;
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        const int col = (wn * TN + ni) * 32 + li;
-        if (BKM) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) b[ni][q] = Bb[(kk + q) * LDB + col];
-        } else {
-          float4 tv = *reinterpret_cast<const float4*>(Bb + col * LDB + kk);
-          b[ni][0] = tv.x; b[ni][1] = tv.y; b[ni][2] = tv.z; b[ni][3] = tv.w;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][q], b[ni][q], acc[mi][ni],
-                                                                0, 0, 0);
-    }
-    if (t + 1 < nt) {
-      sa.store(d.A, As + (cur ^ 1) * ASZ, LDA, tid);
-      sb.store(d.B, Bs + (cur ^ 1) * BSZ, LDB, tid);
-    }
-    __syncthreads();
-  }
-
-  // ---------------------------------------------------------------- epilogue
-  const f2g_epilogue& E = d.E;
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&acc)[TM][TN], int M,
+                                              int N, int m0, int n0, int wm, int wn, int li,
+                                              int h) {
   const float scale = E.scale != 0.f ? E.scale : 1.f;
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
@@ -445,32 +436,287 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const f2g_gemm_desc d, int
   }
 }
 
+// ---- exact fp32: v_mfma_f32_32x32x2_f32 --------------------------------------------------
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                      int kchunk) {
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int LDA = AKM ? BM : LDR;
+  constexpr int LDB = BKM ? BN : LDR;
+  constexpr int ASZ = AKM ? BK * BM : BM * LDR;
+  constexpr int BSZ = BKM ? BK * BN : BN * LDR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;            // 2 buffers
+  float* Bs = smem + 2 * ASZ;  // 2 buffers
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(BM, BN, m0, n0);
+  const int kbeg = blockIdx.z * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  using SA = typename std::conditional<AKM, Loader<AMODE, true, BK, BM>,
+                                       Loader<AMODE, false, BM, BK>>::type;
+  using SB = typename std::conditional<BKM, Loader<BMODE, true, BK, BN>,
+                                       Loader<BMODE, false, BN, BK>>::type;
+  SA sa;
+  SB sb;
+  if (AKM) sa.init(d.A, 0, m0, kbeg, tid); else sa.init(d.A, m0, 0, kbeg, tid);
+  if (BKM) sb.init(d.B, 0, n0, kbeg, tid); else sb.init(d.B, n0, 0, kbeg, tid);
+
+  if (nt > 0) {
+    typename SA::Stg ga;
+    typename SB::Stg gb;
+    sa.load(d.A, kbeg, ga);
+    sb.load(d.B, kbeg, gb);
+    sa.store(d.A, ga, As, LDA, tid);
+    sb.store(d.B, gb, Bs, LDB, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    typename SA::Stg ga;
+    typename SB::Stg gb;
+    {  // unconditional prefetch of the next slab (the last iteration re-reads slab 0, unused)
+      const int kn = (t + 1 < nt) ? kbeg + (t + 1) * BK : kbeg;
+      sa.load(d.A, kn, ga);
+      sb.load(d.B, kn, gb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* Ab = As + cur * ASZ;
+    const float* Bb = Bs + cur * BSZ;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float a[TM][4], b[TN][4];
+      const int kk = h * 16 + s4 * 4;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row = (wm * TM + mi) * 32 + li;
+        if (AKM) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[mi][q] = Ab[(kk + q) * LDA + row];
+        } else {
+          float4 tv = *reinterpret_cast<const float4*>(Ab + row * LDA + kk);
+          a[mi][0] = tv.x; a[mi][1] = tv.y; a[mi][2] = tv.z; a[mi][3] = tv.w;
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int col = (wn * TN + ni) * 32 + li;
+        if (BKM) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b[ni][q] = Bb[(kk + q) * LDB + col];
+        } else {
+          float4 tv = *reinterpret_cast<const float4*>(Bb + col * LDB + kk);
+          b[ni][0] = tv.x; b[ni][1] = tv.y; b[ni][2] = tv.z; b[ni][3] = tv.w;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][q], b[ni][q], acc[mi][ni],
+                                                                0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nt) {
+      sa.store(d.A, ga, As + (cur ^ 1) * ASZ, LDA, tid);
+      sb.store(d.B, gb, Bs + (cur ^ 1) * BSZ, LDB, tid);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h);
+}
+
+// ---- split-bf16 ("bf16x3"): each fp32 operand is staged as hi + lo bf16 and every product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error per
+// product <= ~2^-16 (vs 2^-24 exact fp32, 2^-9 plain bf16) at 3/16 of the fp32-MFMA cycle cost.
+// The MFMA phase of a slab is ~5x shorter than in the fp32 kernel, so latency is hidden with
+// thread-level parallelism instead: 8 waves per block (wave tile 64x32 / 32x32, <=128 VGPRs),
+// two blocks per CU = 4 waves per SIMD.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N / 2)
+void gemm_kernel_b3(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int ASZ = BM * 64;  // bytes of one bf16 image (hi or lo)
+  constexpr int BSZ = BN * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* base = reinterpret_cast<unsigned char*>(smem);
+  constexpr int BUF = 2 * ASZ + 2 * BSZ;  // per buffer: [A_hi | A_lo | B_hi | B_lo]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+  const int li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(BM, BN, m0, n0);
+  const int kbeg = blockIdx.z * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  using SA = typename std::conditional<AKM, Loader<AMODE, true, BK, BM, NT>,
+                                       Loader<AMODE, false, BM, BK, NT>>::type;
+  using SB = typename std::conditional<BKM, Loader<BMODE, true, BK, BN, NT>,
+                                       Loader<BMODE, false, BN, BK, NT>>::type;
+  SA sa;
+  SB sb;
+  if (AKM) sa.init(d.A, 0, m0, kbeg, tid); else sa.init(d.A, m0, 0, kbeg, tid);
+  if (BKM) sb.init(d.B, 0, n0, kbeg, tid); else sb.init(d.B, n0, 0, kbeg, tid);
+
+  auto compute = [&](const unsigned char* Ah) {
+    const unsigned char* Al = Ah + ASZ;
+    const unsigned char* Bh = Ah + 2 * ASZ;
+    const unsigned char* Bl = Bh + BSZ;
+    // per 16-k step: its fragments (one lgkmcnt wait), then the MFMAs back to back with the
+    // accumulators interleaved so that consecutive MFMAs never depend on each other
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      const int c = ks * 2 + h;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int row = (wm * TM + mi) * 32 + li;
+        const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+        ah[mi] = *reinterpret_cast<const bf16x8*>(Ah + off);
+        al[mi] = *reinterpret_cast<const bf16x8*>(Al + off);
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const int row = (wn * TN + ni) * 32 + li;
+        const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+        bh[ni] = *reinterpret_cast<const bf16x8*>(Bh + off);
+        bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            const bf16x8 av = term == 0 ? al[mi] : ah[mi];
+            const bf16x8 bv = term == 1 ? bl[ni] : bh[ni];
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  // clamped slab origin: loads are always issued (never inside control flow); out-of-range slabs
+  // re-read slab 0 and are discarded
+  auto kof = [&](int t) { return t < nt ? kbeg + t * BK : kbeg; };
+
+  // Software pipeline, prefetch distance 1 (global -> registers during the MFMA phase, converted
+  // into the other LDS buffer afterwards); latency is covered by 4 waves per SIMD.
+  unsigned char* bufs[2] = {base, base + BUF};
+  {
+    typename SA::Stg ga;
+    typename SB::Stg gb;
+    sa.load(d.A, kof(0), ga);
+    sb.load(d.B, kof(0), gb);
+    if (nt > 0) {
+      sa.store_split(d.A, ga, bufs[0], bufs[0] + ASZ, tid);
+      sb.store_split(d.B, gb, bufs[0] + 2 * ASZ, bufs[0] + 2 * ASZ + BSZ, tid);
+    }
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    typename SA::Stg ga;
+    typename SB::Stg gb;
+    sa.load(d.A, kof(t + 1), ga);
+    sb.load(d.B, kof(t + 1), gb);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(bufs[cur]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nt) {
+      unsigned char* nb = bufs[cur ^ 1];
+      sa.store_split(d.A, ga, nb, nb + ASZ, tid);
+      sb.store_split(d.B, gb, nb + 2 * ASZ, nb + 2 * ASZ + BSZ, tid);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE,
+          bool B3 = false>
 int launch(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int ASZ = AKM ? BK * BM : BM * LDR;
   constexpr int BSZ = BKM ? BK * BN : BN * LDR;
-  constexpr size_t smem = (size_t)2 * (ASZ + BSZ) * sizeof(float);
+  constexpr size_t smem = B3 ? (size_t)2 * (2 * BM * 64 + 2 * BN * 64)
+                             : (size_t)2 * (ASZ + BSZ) * sizeof(float);
   int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
   if (kchunk < BK) kchunk = BK;
   int zs = (K + kchunk - 1) / kchunk;
   if (zs < 1) zs = 1;
   dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, zs);
   if (grid.x == 0 || grid.y == 0) return F2G_OK;
-  auto kern = gemm_kernel<WAVES_M, WAVES_N, TM, TN, AKM, BKM, AMODE, BMODE>;
   static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
+  if constexpr (B3) {
+    auto kern = gemm_kernel_b3<WAVES_M, WAVES_N, TM, TN, AKM, BKM, AMODE, BMODE>;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), smem, st, d, M, N, K, kchunk);
+  } else {
+    auto kern = gemm_kernel<WAVES_M, WAVES_N, TM, TN, AKM, BKM, AMODE, BMODE>;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, d, M, N, K, kchunk);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, d, M, N, K, kchunk);
   return f2g_check_launch();
 }
 
 template <bool AKM, bool BKM, int AMODE, int BMODE>
 int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+  // split-bf16 core: fast loader modes only; SL operands (small GEMMs) stay on exact fp32
+  if (d.precision == 1 && AMODE != SL && BMODE != SL) {
+    if (AKM && M <= 32)
+      return launch<1, 8, 1, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);  // 32 x 256
+    if (N <= 32) return launch<8, 1, 1, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);
+    if (N <= 64) return launch<4, 2, 1, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);
+    // deep-K, wide-N problems (the 1024-channel MPD layers): 4 waves with 64x64 wave tiles read
+    // less LDS per FLOP; everything else hides latency better with 8 waves of 64x32
+    if (K >= 2048 && N >= 512)
+      return launch<2, 2, 2, 2, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);
+    return launch<2, 4, 2, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);  // 128 x 128
+  }
   if (AKM && M <= 32) return launch<1, 4, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   if (N <= 32) return launch<4, 1, 2, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   if (N <= 64) return launch<4, 1, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);

@@ -135,6 +135,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.E = e
     d.form = form
     d.split_k = split_k
+    d.precision = GEMM_PRECISION
     if GEMM_TIMER is not None:
         GEMM_TIMER.launch(d, A, Bm, form)
     else:
@@ -188,6 +189,19 @@ class GemmTimer:
 
 
 GEMM_TIMER = None
+
+# GEMM arithmetic: 0 = exact fp32 MFMA, 1 = split-bf16 (hi/lo, 3 bf16 MFMAs per product, fp32
+# accumulate).  Selected with F2G_GEMM=fp32|bf16x3 (default fp32) or set_gemm_precision().
+import os as _os
+
+GEMM_PRECISION = 1 if _os.environ.get("F2G_GEMM", "fp32").lower() in ("bf16x3", "split", "1") else 0
+
+
+def set_gemm_precision(name: str) -> None:
+    global GEMM_PRECISION
+    if name not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    GEMM_PRECISION = 1 if name == "bf16x3" else 0
 
 
 def split_for(reduction_rows: int, out_tiles: int) -> int:

@@ -101,6 +101,11 @@ typedef struct {
   f2g_epilogue E;
   int32_t form;
   int32_t split_k;
+  /* 0 = exact fp32 MFMA (bit-for-bit an fmaf chain); 1 = split-bf16: every fp32 operand is staged as
+   * hi+lo bf16 and each product is hi*hi + hi*lo + lo*hi with fp32 accumulation (per-product
+   * relative error <= ~2^-16, i.e. ~100x tighter than plain bf16), ~3-5x the throughput. */
+  int32_t precision;
+  int32_t _pad3;
 } f2g_gemm_desc;
 
 int f2g_gemm(const f2g_gemm_desc* d, f2g_stream_t stream);

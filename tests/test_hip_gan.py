@@ -99,7 +99,10 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, monkeypatch):
             ref = T(g[key])
             err = float((p.grad.cpu().double() - ref.double()).abs().max())
             # exactly-zero reference entries (cancelling hinge terms) get an absolute floor
-            assert err < 5e-3 * float(ref.abs().max()) + 2e-5, (k, err)
+            from flow2gan_amd import ops as _ops
+            # split-bf16 GEMM mode (F2G_GEMM=bf16x3): ~2^-16 per product instead of 2^-24
+            floor = 2e-4 if _ops.GEMM_PRECISION == 1 else 2e-5
+            assert err < 5e-3 * float(ref.abs().max()) + floor, (k, err)
     worst.sort(reverse=True)
     assert worst[0][0] < 5e-3, worst[:5]
     for p in gan.generator.parameters():

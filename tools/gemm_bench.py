@@ -23,3 +23,14 @@ for R, K, N in shapes:
     t1 = timeit(lambda: ops.gemm(ops.mat(out), ops.mat(W), gA, form=1))
     t2 = timeit(lambda: ops.wgrad(out, N, N, ops.mat(A), gW))
     print(f"R={R:6d} K={K:5d} N={N:5d}  fwd {fl/t0/1e12:6.1f} TF  dgrad {fl/t1/1e12:6.1f} TF  wgrad {fl/t2/1e12:6.1f} TF   ({t0*1e6:.0f} / {t1*1e6:.0f} / {t2*1e6:.0f} us)")
+
+# accuracy of the active precision mode vs float64 (one mid-size problem, all three forms)
+R, K, N = 1000, 768, 520
+A = torch.randn(R, K); W = torch.randn(N, K) * 0.05; G = torch.randn(R, N)
+out = torch.empty(R, N, device=dev); gA = torch.empty(R, K, device=dev); gW = torch.zeros(N, K, device=dev)
+ops.gemm(ops.mat(A.to(dev)), ops.mat(W.to(dev)), out)
+ops.gemm(ops.mat(G.to(dev)), ops.mat(W.to(dev)), gA, form=1)
+ops.wgrad(G.to(dev), N, N, ops.mat(A.to(dev)), gW)
+def rel(a, b): return float((a.cpu().double() - b).abs().max() / b.abs().max())
+print("precision mode", ops.GEMM_PRECISION, "max rel err fwd/dgrad/wgrad:",
+      rel(out, A.double() @ W.double().t()), rel(gA, G.double() @ W.double()), rel(gW, G.double().t() @ A.double()))
