@@ -75,7 +75,8 @@ def main():
     from flow2gan_amd.models.config import get_gan_config, get_generator_config
     from flow2gan_amd.models.gan import GAN
 
-    if world > 1:
+    force_dist = bool(os.environ.get("F2G_FORCE_DIST"))  # exercise RCCL with a single rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         fdist.setup_dist(rank, world, backend="nccl")
 
@@ -85,7 +86,7 @@ def main():
     gen.branch_dropout = 0.0 if args.workload == "gan_stage2" else gen.branch_dropout
     gan = GAN(gen, **get_gan_config("gan_multi_scale_mel_recon")).to(device)
     logmel = flow2gan_amd.LogMelSpectrogram(sr, 1024, 256, 100).to(device)
-    reducer = fdist.GradReducer()
+    reducer = fdist.GradReducer(force=force_dist)
     g_params = list(gan.generator.parameters())
     d_params = list(gan.discriminator.parameters())
 
@@ -127,7 +128,7 @@ def main():
         return B * out.shape[1] / sr
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             torch.distributed.barrier()
 
     def timed(nwarm, nsteps):
@@ -215,7 +216,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         fdist.cleanup_dist()
 
 

@@ -61,7 +61,7 @@ class DwnormBwd(C.Structure):
     _fields_ = [
         ("f", DwnormFwd), ("gz", C.c_void_p), ("ldgz", C.c_int64), ("du", C.c_void_p),
         ("lddu", C.c_int64), ("g_cproj", C.c_void_p), ("g_te", C.c_void_p),
-        ("g_beta", C.c_void_p), ("g_log_scale", C.c_void_p),
+        ("g_beta", C.c_void_p), ("g_log_scale", C.c_void_p), ("partials", C.c_void_p),
     ]
 
 
@@ -72,6 +72,7 @@ class DwconvBwd(C.Structure):
         ("B", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("K", C.c_int32),
         ("lens", C.c_void_p), ("w_dw", C.c_void_p), ("gres", C.c_void_p), ("ldgres", C.c_int64),
         ("gamma", C.c_void_p), ("g_w", C.c_void_p), ("g_b", C.c_void_p), ("g_gamma", C.c_void_p),
+        ("partials", C.c_void_p),
     ]
 
 
@@ -114,7 +115,8 @@ _SIGS = {
     "f2g_fill": [_P, _F, _L],
     "f2g_log_clip": [_P, _L, _F],
 }
-EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error"])
+EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_dwnorm_bwd_workspace",
+                                 "f2g_dwconv_bwd_workspace"])
 
 
 class F2GError(RuntimeError):
@@ -131,6 +133,10 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = list(args) + [C.c_void_p]
         fn.restype = C.c_int
+    for name in ("f2g_dwnorm_bwd_workspace", "f2g_dwconv_bwd_workspace"):
+        fn = getattr(lib, name)
+        fn.argtypes = [C.c_int32] * 4
+        fn.restype = C.c_int64
     lib.f2g_version.restype = C.c_char_p
     lib.f2g_last_error.restype = C.c_char_p
     return lib

@@ -1,112 +1,98 @@
 // HBM-bound kernels of the ConvNeXt block (reference modules.py:286-416, 419-495):
 // depthwise k<=7 conv + BiasNorm + condition add + time scale, fused, forward and backward.
 //
-// Layout: channels-last rows (b*F + f) x C.  A block owns TF=16 consecutive frames of one batch
-// item; the (TF+6) x C input strip is staged once in LDS (halo rows re-read from L2, not HBM),
-// then each wave walks 4 frames with lanes striding the channel axis, so the per-frame channel
-// reduction of BiasNorm is a 6-step wave shuffle and every global access is a coalesced row.
+// Layout: channels-last rows (b*F + f) x C.  One WAVE owns 2 (or 4) consecutive frames; lanes
+// stride the channel axis, so the per-frame channel reduction of BiasNorm is a 6-step wave
+// shuffle and every global access is a coalesced 256-byte row; the 7-tap halo re-reads are L1/L2
+// hits (HBM sees each row once).  No LDS, no barriers, thousands of independent waves.
 #include "common.h"
 
 namespace {
 
-constexpr int TF = 16;    // frames per block
 constexpr int HALO = 3;   // (7-1)/2
 constexpr int CPL = 12;   // channels per lane: C <= 768
 
-__device__ __forceinline__ void stage_strip(float* xs, const float* x, long long ldx, int b, int F,
-                                            int C, int f0, int nrows, int len_b) {
-  // xs[(i)*C + c] = x[b, f0 - HALO + i, c] * mask, zero outside [0, min(F, len)).
-  const bool vec = ((C & 3) == 0) && ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
-  if (vec) {
-    const int c4 = C >> 2;
-    for (int idx = threadIdx.x; idx < nrows * c4; idx += blockDim.x) {
-      int i = idx / c4, q = idx - i * c4;
-      int f = f0 - HALO + i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f >= 0 && f < F && f < len_b)
-        v = *reinterpret_cast<const float4*>(x + ((long long)b * F + f) * ldx + q * 4);
-      *reinterpret_cast<float4*>(xs + i * C + q * 4) = v;
-    }
-  } else {
-    for (int idx = threadIdx.x; idx < nrows * C; idx += blockDim.x) {
-      int i = idx / C, c = idx - i * C;
-      int f = f0 - HALO + i;
-      float v = 0.f;
-      if (f >= 0 && f < F && f < len_b) v = x[((long long)b * F + f) * ldx + c];
-      xs[i * C + c] = v;
-    }
-  }
-}
-
-template <bool BWD>
+// One wave owns FW consecutive frames of one batch item; lanes stride the channel axis
+// (c = lane + 64k).  No LDS, no barriers: the (FW+6) x C input window is read straight from
+// global memory as coalesced 256-byte rows (the 7x tap reuse is served by L1/L2, HBM sees each row
+// once), channel chunk by channel chunk, so a lane keeps (FW+6) independent loads in flight per
+// chunk and only u[FW][CPL] lives across the BiasNorm reduction (a 6-step wave shuffle).
+template <bool BWD, int FW>
 __global__ __launch_bounds__(256) void dwnorm_kernel(const f2g_dwnorm_bwd_desc D) {
   const f2g_dwnorm_fwd_desc& P = D.f;
-  extern __shared__ __attribute__((aligned(16))) float xs[];
-  const int b = blockIdx.y, f0 = blockIdx.x * TF;
-  const int F = P.F, C = P.C, K = P.K;
-  const int len_b = P.lens ? P.lens[b] : F;
-  stage_strip(xs, P.x, P.ldx, b, F, C, f0, TF + 2 * HALO, len_b);
-  __syncthreads();
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int F = P.F, C = P.C, K = P.K;
+  const int groups = (F + FW - 1) / FW;           // frame groups per batch item
+  // grid: x = blocks of 4 groups inside one batch item, y = batch item
+  const int b = blockIdx.y;
+  const int grp = blockIdx.x * 4 + wave;
+  const bool live = grp < groups;                 // idle waves still take part in the block reduce
+  const int f0 = (live ? grp : 0) * FW;
+  const int len_b = P.lens ? P.lens[b] : F;
   const int koff = (7 - K) / 2;
-  float w[CPL][7], bdw[CPL], beta[CPL], te1[CPL];
-#pragma unroll
-  for (int k = 0; k < CPL; ++k) {
-    const int c = lane + 64 * k;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) w[k][j] = 0.f;
-    bdw[k] = 0.f; beta[k] = 0.f; te1[k] = 1.f;
-    if (c < C) {
-      for (int j = 0; j < K; ++j) w[k][j + koff] = P.w_dw[c * K + j];
-      bdw[k] = P.b_dw ? P.b_dw[c] : 0.f;
-      beta[k] = P.beta[c];
-      if (P.te) te1[k] = 1.f + P.te[(long long)b * P.ldte + c];
-    }
-  }
+  const int nk = (C + 63) >> 6;
   const float escale = expf(P.log_scale[0]);
   const float invC = 1.f / (float)C;
+  const long long rb = (long long)b * F;
 
-  float gbeta[CPL], gte[CPL], gcp[CPL];
+  float u[FW][CPL];
+  float ssq[FW];
+#pragma unroll
+  for (int i = 0; i < FW; ++i) ssq[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+#pragma unroll
+    for (int i = 0; i < FW; ++i) u[i][k] = 0.f;
+    const int c = lane + 64 * k;
+    if (k < nk && c < C) {
+      float w[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) w[j] = 0.f;
+      for (int j = 0; j < K; ++j) w[j + koff] = P.w_dw[c * K + j];
+      const float bdw = P.b_dw ? P.b_dw[c] : 0.f;
+      const float bt = P.beta[c];
+      float xr[FW + 6];
+#pragma unroll
+      for (int r = 0; r < FW + 6; ++r) {
+        const int f = f0 - HALO + r;
+        xr[r] = (f >= 0 && f < F && f < len_b) ? P.x[(rb + f) * P.ldx + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < FW; ++i) {
+        float acc = bdw;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc += w[j] * xr[i + j];
+        u[i][k] = acc;
+        const float dlt = acc - bt;
+        ssq[i] += dlt * dlt;
+      }
+    }
+  }
+  float gcp[CPL], gbeta[CPL], gte[CPL];
   float glam = 0.f;
   if (BWD) {
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) { gbeta[k] = 0.f; gte[k] = 0.f; gcp[k] = 0.f; }
+    for (int k = 0; k < CPL; ++k) { gcp[k] = 0.f; gbeta[k] = 0.f; gte[k] = 0.f; }
   }
-
-  for (int i = 0; i < 4; ++i) {
-    const int fl = wave * 4 + i;  // local frame
-    const int f = f0 + fl;
-    if (f >= F) break;
-    const long long row = (long long)b * F + f;
-    float u[CPL];
-    float ssq = 0.f;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int c = lane + 64 * k;
-      u[k] = 0.f;
-      if (c < C) {
-        float acc = bdw[k];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) acc += w[k][j] * xs[(fl + j) * C + c];
-        u[k] = acc;
-        const float dlt = acc - beta[k];
-        ssq += dlt * dlt;
-      }
-    }
-    ssq = wave_sum(ssq);
-    const float r = ssq * invC;
+  for (int i = 0; i < FW; ++i) {
+    const int f = f0 + i;
+    if (f >= F || !live) break;
+    const long long row = rb + f;
+    const float r = wave_sum(ssq[i]) * invC;
     const float s = escale / sqrtf(r);
     const int fc = P.cproj ? f / P.up : 0;
     const bool has_cp = P.cproj && fc < P.Fc;
+    const float* cprow = has_cp ? P.cproj + ((long long)b * P.Fc + fc) * P.ldcp : nullptr;
     if (!BWD) {
 #pragma unroll
       for (int k = 0; k < CPL; ++k) {
         const int c = lane + 64 * k;
-        if (c < C) {
-          float v = u[k] * s;
-          if (has_cp) v += P.cproj[((long long)b * P.Fc + fc) * P.ldcp + c];
-          P.z[row * P.ldz + c] = v * te1[k];
+        if (k < nk && c < C) {
+          float v = u[i][k] * s;
+          if (has_cp) v += cprow[c];
+          const float te1 = P.te ? 1.f + P.te[(long long)b * P.ldte + c] : 1.f;
+          P.z[row * P.ldz + c] = v * te1;
         }
       }
       if (P.rstd && lane == 0) P.rstd[row] = s;
@@ -117,13 +103,14 @@ __global__ __launch_bounds__(256) void dwnorm_kernel(const f2g_dwnorm_bwd_desc D
       for (int k = 0; k < CPL; ++k) {
         const int c = lane + 64 * k;
         gv[k] = 0.f;
-        if (c < C) {
+        if (k < nk && c < C) {
           const float g = D.gz[row * D.ldgz + c];
-          gv[k] = g * te1[k];
-          dsum += gv[k] * u[k];
+          const float te1 = P.te ? 1.f + P.te[(long long)b * P.ldte + c] : 1.f;
+          gv[k] = g * te1;
+          dsum += gv[k] * u[i][k];
           if (D.g_te) {
-            float v = u[k] * s;
-            if (has_cp) v += P.cproj[((long long)b * P.Fc + fc) * P.ldcp + c];
+            float v = u[i][k] * s;
+            if (has_cp) v += cprow[c];
             gte[k] += g * v;
           }
           gcp[k] += gv[k];
@@ -135,41 +122,74 @@ __global__ __launch_bounds__(256) void dwnorm_kernel(const f2g_dwnorm_bwd_desc D
 #pragma unroll
       for (int k = 0; k < CPL; ++k) {
         const int c = lane + 64 * k;
-        if (c < C) {
-          const float t = coef * (u[k] - beta[k]);
+        if (k < nk && c < C) {
+          const float t = coef * (u[i][k] - P.beta[c]);
           gbeta[k] += t;
           D.du[row * D.lddu + c] = s * gv[k] - t;
         }
       }
-      // condition gradient: frames sharing one condition row (f/up) are summed in-wave (the wave's
-      // 4 frames start at a multiple of 4 >= up), then added to the exclusively-owned slot.
-      const bool group_end = ((f + 1) % P.up == 0) || (f == F - 1) || (i == 3);
+      // condition gradient: the frames sharing one condition row (f / up) lie in this wave (FW is a
+      // multiple of up and groups start at multiples of FW): sum them here, then add to the slot
+      // this wave owns exclusively.
+      const bool group_end = ((f + 1) % P.up == 0) || (f == F - 1) || (i == FW - 1);
       if (D.g_cproj && group_end) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
           const int c = lane + 64 * k;
-          if (c < C && has_cp) D.g_cproj[((long long)b * P.Fc + fc) * P.ldcp + c] += gcp[k];
+          if (k < nk && c < C && has_cp)
+            D.g_cproj[((long long)b * P.Fc + fc) * P.ldcp + c] += gcp[k];
           gcp[k] = 0.f;
         }
       }
     }
   }
   if (BWD) {
+    if (D.partials) {
+      // block partials (no atomics): [ (b*nxb + xb) ][ beta(C) | te(C) | log_scale(1) ]
+      __shared__ float red[4][2 * 64 * CPL + 1];
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int c = lane + 64 * k;
-      if (c < C) {
-        if (D.g_beta) atomicAdd(D.g_beta + c, gbeta[k]);
-        if (D.g_te) atomicAdd(D.g_te + (long long)b * P.ldte + c, gte[k]);
+      for (int k = 0; k < CPL; ++k) {
+        const int c = lane + 64 * k;
+        if (k < nk && c < C) { red[wave][c] = gbeta[k]; red[wave][C + c] = gte[k]; }
       }
+      if (lane == 0) red[wave][2 * C] = glam;
+      __syncthreads();
+      float* prow = D.partials + ((long long)b * gridDim.x + blockIdx.x) * (2 * C + 1);
+      for (int i = threadIdx.x; i < 2 * C + 1; i += 256)
+        prow[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    } else {
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        const int c = lane + 64 * k;
+        if (k < nk && c < C) {
+          if (D.g_beta) atomicAdd(D.g_beta + c, gbeta[k]);
+          if (D.g_te) atomicAdd(D.g_te + (long long)b * P.ldte + c, gte[k]);
+        }
+      }
+      if (D.g_log_scale && lane == 0) atomicAdd(D.g_log_scale, glam);
     }
-    if (D.g_log_scale && lane == 0) atomicAdd(D.g_log_scale, glam);
+  }
+}
+
+// second stage of the parameter-gradient reduction of dwnorm_kernel<true>
+__global__ __launch_bounds__(256) void dwnorm_reduce_kernel(const float* partials, int B, int nxb,
+                                                            int C, float* g_beta, float* g_te,
+                                                            long long ldte, float* g_log_scale) {
+  // time-embedding gradient only: per batch item, over its nxb block partials (short loop);
+  // g_beta / g_log_scale are column sums over ALL rows and go through f2g_colsum.
+  const int W = 2 * C + 1;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B * C) {
+    const int b = i / C, c = i - b * C;
+    float s = 0.f;
+    for (int r = 0; r < nxb; ++r) s += partials[((long long)b * nxb + r) * W + C + c];
+    if (g_te) g_te[(long long)b * ldte + c] += s;
   }
 }
 
 // dx / dw / db / dgamma of the depthwise conv: thread = channel, register sliding window over a
 // strip of TFB frames (halo 6 -> 1.09x reads), partial parameter gradients reduced by atomics.
-constexpr int TFB = 64;
+constexpr int TFB = 32;
 
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const f2g_dwconv_bwd_desc P) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -221,11 +241,21 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const f2g_dwconv_bwd_de
 #pragma unroll
     for (int j = 0; j < 6; ++j) { dw_[j] = dw_[j + 1]; xw[j] = xw[j + 1]; }
   }
+  if (P.partials) {
+    // row (b*nstrips + strip) = [ g_w (C*K, checkpoint layout) | g_b (C) | g_gamma (C) ]: no
+    // atomics here; the rows are summed by three f2g_colsum launches
+    float* prow = P.partials + ((long long)b * gridDim.y + blockIdx.y) * (long long)(K + 2) * C;
+    for (int j = 0; j < K; ++j) prow[(long long)c * K + j] = gw[j + koff];
+    prow[(long long)K * C + c] = gb;
+    prow[(long long)(K + 1) * C + c] = gg;
+    return;
+  }
   if (P.g_w)
     for (int j = 0; j < K; ++j) atomicAdd(P.g_w + c * K + j, gw[j + koff]);
   if (P.g_b) atomicAdd(P.g_b + c, gb);
   if (P.g_gamma && P.gres) atomicAdd(P.g_gamma + c, gg);
 }
+
 
 // BiasNorm alone (decoder.in_norm / cond_encoder.in_norm): one wave per row.
 __global__ __launch_bounds__(256) void biasnorm_fwd_kernel(const float* x, long long ldx, float* y,
@@ -321,20 +351,41 @@ template <bool BWD>
 int launch_dwnorm(const f2g_dwnorm_bwd_desc& d, hipStream_t st) {
   const f2g_dwnorm_fwd_desc& f = d.f;
   if (f.B <= 0 || f.F <= 0) return F2G_OK;
-  size_t smem = (size_t)(TF + 2 * HALO) * f.C * sizeof(float);
-  auto kern = dwnorm_kernel<BWD>;
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 22 * 64 * CPL * 4);
-    done = true;
+  // frames per wave: a multiple of the condition upsampling factor (4 | up)
+  const bool four = BWD && f.cproj && f.up == 4;
+  const int FW = four ? 4 : 2;
+  const int groups = (f.F + FW - 1) / FW;
+  const int nxb = (groups + 3) / 4;
+  dim3 grid(nxb, f.B);
+  if (four) hipLaunchKernelGGL((dwnorm_kernel<BWD, 4>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((dwnorm_kernel<BWD, 2>), grid, dim3(256), 0, st, d);
+  int rc = f2g_check_launch();
+  if (rc || !BWD || !d.partials) return rc;
+  const int W = 2 * f.C + 1, prow = f.B * nxb;
+  if (d.g_beta && (rc = f2g_colsum(d.g_beta, d.partials, W, nullptr, 0, prow, f.C, st))) return rc;
+  if (d.g_log_scale &&
+      (rc = f2g_colsum(d.g_log_scale, d.partials + 2 * f.C, W, nullptr, 0, prow, 1, st)))
+    return rc;
+  if (d.g_te) {
+    const int n = f.B * f.C;
+    hipLaunchKernelGGL(dwnorm_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d.partials,
+                       f.B, nxb, f.C, d.g_beta, d.g_te, (long long)f.ldte, d.g_log_scale);
+    rc = f2g_check_launch();
   }
-  dim3 grid((f.F + TF - 1) / TF, f.B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, d);
-  return f2g_check_launch();
+  return rc;
 }
 
 }  // namespace
+
+extern "C" int64_t f2g_dwnorm_bwd_workspace(int32_t B, int32_t F, int32_t C, int32_t up) {
+  const int FW = up == 4 ? 4 : 2;
+  const int groups = (F + FW - 1) / FW;
+  return (int64_t)B * ((groups + 3) / 4) * (2 * C + 1);
+}
+
+extern "C" int64_t f2g_dwconv_bwd_workspace(int32_t B, int32_t F, int32_t C, int32_t K) {
+  return (int64_t)B * ((F + TFB - 1) / TFB) * (K + 2) * C;
+}
 
 extern "C" int f2g_dwnorm_fwd(const f2g_dwnorm_fwd_desc* d, f2g_stream_t stream) {
   if (!d || !d->z) return F2G_EINVAL;
@@ -358,7 +409,16 @@ extern "C" int f2g_dwconv_bwd(const f2g_dwconv_bwd_desc* d, f2g_stream_t stream)
   if (d->B <= 0 || d->F <= 0 || d->C <= 0) return F2G_OK;
   dim3 grid((d->C + 255) / 256, (d->F + TFB - 1) / TFB, d->B);
   hipLaunchKernelGGL(dwconv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
-  return f2g_check_launch();
+  int rc = f2g_check_launch();
+  if (rc || !d->partials) return rc;
+  const int W = (d->K + 2) * d->C, prow = (int)(grid.y * grid.z), CK = d->C * d->K;
+  if (d->g_w && (rc = f2g_colsum(d->g_w, d->partials, W, nullptr, 0, prow, CK, stream))) return rc;
+  if (d->g_b && (rc = f2g_colsum(d->g_b, d->partials + CK, W, nullptr, 0, prow, d->C, stream)))
+    return rc;
+  if (d->g_gamma && d->gres &&
+      (rc = f2g_colsum(d->g_gamma, d->partials + CK + d->C, W, nullptr, 0, prow, d->C, stream)))
+    return rc;
+  return rc;
 }
 
 extern "C" int f2g_biasnorm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows,

@@ -93,22 +93,34 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(float* x, long long ld, 
   }
 }
 
-// out[c] += sum_r a[r,c] (* b[r,c]); block = 256 columns x ROWS_PER rows, atomics per block.
+// out[c] += sum_r a[r,c] (* b[r,c]).  A block is CS columns x (256/CS) row lanes (CS = power of
+// two >= min(cols, 256)), so narrow matrices (32-channel MRD maps) still use all 256 threads and
+// every row segment is read coalesced; row lanes are combined through LDS, one atomic per column.
 __global__ __launch_bounds__(256) void colsum_kernel(float* out, const float* a, long long lda,
                                                      const float* b, long long ldb, int rows,
-                                                     int cols, int rows_per) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+                                                     int cols, int rows_per, int cs_log2) {
+  __shared__ float red[256];
+  const int CS = 1 << cs_log2;
+  const int RS = 256 >> cs_log2;
+  const int cl = threadIdx.x & (CS - 1), rl = threadIdx.x >> cs_log2;
+  const int c = blockIdx.x * CS + cl;
   const int r0 = blockIdx.y * rows_per;
   int r1 = r0 + rows_per;
   if (r1 > rows) r1 = rows;
   float s = 0.f;
-  if (b) {
-    for (int r = r0; r < r1; ++r) s += a[(long long)r * lda + c] * b[(long long)r * ldb + c];
-  } else {
-    for (int r = r0; r < r1; ++r) s += a[(long long)r * lda + c];
+  if (c < cols) {
+    if (b) {
+      for (int r = r0 + rl; r < r1; r += RS) s += a[(long long)r * lda + c] * b[(long long)r * ldb + c];
+    } else {
+      for (int r = r0 + rl; r < r1; r += RS) s += a[(long long)r * lda + c];
+    }
   }
-  atomicAdd(out + c, s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    for (int i = 1; i < RS; ++i) s += red[(i << cs_log2) + cl];
+    atomicAdd(out + c, s);
+  }
 }
 
 __global__ __launch_bounds__(256) void rows_fold_up_kernel(float* out, long long ldo,
@@ -427,10 +439,14 @@ extern "C" int f2g_colsum(float* out, const float* a, int64_t lda, const float* 
                           int32_t rows, int32_t cols, f2g_stream_t stream) {
   if (!out || !a) return F2G_EINVAL;
   if (rows <= 0 || cols <= 0) return F2G_OK;
-  int rows_per = 128;
-  dim3 grid((cols + 255) / 256, (rows + rows_per - 1) / rows_per);
+  int cs_log2 = 0;
+  while ((1 << cs_log2) < cols && cs_log2 < 8) ++cs_log2;
+  const int CS = 1 << cs_log2, RS = 256 >> cs_log2;
+  int rows_per = 64 * RS;  // 64 rows per thread
+  if (rows_per > rows) rows_per = rows;
+  dim3 grid((cols + CS - 1) / CS, (rows + rows_per - 1) / rows_per);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, ST, out, a, (long long)lda, b,
-                     (long long)ldb, rows, cols, rows_per);
+                     (long long)ldb, rows, cols, rows_per, cs_log2);
   return f2g_check_launch();
 }
 

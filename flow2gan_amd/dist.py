@@ -50,10 +50,11 @@ def get_rank() -> int:
 class GradReducer:
     """Average the .grad of the given parameters across ranks in ~bucket_mb flat buckets."""
 
-    def __init__(self, bucket_mb: float = 128.0, group=None):
+    def __init__(self, bucket_mb: float = 128.0, group=None, force: bool = False):
         self.bucket_bytes = int(bucket_mb * 2 ** 20)
         self.group = group
         self._stream = None
+        self.force = force  # run the exchange even with one rank (single-GPU test of the RCCL path)
 
     def _comm_stream(self, device):
         if device.type != "cuda":
@@ -63,9 +64,9 @@ class GradReducer:
         return self._stream
 
     @staticmethod
-    def _buckets(grads: List[torch.Tensor], limit: int) -> List[List[torch.Tensor]]:
+    def _buckets(params: List[torch.nn.Parameter], limit: int) -> List[List[torch.nn.Parameter]]:
         out, cur, size = [], [], 0
-        for g in grads:
+        for g in params:
             nbytes = g.numel() * g.element_size()
             if cur and size + nbytes > limit:
                 out.append(cur)
@@ -78,29 +79,33 @@ class GradReducer:
 
     @torch.no_grad()
     def reduce(self, params: Iterable[torch.nn.Parameter]) -> int:
-        """All-reduce (mean) the gradients of `params` in place.  Returns the bytes exchanged."""
+        """All-reduce (mean) the gradients of `params`.  Afterwards every p.grad is a view into its
+        bucket's flat buffer (no copy back).  Returns the bytes exchanged."""
         world = get_world_size()
-        grads = [p.grad for p in params if p.grad is not None]
-        if world == 1 or not grads:
+        live = [p for p in params if p.grad is not None]
+        if not live or (world == 1 and not (self.force and dist.is_initialized())):
             return 0
-        device = grads[0].device
+        device = live[0].grad.device
         comm = self._comm_stream(device)
         total = 0
         if comm is not None:
             comm.wait_stream(torch.cuda.current_stream(device))
         ctx = torch.cuda.stream(comm) if comm is not None else _Null()
         with ctx:
-            for bucket in self._buckets(grads, self.bucket_bytes):
-                flat = torch.cat([g.reshape(-1) for g in bucket])
+            for bucket in self._buckets(live, self.bucket_bytes):
+                flat = torch.cat([p.grad.reshape(-1) for p in bucket])
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                flat.div_(world)
+                if world > 1:
+                    flat.div_(world)
                 off = 0
-                for g in bucket:
-                    n = g.numel()
-                    g.copy_(flat[off:off + n].view_as(g))
-                    off += n
+                for p in bucket:
+                    n = p.numel()
                     if comm is not None:
-                        g.record_stream(comm)
+                        p.grad.record_stream(comm)  # still being read by the cat on `comm`
+                    p.grad = flat[off:off + n].view_as(p)
+                    off += n
+                if comm is not None:
+                    flat.record_stream(torch.cuda.current_stream(device))
                 total += flat.numel() * flat.element_size()
         if comm is not None:
             torch.cuda.current_stream(device).wait_stream(comm)

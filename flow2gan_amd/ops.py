@@ -265,6 +265,9 @@ def dwnorm_bwd(x, gz, du, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=
     d.g_cproj = None if g_cproj is None else ptr(g_cproj) + 4 * cp_off
     d.g_te = None if g_te is None else ptr(g_te) + 4 * te_off
     d.g_beta, d.g_log_scale = ptr(g_beta), ptr(g_log_scale)
+    ws = torch.empty(L.lib.f2g_dwnorm_bwd_workspace(B, F, Cc, up if cproj is not None else 1),
+                     device=x.device, dtype=torch.float32)
+    d.partials = ptr(ws)
     call("f2g_dwnorm_bwd", C.byref(d))
     return du
 
@@ -282,6 +285,9 @@ def dwconv_bwd(du, x, gx, B, F, Cc, K, lens, w_dw, gres=None, gamma=None, g_w=No
     d.ldgres = gres.stride(0) if gres is not None else 0
     d.gamma = ptr(gamma)
     d.g_w, d.g_b, d.g_gamma = ptr(g_w), ptr(g_b), ptr(g_gamma)
+    ws = torch.empty(L.lib.f2g_dwconv_bwd_workspace(B, F, Cc, K), device=x.device,
+                     dtype=torch.float32)
+    d.partials = ptr(ws)
     call("f2g_dwconv_bwd", C.byref(d))
     return gx
 

@@ -155,8 +155,13 @@ typedef struct {
   float* g_te;
   float* g_beta;
   float* g_log_scale;
+  /* optional workspace of f2g_dwnorm_bwd_workspace(B,F,C,up) floats: block partials of g_beta /
+   * g_te / g_log_scale are written there without atomics and summed by a second launch (the
+   * sums are ADDED to g_beta/g_te/g_log_scale).  NULL: contended atomics. */
+  float* partials;
 } f2g_dwnorm_bwd_desc;
 int f2g_dwnorm_bwd(const f2g_dwnorm_bwd_desc* d, f2g_stream_t stream);
+int64_t f2g_dwnorm_bwd_workspace(int32_t B, int32_t F, int32_t C, int32_t up);
 
 /* dx[c,t] (+)= mask * sum_j w[c,j] du[c,t-j+pad] (+ gamma[c]*gres[c,t]);
  * g_w[c,j] += sum du[c,t]*xm[c,t+j-pad]; g_b[c] += sum du; g_gamma[c] += sum gres*x. */
@@ -176,8 +181,10 @@ typedef struct {
   float* g_w;
   float* g_b;
   float* g_gamma;
+  float* partials; /* optional workspace of f2g_dwconv_bwd_workspace(B,F,C,K) floats (as above) */
 } f2g_dwconv_bwd_desc;
 int f2g_dwconv_bwd(const f2g_dwconv_bwd_desc* d, f2g_stream_t stream);
+int64_t f2g_dwconv_bwd_workspace(int32_t B, int32_t F, int32_t C, int32_t K);
 
 /* BiasNorm alone (modules.py:286-416), channels-last, in place allowed (y may equal x). */
 int f2g_biasnorm_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows, int32_t C,
