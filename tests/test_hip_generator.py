@@ -167,3 +167,85 @@ def test_log_mel_frontend_matches_reference_fixture(f2g, golden):
         want = T(g[f"{tag}/logmel"])
         got = lm(T(g[f"{tag}/wave"])[None].to(DEV))[0, :, :want.shape[1]].cpu()
         assert float((got - want).abs().max()) < tol
+
+
+def test_44k_config_shapes_against_oracle(f2g):
+    """mel_44k_128band_512x_base geometry (n_fft 1024/512/256, hop 512/256/128, 128 mels, loss
+    n_fft 2048) at reduced width: inference and stage-1 loss/grads vs the CPU oracle."""
+    import flow2gan_oracle as O
+    from flow2gan_amd.models.config import get_generator_config
+    cfg = dict(get_generator_config("mel_44k_128band_512x_base"))
+    cfg.update(channels=(40, 32, 24), num_layers=(1, 1, 1), cond_enc_channels=32,
+               cond_enc_num_layers=1, time_embed_channels=32, branch_dropout=0.0)
+    torch.manual_seed(8)
+    mo = O.MelAudioGenerator(**cfg)
+    mh = f2g.MelAudioGenerator(**cfg)
+    mh.load_state_dict(mo.state_dict())
+    mh = mh.to(DEV)
+    gen = torch.Generator().manual_seed(9)
+    B, Tn = 2, 11025
+    audio = 0.1 * torch.randn(B, Tn, generator=gen)
+    lens = torch.tensor([11025, 9000])
+    lm_o = O.LogMelSpectrogram(44100, 2048, 512, 128)
+    lm_h = f2g.LogMelSpectrogram(44100, 2048, 512, 128).to(DEV)
+    mel = lm_o(audio)
+    assert float((lm_h(audio.to(DEV)).cpu() - mel).abs().max()) < 1e-3
+    noise = 0.1 * torch.randn(B, Tn, generator=gen)
+    t = torch.tensor([[0.35], [0.6]])
+    random.seed(3)
+    mo.train()
+    lo = mo(mel, audio, lens, noise=noise, t=t)
+    lo.backward()
+    random.seed(3)
+    mh.train()
+    lh = mh(mel.to(DEV), audio.to(DEV), lens, noise=noise.to(DEV), t=t.to(DEV))
+    lh.backward()
+    assert abs(float(lh) - float(lo)) < 5e-5 * abs(float(lo))
+    po = dict(mo.named_parameters())
+    worst = max((float((p.grad.cpu() - po[n].grad).abs().max()) / (float(po[n].grad.abs().max()) + 1e-12), n)
+                for n, p in mh.named_parameters())
+    assert worst[0] < 3e-3, worst
+    mo.eval(), mh.eval()
+    with torch.no_grad():
+        nz = 0.1 * torch.randn(B, mel.shape[2] * 512, generator=gen)
+        yo = mo.infer(mel, None, 2, True, noise=nz)
+        yh = mh.infer(mel.to(DEV), None, 2, True, noise=nz.to(DEV))
+    assert rms(yh, yo) < RMS_TOL
+
+
+def test_harness_compute_loss_matches_oracle(f2g, golden):
+    """C1/C2: compute_loss_stage1 / compute_loss_stage2 (cond computed inside the step, reference
+    loss weights) against the oracle on the same inputs."""
+    import flow2gan_oracle as O
+    from flow2gan_amd import harness
+    from flow2gan_amd.models.gan import GAN
+    g = golden("tiny_stage2")
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("w/")}
+    mo = O.MelAudioGenerator(**TINY)
+    mo.load_state_dict(sd)
+    mh = f2g.MelAudioGenerator(**TINY)
+    mh.load_state_dict(sd)
+    mo.branch_dropout = mh.branch_dropout = 0.0
+    torch.manual_seed(int(g["d_seed"]))
+    go = O.GAN(mo)
+    gh = GAN(mh)
+    gh.discriminator.load_state_dict(go.discriminator.state_dict(), strict=False)
+    gh = gh.to(DEV)
+    audio = T(g["audio"])
+    lens = torch.tensor([6000, 6000])
+    lm_o, lm_h = O.LogMelSpectrogram(), f2g.LogMelSpectrogram().to(DEV)
+    # deterministic noise for both: patch torch.randn used by infer()
+    noise = T(g["noise"])
+    for train_disc in (True, False):
+        want = go(lm_o(audio), audio, lens, 1, train_disc, noise=noise)
+        ws = (1.0, 0.1) if train_disc else (1.0, 0.1, 1.0, 0.1, 45.0)
+        want_total = float(sum(w * l for w, l in zip(ws, want)))
+        orig = torch.randn
+        try:
+            torch.randn = lambda *a, **k: (noise / 0.1).to(DEV)
+            loss, info = harness.compute_loss_stage2(audio.to(DEV), lens, gh, lm_h, 1,
+                                                     train_disc=train_disc)
+        finally:
+            torch.randn = orig
+        assert abs(float(loss) - want_total) < 1e-4 * abs(want_total), (train_disc, float(loss), want_total)
+        assert info["samples"] == 2

@@ -137,3 +137,43 @@ def test_grad_reducer_world_size_2_gloo(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert torch.load(tmp_path / "ok0.pt") and torch.load(tmp_path / "ok1.pt")
+
+
+def test_gan_stepper_schedule_matches_reference():
+    """finetune.py:569-631: D-only until gen_start_batch_idx, then D/G alternation on new batches;
+    only the stepped sub-model gets gradients; reference loss weights."""
+    from flow2gan_amd.harness import GanLossScales, GanStepper
+
+    class StubGan(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.generator = torch.nn.Linear(1, 1)
+            self.discriminator = torch.nn.Linear(1, 1)
+            self.calls = []
+
+        def forward(self, cond, audio, audio_lens, n_timesteps, train_disc):
+            self.calls.append((train_disc, n_timesteps, float(audio.sum())))
+            if train_disc:
+                s = self.discriminator(audio[:, :1]).sum()
+                return s, 2 * s
+            s = self.generator(audio[:, :1]).sum()
+            return s, s, s, s, s
+
+    gan = StubGan()
+    st = GanStepper(gan, cond_module=lambda a: a, n_timesteps=2, gen_start_batch_idx=3)
+    kinds = []
+    for i in range(8):
+        gan.zero_grad()
+        info = st.step(torch.full((2, 4), float(i + 1)), torch.tensor([4, 4]))
+        kinds.append(info["train_disc"])
+        live = gan.discriminator if info["train_disc"] else gan.generator
+        dead = gan.generator if info["train_disc"] else gan.discriminator
+        assert all(p.grad is not None for p in live.parameters())
+        assert all(p.grad is None for p in dead.parameters())
+    assert kinds == [True, True, True, False, True, False, True, False]
+    assert [c[2] for c in gan.calls] == [8.0 * (i + 1) for i in range(8)]  # a new batch every step
+    assert all(c[1] == 2 for c in gan.calls)
+    w = GanLossScales()
+    assert (w.disc_loss_mp_scale, w.disc_loss_mr_scale) == (1.0, 0.1)
+    assert (w.gen_loss_mp_scale, w.gen_loss_mr_scale, w.feat_map_loss_mp_scale,
+            w.feat_map_loss_mr_scale, w.mel_recon_loss_scale) == (1.0, 0.1, 1.0, 0.1, 45.0)
