@@ -152,7 +152,7 @@ struct Loader {
   // across the MFMA phase.
   struct Stg {
     float4 r[NLD];
-    float4 r2[MODE == GF ? NLD : 1];  // lrelu_src values of the chunk
+    float4 r2[MODE != PF ? NLD : 1];  // lrelu_src values of the chunk
     float4 a4;                        // PReLU slopes of the chunk's 4 columns
     unsigned vmask;                   // bit q: chunk q holds valid data
   };
@@ -217,7 +217,7 @@ struct Loader {
         row0 = rr;
         seg = 0; o = c0;
         if (S.seglen < S.cols) { seg = c0 / S.seglen; o = c0 - seg * S.seglen; }
-        if (MODE == GF && S.alpha) {
+        if (MODE != PF && S.alpha) {
           if (c0 < S.cols) a4.x = S.alpha[c0];
           if (c0 + 1 < S.cols) a4.y = S.alpha[c0 + 1];
           if (c0 + 2 < S.cols) a4.z = S.alpha[c0 + 2];
@@ -239,7 +239,32 @@ struct Loader {
       if (S.lrelu_src) g.r2[q] = *reinterpret_cast<const float4*>(S.lrelu_src + off);
       g.vmask |= (v ? 1u : 0u) << q;
     } else {
-      g.r[q] = rowok ? load_chunk_generic(S, rcx, c, sg, oo) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // SL: the same clamped-address scheme element by element (4 unconditional scalar loads, no
+      // divergent branches); handles reflect padding, odd segment lengths and misaligned rows.
+      const int seglen = S.seglen < S.cols ? S.seglen : S.cols;
+      float vv[4], lv[4];
+      int sg_e = sg, oo_e = oo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int l1 = rcx.l1b + sg_e;
+        int off_e = rcx.e0 + oo_e;
+        bool ok = rowok && (c + e) < S.cols && (unsigned)l1 < (unsigned)S.L1;
+        if (S.reflect) {
+          off_e = off_e < 0 ? -off_e : off_e;
+          off_e = off_e >= S.L0u ? 2 * (S.L0u - 1) - off_e : off_e;
+        }
+        ok = ok && (unsigned)off_e < (unsigned)S.L0u;
+        const long long a = ok ? rcx.base + (long long)l1 * S.line_stride + off_e : 0;
+        const float x = S.base[a];
+        lv[e] = S.lrelu_src ? S.lrelu_src[a] : 1.f;
+        vv[e] = ok ? x : 0.f;
+        ++oo_e;
+        const bool wrap = oo_e >= seglen;
+        oo_e = wrap ? 0 : oo_e;
+        sg_e += wrap ? 1 : 0;
+      }
+      g.r[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      g.r2[q] = make_float4(lv[0], lv[1], lv[2], lv[3]);
       g.vmask |= 1u << q;
     }
   }
@@ -265,7 +290,7 @@ struct Loader {
         const int c = c0 + k0;
         int sg = 0, oo = c;
         if (S.seglen < S.cols) { sg = c / S.seglen; oo = c - sg * S.seglen; }
-        if (MODE == GF && S.alpha) {
+        if (MODE != PF && S.alpha) {
           g.a4.x = c < S.cols ? S.alpha[c] : 0.f;
           g.a4.y = c + 1 < S.cols ? S.alpha[c + 1] : 0.f;
           g.a4.z = c + 2 < S.cols ? S.alpha[c + 2] : 0.f;
@@ -296,12 +321,12 @@ struct Loader {
       if (!(cmask & 4)) v.z = 0.f;
       if (!(cmask & 8)) v.w = 0.f;
     }
-    if (MODE == GF && S.lrelu_src) {
+    if (MODE != PF && S.lrelu_src) {
       const float sl = S.lrelu_slope;
       v.x *= g.r2[q].x > 0.f ? 1.f : sl; v.y *= g.r2[q].y > 0.f ? 1.f : sl;
       v.z *= g.r2[q].z > 0.f ? 1.f : sl; v.w *= g.r2[q].w > 0.f ? 1.f : sl;
     }
-    if (MODE != SL && S.alpha) {  // SL applied it element-wise on load
+    if (S.alpha) {
       v.x = prelu1(v.x, a4.x); v.y = prelu1(v.y, a4.y);
       v.z = prelu1(v.z, a4.z); v.w = prelu1(v.w, a4.w);
     }
@@ -706,7 +731,9 @@ int launch(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t s
 template <bool AKM, bool BKM, int AMODE, int BMODE>
 int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
   // split-bf16 core: fast loader modes only; SL operands (small GEMMs) stay on exact fp32
-  if (d.precision == 1 && AMODE != SL && BMODE != SL) {
+  // (the reflect-padded STFT framing stays exact: small spectral bins are differences of large
+  // terms, and the log-mel / spectral losses take their logarithm)
+  if (d.precision == 1 && !d.A.reflect && !d.B.reflect) {
     if (AKM && M <= 32)
       return launch<1, 8, 1, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);  // 32 x 256
     if (N <= 32) return launch<8, 1, 1, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);

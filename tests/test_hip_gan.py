@@ -120,4 +120,8 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, monkeypatch):
         assert p.grad is not None, k
         worst.append((relerr(p.grad, ref), k))
     worst.sort(reverse=True)
-    assert worst[0][0] < 5e-3, worst[:8]
+    from flow2gan_amd import ops as _ops
+    # exact-fp32 GEMMs: 5e-3 of each gradient's max.  The opt-in split-bf16 mode perturbs activations
+    # by ~1e-5, which flips some sign() terms of the L1 / hinge / leaky-ReLU gradients (they are
+    # discontinuous), so its G-step gradients are only held to 1e-1 of their max.
+    assert worst[0][0] < (1e-1 if _ops.GEMM_PRECISION == 1 else 5e-3), worst[:8]
