@@ -173,7 +173,7 @@ def main():
         torch.cuda.synchronize()
         n, flops, secs = ops.GEMM_TIMER.summary()
         if os.environ.get("F2G_GEMM_REPORT") and rank == 0:
-            print(ops.GEMM_TIMER.report(40), file=sys.stderr)
+            print(ops.GEMM_TIMER.report(int(os.environ["F2G_GEMM_REPORT"])), file=sys.stderr)
         ops.GEMM_TIMER = None
         achieved = flops / secs / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA implicit GEMM, all forms)",

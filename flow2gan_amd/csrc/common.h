@@ -8,6 +8,8 @@
 #include "../../include/flow2gan_hip.h"
 
 int f2g_check_launch();
+// narrow.hip: VALU path for <= 4 output columns / gradient rows; 1 = handled, 0 = not applicable
+int f2g_gemm_narrow(const f2g_gemm_desc& d, hipStream_t st);
 void f2g_set_error(const char* msg);
 
 #define F2G_WAVE 64

@@ -299,12 +299,30 @@ struct Loader {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) gchunk(S, g, q, (rokm >> q) & 1, rc[q], c, sg, oo);
       } else {
+        // the thread's NLD rows are consecutive pixels: decode the first (two divisions), then
+        // step (p0, p1, s) with carries
+        const int rfirst = k0 + row0 * NLD;
+        int s_, p1_, p0_;
+        {
+          const int r = rfirst < S.rows ? rfirst : 0;
+          if (S.P0 == 1 && S.P1 == 1) { s_ = r; p1_ = 0; p0_ = 0; }
+          else { const int qq = r / S.P0; p0_ = r - qq * S.P0; s_ = qq / S.P1; p1_ = qq - s_ * S.P1; }
+        }
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-          const int row = k0 + row0 * NLD + q;
-          const bool ok = row < S.rows;
-          RowCtx rcx = decode_row(S, ok ? row : 0);
+          const bool ok = rfirst + q < S.rows;
+          RowCtx rcx;
+          rcx.base = (long long)s_ * S.seq_stride;
+          rcx.l1b = p1_ * S.step1 - S.pad1;
+          rcx.e0 = (p0_ * S.step0 - S.pad0) * S.unit;
           gchunk(S, g, q, ok, rcx, c0, seg, o);
+          ++p0_;
+          const bool c0w = p0_ >= S.P0;
+          p0_ = c0w ? 0 : p0_;
+          p1_ += c0w ? 1 : 0;
+          const bool c1w = p1_ >= S.P1;
+          p1_ = c1w ? 0 : p1_;
+          s_ += c1w ? 1 : 0;
         }
       }
     }
@@ -745,7 +763,10 @@ int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
     return launch<2, 4, 2, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);  // 128 x 128
   }
   if (AKM && M <= 32) return launch<1, 4, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
-  if (N <= 32) return launch<4, 1, 2, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
+  // 128 x 32 (46 KB of LDS -> 3 blocks per CU); a 256 x 32 tile needs 83 KB and leaves ONE block
+  // = one wave per SIMD on the CU, which cannot hide anything (measured 50 TFLOP/s on the
+  // 32-channel MRD convs)
+  if (N <= 32) return launch<4, 1, 1, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   if (N <= 64) return launch<4, 1, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   return launch<2, 2, 2, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
 }
@@ -780,6 +801,10 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   const f2g_gemm_desc& d = *dp;
   hipStream_t st = (hipStream_t)stream;
   int split = d.split_k > 0 ? d.split_k : 1;
+  {
+    const int nr = f2g_gemm_narrow(d, st);  // <= 4 output columns / gradient rows: VALU kernels
+    if (nr != 0) return nr < 0 ? nr : F2G_OK;
+  }
   if (d.form == 0 || d.form == 1) {
     const bool f1 = d.form == 1;
     if (f1 ? d.A.cols != d.B.rows : d.A.cols != d.B.cols) return F2G_EINVAL;
