@@ -95,31 +95,29 @@ def main():
     lens = torch.full((B,), T, dtype=torch.int64)
     nts = args.n_timesteps
 
-    def zero(params):
-        for p in params:
-            p.grad = None
-
+    # reducer.prepare() zeroes the gradients (views into flat arenas when there is an exchange);
+    # every bucket's all-reduce starts from an autograd hook while backward is still running
     def step():
         if args.workload == "gan_stage2":
             # discriminator step on its batch
-            zero(d_params)
+            reducer.prepare(d_params)
             cond = logmel(audio_d)
             mp, mr = gan(cond, audio_d, lens, nts, True)
             (D_WEIGHTS[0] * mp + D_WEIGHTS[1] * mr).backward()
-            reducer.reduce(d_params)
+            reducer.finish()
             # generator step on a new batch
-            zero(g_params)
+            reducer.prepare(g_params)
             cond = logmel(audio_g)
             ls = gan(cond, audio_g, lens, nts, False)
             sum(w * l for w, l in zip(G_WEIGHTS, ls)).backward()
-            reducer.reduce(g_params)
+            reducer.finish()
             return 2 * B * (T / sr)
         if args.workload == "stage1":
             gen.train()
-            zero(g_params)
+            reducer.prepare(g_params)
             cond = logmel(audio_g)
             gen(cond, audio_g, lens).backward()
-            reducer.reduce(g_params)
+            reducer.finish()
             return B * (T / sr)
         gen.eval()
         with torch.no_grad():
@@ -176,10 +174,18 @@ def main():
             print(ops.GEMM_TIMER.report(int(os.environ["F2G_GEMM_REPORT"])), file=sys.stderr)
         ops.GEMM_TIMER = None
         achieved = flops / secs / 1e12
+        # HBM bytes per GEMM launch come from the committed PMC passes over this same command
+        # (counters cannot be read live from inside the process); null when the workload differs
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                           "r01_pmc_gemm_traffic.json")
+        if args.workload == "gan_stage2" and args.gemm == "fp32" and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch_fetch_x2"])
         roofline = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA implicit GEMM, all forms)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": None, "launches_per_step": n,
+                    "traffic": traffic, "launches_per_step": n,
                     "gemm_share_of_step": round(secs / (elapsed / args.steps), 3),
                     "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
 
@@ -215,6 +221,10 @@ def main():
                        "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast,
         }
+        # RCCL prints its version banner through C stdio (flushed at exit): push it out first so
+        # that the JSON line is the last line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
     if world > 1 or force_dist:
         fdist.cleanup_dist()

@@ -55,6 +55,9 @@ class GradReducer:
         self.group = group
         self._stream = None
         self.force = force  # run the exchange even with one rank (single-GPU test of the RCCL path)
+        self._plans: dict = {}
+        self._hooked: set = set()
+        self._active: Optional["_Plan"] = None
 
     def _comm_stream(self, device):
         if device.type != "cuda":
@@ -110,6 +113,126 @@ class GradReducer:
         if comm is not None:
             torch.cuda.current_stream(device).wait_stream(comm)
         return total
+
+
+    # ---- overlapped mode: buckets leave as soon as their gradients are final -----------------
+    #
+    #   reducer.prepare(params)   # before forward: grads become zeroed views into flat arenas
+    #   loss.backward()           # a bucket's all-reduce starts on the communication stream the
+    #                             # moment autograd has accumulated its last gradient
+    #   reducer.finish()          # flush the stragglers, make the compute stream wait
+    #
+    # Buckets are cut in REVERSE parameter order (backward reaches the last layers first): in a
+    # D-step the MRD bucket travels while the MPD data-gradient convs still run, in a G-step the
+    # branch buckets travel under the remaining branches' backward.  The arenas are persistent
+    # (288 GB of HBM: 486 MB of gradient arenas is noise), so there is no pack / unpack copy.
+
+    def prepare(self, params: Iterable[torch.nn.Parameter]) -> None:
+        params = [p for p in params if p.requires_grad]
+        if get_world_size() == 1 and not (self.force and dist.is_initialized()):
+            # nothing to exchange: plain zero_grad(set_to_none=True), autograd keeps its own buffers
+            for p in params:
+                p.grad = None
+            self._active = None
+            return
+        key = tuple(id(p) for p in params)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(params, self.bucket_bytes)
+            self._plans[key] = plan
+            for p in params:
+                if id(p) not in self._hooked:
+                    self._hooked.add(id(p))
+                    p.register_post_accumulate_grad_hook(self._on_grad)
+        world = get_world_size()
+        plan.exchange = world > 1 or (self.force and dist.is_initialized())
+        plan.arm()
+        self._active = plan
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        plan = self._active
+        if plan is None:
+            return
+        b = plan.bucket_of.get(id(p))
+        if b is None:
+            return
+        b.fired.add(id(p))
+        if len(b.fired) == len(b.params) and not b.sent:
+            self._send(plan, b)
+
+    @torch.no_grad()
+    def _send(self, plan: "_Plan", b: "_Bucket") -> None:
+        b.sent = True
+        if not plan.exchange:
+            return
+        world = get_world_size()
+        comm = self._comm_stream(b.flat.device)
+        if comm is None:
+            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if world > 1:
+                b.flat.div_(world)
+        else:
+            comm.wait_stream(torch.cuda.current_stream(b.flat.device))
+            with torch.cuda.stream(comm):
+                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+                if world > 1:
+                    b.flat.div_(world)
+        plan.bytes += b.flat.numel() * b.flat.element_size()
+
+    def finish(self) -> int:
+        """Send what has not left yet, wait for the exchange; parameters that received no
+        gradient in this backward get `.grad = None` back (as without the reducer).  Returns the
+        bytes exchanged."""
+        plan, self._active = self._active, None
+        if plan is None:
+            return 0
+        for b in plan.buckets:
+            if b.fired and not b.sent:
+                self._send(plan, b)
+            for p in b.params:
+                if id(p) not in b.fired:
+                    p.grad = None
+        dev = plan.buckets[0].flat.device if plan.buckets else None
+        if dev is not None and dev.type == "cuda" and self._stream is not None:
+            torch.cuda.current_stream(dev).wait_stream(self._stream)
+        return plan.bytes
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.views, off = [], 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.fired: set = set()
+        self.sent = False
+
+
+class _Plan:
+    def __init__(self, params: List[torch.nn.Parameter], limit: int):
+        self.buckets: List[_Bucket] = []
+        groups: dict = {}
+        for p in reversed(params):  # backward order; one arena per (dtype, device)
+            groups.setdefault((p.dtype, p.device), []).append(p)
+        for plist in groups.values():
+            for chunk in GradReducer._buckets(plist, limit):
+                self.buckets.append(_Bucket(chunk))
+        self.bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        self.exchange = False
+        self.bytes = 0
+
+    @torch.no_grad()
+    def arm(self) -> None:
+        self.bytes = 0
+        for b in self.buckets:
+            b.flat.zero_()
+            b.fired.clear()
+            b.sent = False
+            for p, v in zip(b.params, b.views):
+                p.grad = v
 
 
 class _Null:

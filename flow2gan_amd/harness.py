@@ -87,12 +87,11 @@ class GanStepper:
         self.batch_idx_train += 1
         disc = self.train_disc
         params = list((self.gan.discriminator if disc else self.gan.generator).parameters())
-        for p in params:
-            p.grad = None
+        self.reducer.prepare(params)  # zero grads; buckets leave from autograd hooks during backward
         loss, info = compute_loss_stage2(audio, audio_lens, self.gan, self.cond_module,
                                          self.n_timesteps, self.scales, True, disc)
         loss.backward()
-        self.reducer.reduce(params)
+        self.reducer.finish()
         opt = self.optimizer_d if disc else self.optimizer_g
         if opt is not None:
             opt()

@@ -139,6 +139,49 @@ def test_grad_reducer_world_size_2_gloo(tmp_path):
     assert torch.load(tmp_path / "ok0.pt") and torch.load(tmp_path / "ok1.pt")
 
 
+def _overlap_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from flow2gan_amd import dist as fdist
+    fdist.setup_dist(rank, world, backend="gloo")
+    torch.manual_seed(0)  # same weights on both ranks
+    net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),
+                              torch.nn.Tanh(), torch.nn.Linear(64, 1))
+    unused = torch.nn.Parameter(torch.zeros(5))
+    params = list(net.parameters()) + [unused]
+    xs = [torch.randn(8, 16, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    # expected: mean over ranks of the local-batch gradients
+    want = [torch.zeros_like(p) for p in net.parameters()]
+    for x in xs:
+        for w, g in zip(want, torch.autograd.grad(net(x).pow(2).mean(), list(net.parameters()))):
+            w += g / world
+    sent_during_backward = []
+    red = fdist.GradReducer(bucket_mb=0.012)  # ~3 buckets
+    ok = True
+    for it in range(2):  # second pass re-uses the arenas and must not accumulate stale values
+        red.prepare(params)
+        loss = net(xs[rank]).pow(2).mean()
+        loss.backward()
+        sent_during_backward.append(sum(b.sent for b in red._active.buckets))
+        moved = red.finish()
+        ok = ok and all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7)
+                        for p, w in zip(net.parameters(), want))
+        ok = ok and unused.grad is None
+        ok = ok and moved == 4 * sum(p.numel() for p in params)  # arenas travel whole
+    ok = ok and len(red._plans) == 1 and len(next(iter(red._plans.values())).buckets) >= 3
+    ok = ok and all(n >= 2 for n in sent_during_backward)  # left from the autograd hooks
+    torch.save(ok, os.path.join(out, f"ov{rank}.pt"))
+    fdist.cleanup_dist()
+
+
+def test_overlapped_grad_reducer_world_size_2_gloo(tmp_path):
+    """prepare() / finish(): buckets are exchanged from autograd hooks during backward."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert torch.load(tmp_path / "ov0.pt") and torch.load(tmp_path / "ov1.pt")
+
+
 def test_gan_stepper_schedule_matches_reference():
     """finetune.py:569-631: D-only until gen_start_batch_idx, then D/G alternation on new batches;
     only the stepped sub-model gets gradients; reference loss weights."""
