@@ -11,6 +11,14 @@ int f2g_check_launch();
 // narrow.hip: VALU path for <= 4 output columns / gradient rows; 1 = handled, 0 = not applicable
 int f2g_gemm_narrow(const f2g_gemm_desc& d, hipStream_t st);
 void f2g_set_error(const char* msg);
+// elementwise.hip: out[k][c - begin[k]] += sum_r a[r, c] for up to 3 column ranges (null = skip)
+struct f2g_colsegs {
+  float* out[3];
+  int begin[3];
+  int count[3];
+};
+int f2g_colsum_segments(const float* a, long long lda, int rows, int ncols,
+                        const f2g_colsegs& segs, hipStream_t st);
 
 #define F2G_WAVE 64
 

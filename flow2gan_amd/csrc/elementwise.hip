@@ -123,6 +123,34 @@ __global__ __launch_bounds__(256) void colsum_kernel(float* out, const float* a,
   }
 }
 
+// Column sums of a short, wide partial-gradient matrix, scattered into up to 3 outputs (column
+// ranges).  The row axis is cut into enough slices for >= ~512 blocks; 4 independent loads per
+// thread and iteration; one atomic per (slice, column).
+__global__ __launch_bounds__(256) void colsum_seg_kernel(const float* a, long long lda, int rows,
+                                                         int rows_per, int ncols,
+                                                         f2g_colsegs segs) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  const int r0 = blockIdx.y * rows_per;
+  int r1 = r0 + rows_per;
+  if (r1 > rows) r1 = rows;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += a[(long long)r * lda + c];
+    s1 += a[(long long)(r + 1) * lda + c];
+    s2 += a[(long long)(r + 2) * lda + c];
+    s3 += a[(long long)(r + 3) * lda + c];
+  }
+  for (; r < r1; ++r) s0 += a[(long long)r * lda + c];
+  const float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (segs.out[k] && c >= segs.begin[k] && c < segs.begin[k] + segs.count[k])
+      atomicAdd(segs.out[k] + (c - segs.begin[k]), s);
+  }
+}
+
 __global__ __launch_bounds__(256) void rows_fold_up_kernel(float* out, long long ldo,
                                                            const float* g, long long ldg, int B,
                                                            int F, int Fc, int up, int C) {
@@ -447,6 +475,19 @@ extern "C" int f2g_colsum(float* out, const float* a, int64_t lda, const float* 
   dim3 grid((cols + CS - 1) / CS, (rows + rows_per - 1) / rows_per);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, ST, out, a, (long long)lda, b,
                      (long long)ldb, rows, cols, rows_per, cs_log2);
+  return f2g_check_launch();
+}
+
+int f2g_colsum_segments(const float* a, long long lda, int rows, int ncols,
+                        const f2g_colsegs& segs, hipStream_t st) {
+  if (rows <= 0 || ncols <= 0) return F2G_OK;
+  const int cb = (ncols + 255) / 256;
+  int slices = (512 + cb - 1) / cb;
+  if (slices > rows) slices = rows;
+  const int rows_per = (rows + slices - 1) / slices;
+  dim3 grid(cb, (rows + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(colsum_seg_kernel, grid, dim3(256), 0, st, a, lda, rows, rows_per, ncols,
+                     segs);
   return f2g_check_launch();
 }
 
