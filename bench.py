@@ -42,6 +42,7 @@ def parse():
                     help="gan_stage2 = the BASELINE metric; stage1 / infer4 = configs 3 / 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--eager-gpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3"],
@@ -58,6 +59,10 @@ def synthetic_batch(B, T, seed, device):
 
 def main():
     args = parse()
+    if args.eager_gpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.workload, args.n_timesteps, args.cpu_threads, True)),
+              flush=True)
+        return
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.workload, args.n_timesteps, args.cpu_threads)), flush=True)
         return
@@ -230,9 +235,13 @@ def main():
         fdist.cleanup_dist()
 
 
-def cpu_baseline(workload: str, nts: int, threads: int = 0):
+def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = False):
     """The CPU oracle (oracle/flow2gan_oracle.py, a port validated against the reference) on the
-    host cores, bounded: B=8 x 1 s, one warm-up + timed steps for >= 10 s (at most 6)."""
+    host cores, bounded: B=8 x 1 s, one warm-up + timed steps for >= 10 s (at most 6).
+
+    eager_gpu=True (hidden flag --eager-gpu-baseline-only, never part of the default run) times the
+    same PyTorch restatement as eager ROCm kernels (MIOpen / rocBLAS / hipFFT) on the GPU at the
+    full B=64: what the reference's own code path costs on this MI355X, for DESIGN.md's table."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import flow2gan_oracle as O
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -240,13 +249,16 @@ def cpu_baseline(workload: str, nts: int, threads: int = 0):
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     gen = O.build_generator("mel_24k_base")
-    B, T = 8, 24000
-    audio = (0.1 * torch.randn(B, T)).clamp_(-1, 1)
-    lens = torch.full((B,), T)
-    lm = O.LogMelSpectrogram()
+    B, T = (64 if eager_gpu else 8), 24000
+    dev = torch.device("cuda" if eager_gpu else "cpu")
+    audio = (0.1 * torch.randn(B, T)).clamp_(-1, 1).to(dev)
+    lens = torch.full((B,), T, device=dev)
+    lm = O.LogMelSpectrogram().to(dev)
+    gen = gen.to(dev)
+    sync = torch.cuda.synchronize if eager_gpu else (lambda: None)
     if workload == "gan_stage2":
         gen.branch_dropout = 0.0
-        gan = O.GAN(gen)
+        gan = O.GAN(gen).to(dev)
 
         def step():
             gan.zero_grad()
@@ -270,13 +282,20 @@ def cpu_baseline(workload: str, nts: int, threads: int = 0):
             with torch.no_grad():
                 gen.infer(lm(audio[:, :94 * 256]), None, 4)
             return B * 94 * 256 / 24000
-    step()
+    for _ in range(3 if eager_gpu else 1):
+        step()
+    sync()
     t0 = time.perf_counter()
     done, nstep = 0.0, 0
     while nstep < 6 and (time.perf_counter() - t0 < 10.0 or nstep == 0):
         done += step()
+        sync()
         nstep += 1
     dt = time.perf_counter() - t0
+    if eager_gpu:
+        return {"value": round(done / dt, 3), "unit": "audio-s/s", "ms_per_step": round(1e3 * dt / nstep, 2),
+                "kind": "PyTorch eager restatement of the reference on this GPU (MIOpen/rocBLAS/hipFFT)",
+                "sample": f"B={B} x 1 s, 3 warm-up + {nstep} timed step(s), fp32"}
     return {"value": round(done / dt, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
             "sample": f"oracle (PyTorch CPU fp32 restatement), B={B} x 1 s, 1 warm-up + {nstep} timed "
                       f"step(s) of the same workload ({dt:.1f} s)"}
