@@ -35,7 +35,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (items of 1 s)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="per-GPU batch (items of 1 s); default 64 (24 kHz) / 32 (44.1 kHz)")
+    ap.add_argument("--model", default="mel_24k_base",
+                    choices=["mel_24k_base", "mel_44k_128band_512x_base"],
+                    help="mel_24k_base = the BASELINE metric; the 44.1 kHz model = config 5")
     ap.add_argument("--n-timesteps", type=int, default=1, help="ODE steps unrolled in the GAN stage")
     ap.add_argument("--workload", default="gan_stage2",
                     choices=["gan_stage2", "stage1", "infer4"],
@@ -60,11 +64,13 @@ def synthetic_batch(B, T, seed, device):
 def main():
     args = parse()
     if args.eager_gpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.workload, args.n_timesteps, args.cpu_threads, True)),
+        print(json.dumps(cpu_baseline(args.workload, args.n_timesteps, args.cpu_threads, True,
+                                      args.model)),
               flush=True)
         return
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.workload, args.n_timesteps, args.cpu_threads)), flush=True)
+        print(json.dumps(cpu_baseline(args.workload, args.n_timesteps, args.cpu_threads, False,
+                                      args.model)), flush=True)
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,12 +91,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         fdist.setup_dist(rank, world, backend="nccl")
 
-    B, T, sr = args.batch, 24000, 24000
+    gcfg = get_generator_config(args.model)
+    sr = gcfg["sampling_rate"]
+    B, T = args.batch or (64 if sr == 24000 else 32), sr
+    mel_hop = gcfg["mel_hop_length"]
     torch.manual_seed(1234)  # same weights on every rank (pretrain.py:750, finetune.py:868)
-    gen = flow2gan_amd.MelAudioGenerator(**get_generator_config("mel_24k_base"))
+    gen = flow2gan_amd.MelAudioGenerator(**gcfg)
     gen.branch_dropout = 0.0 if args.workload == "gan_stage2" else gen.branch_dropout
     gan = GAN(gen, **get_gan_config("gan_multi_scale_mel_recon")).to(device)
-    logmel = flow2gan_amd.LogMelSpectrogram(sr, 1024, 256, 100).to(device)
+    logmel = flow2gan_amd.LogMelSpectrogram(sr, gcfg["mel_n_fft"], mel_hop, gcfg["n_mels"]).to(device)
+    T_inf = T  # config 2: audio_lens=None, output length = mel frames x hop (24064 at 24 kHz)
     reducer = fdist.GradReducer(force=force_dist)
     g_params = list(gan.generator.parameters())
     d_params = list(gan.discriminator.parameters())
@@ -126,7 +136,7 @@ def main():
             return B * (T / sr)
         gen.eval()
         with torch.no_grad():
-            cond = logmel(audio_g[:, :94 * 256])
+            cond = logmel(audio_g[:, :T_inf])
             out = gen.infer(cond, None, 4)
         return B * out.shape[1] / sr
 
@@ -184,7 +194,8 @@ def main():
         traffic = None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                            "r01_pmc_gemm_traffic.json")
-        if args.workload == "gan_stage2" and args.gemm == "fp32" and os.path.exists(pmc):
+        if (args.workload == "gan_stage2" and args.gemm == "fp32" and args.model == "mel_24k_base"
+                and B == 64 and os.path.exists(pmc)):
             with open(pmc) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch_fetch_x2"])
         roofline = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA implicit GEMM, all forms)",
@@ -202,7 +213,7 @@ def main():
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
                                 "--workload", args.workload, "--n-timesteps", str(nts),
-                                "--cpu-threads", str(args.cpu_threads)],
+                                "--cpu-threads", str(args.cpu_threads), "--model", args.model],
                                capture_output=True, text=True, timeout=150)
             cpu = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
@@ -211,17 +222,18 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "audio-seconds/sec (train step, G+D fwd/bwd) mel_24k_base",
+            "metric": f"audio-seconds/sec (train step, G+D fwd/bwd) {args.model}",
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.gemm == "fp32" else "f32 (split-bf16 GEMM, fp32 accumulate)",
             "data": "synthetic (0.1*randn clipped, seeded per rank); seeded random-init weights",
-            "config": {"workload": {"gan_stage2": "mel_24k_base GAN stage-2 train step: D-step + G-step, "
-                                                  "each on its own batch (MPD+MRD+FM+multi-scale mel), "
-                                                  "fwd+bwd+grad all-reduce, no optimizer (metric is fwd/bwd)",
-                                    "stage1": "mel_24k_base flow-matching stage-1 fwd+bwd",
-                                    "infer4": "mel_24k_base 4-step Euler inference"}[args.workload],
+            "config": {"workload": args.model + " " + {
+                           "gan_stage2": "GAN stage-2 train step: D-step + G-step, "
+                                         "each on its own batch (MPD+MRD+FM+multi-scale mel), "
+                                         "fwd+bwd+grad all-reduce, no optimizer (metric is fwd/bwd)",
+                           "stage1": "flow-matching stage-1 fwd+bwd",
+                           "infer4": "4-step Euler inference"}[args.workload],
                        "per_gpu_batch": B, "seconds_per_item": T / sr, "n_timesteps": nts,
                        "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast,
@@ -235,7 +247,8 @@ def main():
         fdist.cleanup_dist()
 
 
-def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = False):
+def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = False,
+                 model: str = "mel_24k_base"):
     """The CPU oracle (oracle/flow2gan_oracle.py, a port validated against the reference) on the
     host cores, bounded: B=8 x 1 s, one warm-up + timed steps for >= 10 s (at most 6).
 
@@ -248,12 +261,14 @@ def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = Fa
     cores = threads if threads > 0 else max(1, min(avail // 2, 32))  # physical cores, capped
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    gen = O.build_generator("mel_24k_base")
-    B, T = (64 if eager_gpu else 8), 24000
+    gen = O.build_generator(model)
+    gc = O.GENERATOR_CONFIGS[model]
+    sr, hop = gc["sampling_rate"], gc["mel_hop_length"]
+    B, T = ((64 if sr == 24000 else 32) if eager_gpu else 8), sr
     dev = torch.device("cuda" if eager_gpu else "cpu")
     audio = (0.1 * torch.randn(B, T)).clamp_(-1, 1).to(dev)
     lens = torch.full((B,), T, device=dev)
-    lm = O.LogMelSpectrogram().to(dev)
+    lm = O.LogMelSpectrogram(sr, gc["mel_n_fft"], hop, gc["n_mels"]).to(dev)
     gen = gen.to(dev)
     sync = torch.cuda.synchronize if eager_gpu else (lambda: None)
     if workload == "gan_stage2":
@@ -280,8 +295,8 @@ def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = Fa
 
         def step():
             with torch.no_grad():
-                gen.infer(lm(audio[:, :94 * 256]), None, 4)
-            return B * 94 * 256 / 24000
+                gen.infer(lm(audio), None, 4)
+            return B * (1 + T // hop) * hop / sr
     for _ in range(3 if eager_gpu else 1):
         step()
     sync()

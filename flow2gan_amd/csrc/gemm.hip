@@ -429,14 +429,15 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
                                               int N, int m0, int n0, int wm, int wn, int li,
                                               int h) {
   const float scale = E.scale != 0.f ? E.scale : 1.f;
+  const bool first = blockIdx.z == 0;  // split-K: bias and residual enter once
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
     const int col = n0 + (wn * TN + ni) * 32 + li;
     const bool cok = col < N;
     float bias = 0.f, gam = 0.f, aln = 0.f;
     if (cok) {
-      if (E.bias) bias = E.bias[col];
-      if (E.res) gam = E.gamma ? E.gamma[col] : 1.f;
+      if (E.bias && first) bias = E.bias[col];
+      if (E.res && first) gam = E.gamma ? E.gamma[col] : 1.f;
       if (E.aux) aln = E.alpha_n[col];
     }
     float cs = 0.f, csa = 0.f;
@@ -447,7 +448,7 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
         const int row = m0 + (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (!cok || row >= M) continue;
         float v = acc[mi][ni][e] * scale + bias;
-        if (E.res) v += gam * E.res[(long long)row * E.ldres + col];
+        if (E.res && first) v += gam * E.res[(long long)row * E.ldres + col];
         if (E.aux) {
           float av = E.aux[(long long)row * E.ldaux + col];
           csa += v * fminf(av, 0.f);
@@ -771,6 +772,55 @@ int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
   return launch<2, 2, 2, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
 }
 
+// ---- split-K for forward / data-gradient GEMMs ------------------------------------------------
+// A 128x128 tiling of e.g. pwconv2 (M=6016, N=768) yields 282 blocks for 256 CUs: 26 CUs carry two
+// tiles, the other 230 idle for half the kernel.  With a linear epilogue the reduction can be cut
+// into s chunks whose partial tiles are added atomically onto a zeroed output (bias / residual
+// enter through chunk 0): s*tiles blocks fill the last wave of resident blocks.
+__global__ __launch_bounds__(256) void zero_out_kernel(const f2g_epilogue E, int M, int N) {
+  const long long total = (long long)M * N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int row = (int)(i / N), col = (int)(i - (long long)row * N);
+    long long off;
+    if (E.P0o > 0) {
+      const int sq = row / E.P0o;
+      off = (long long)sq * E.seq_stride_o + (long long)(row - sq * E.P0o) * E.row_stride_o +
+            E.off_o + col;
+    } else {
+      off = (long long)row * E.ldc + col;
+    }
+    E.C[off] = 0.f;
+  }
+}
+
+inline int auto_split(int M, int N, int K) {
+  if (N <= 64) return 1;  // narrow tiles: thousands of blocks already
+  // Measured (tools/splitk_sweep.py): splitting pays only for deep reductions (>= 64 slabs, each
+  // chunk >= 20 slabs) and only through the fill of the last wave of 512 resident blocks:
+  // 282 tiles x K 2304: s=3 +31 %; 1192 x 5120: s=3 +19 %; 188 x 6144: s=8 +22 %; every
+  // shallower shape loses to the atomic epilogue.
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const int nk = (K + BK - 1) / BK;
+  if (nk < 64) return 1;
+  auto eff = [&](int s) {
+    const double w = (double)(tiles * s) / 512.0;
+    return w / (double)((tiles * s + 511) / 512);
+  };
+  const double e1 = eff(1);
+  double best = e1 + 0.15;
+  int best_s = 1;
+  for (int s = 2; s <= 8; ++s) {
+    if (nk / s < 20) break;
+    const double e = eff(s);
+    if (e > best + 0.02) {
+      best = e;
+      best_s = s;
+    }
+  }
+  return best_s;
+}
+
 inline bool host_plain(const f2g_operand& S) {
   return S.P0 == 1 && S.P1 == 1 && S.seglen >= S.cols && S.L1 == 1 && S.pad0 == 0 &&
          S.pad1 == 0 && S.L0u >= S.cols && !S.reflect && !S.lrelu_src;
@@ -811,14 +861,28 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     if (!host_plain(d.B)) return F2G_EINVAL;
     const int M = d.A.rows, N = f1 ? d.B.cols : d.B.rows, K = d.A.cols;
     const int am = op_mode(d.A, true), bm = op_mode(d.B, !f1);
-    if (!f1) {
-      if (am == PF && bm == PF) return dispatch_tile<false, false, PF, PF>(d, M, N, K, 1, st);
-      if (am == GF && bm == PF) return dispatch_tile<false, false, GF, PF>(d, M, N, K, 1, st);
-      return dispatch_tile<false, false, SL, SL>(d, M, N, K, 1, st);
+    // split_k: 1 = off, > 1 = as asked, 0 = decide here (linear epilogues only)
+    const bool linear = d.E.lrelu_slope == 0.f && d.E.res != d.E.C;
+    int s = d.split_k;
+    if (s == 0) s = (linear && am != SL && bm != SL && M > 0) ? auto_split(M, N, K) : 1;
+    if (s > 1 && !linear) return F2G_EINVAL;
+    f2g_gemm_desc dd = d;
+    if (s > 1 && !d.E.atomic) {
+      if (!d.E.accumulate) {
+        hipLaunchKernelGGL(zero_out_kernel, dim3(f2g_grid_for((int64_t)M * N, 256)), dim3(256), 0,
+                           st, d.E, M, N);
+      }
+      dd.E.atomic = 1;
+      dd.E.accumulate = 0;
     }
-    if (am == PF && bm == PF) return dispatch_tile<false, true, PF, PF>(d, M, N, K, 1, st);
-    if (am == GF && bm == PF) return dispatch_tile<false, true, GF, PF>(d, M, N, K, 1, st);
-    return dispatch_tile<false, true, SL, SL>(d, M, N, K, 1, st);
+    if (!f1) {
+      if (am == PF && bm == PF) return dispatch_tile<false, false, PF, PF>(dd, M, N, K, s, st);
+      if (am == GF && bm == PF) return dispatch_tile<false, false, GF, PF>(dd, M, N, K, s, st);
+      return dispatch_tile<false, false, SL, SL>(dd, M, N, K, s, st);
+    }
+    if (am == PF && bm == PF) return dispatch_tile<false, true, PF, PF>(dd, M, N, K, s, st);
+    if (am == GF && bm == PF) return dispatch_tile<false, true, GF, PF>(dd, M, N, K, s, st);
+    return dispatch_tile<false, true, SL, SL>(dd, M, N, K, s, st);
   } else if (d.form == 2) {
     if (d.A.rows != d.B.rows) return F2G_EINVAL;
     if (split > 1 && !d.E.atomic) return F2G_EINVAL;

@@ -344,7 +344,7 @@ class _BranchView:
 
 
 def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pred, accumulate,
-                    lens_f, training, keep):
+                    lens_f, training, keep, lanes=None):
     n_fft, hop, up, window = meta
     dev = x.device
     B, T = x.shape
@@ -392,7 +392,11 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
         ops.mask_rows(yspec, B, F, Cin, lens_f)
     frames = ops.empty(rows, N, device=dev)
     gemm(mat(yspec, rows, Cin), mat(Wi), frames)
+    if lanes is not None:
+        lanes.chain_enter()  # pred is accumulated branch after branch
     ops.istft_ola(frames, pred, B, F, N, hop, T, window, wbranch_row, wscale, accumulate)
+    if lanes is not None:
+        lanes.chain_leave()
     if keep:
         return dict(packed=packed, h0=h0, blocks=saved_blocks, x_last=xcur, emb=emb, th=th, ts=ts,
                     te=te, tew=tew, te_all=te_all, flags=flags, F=F)
@@ -400,7 +404,7 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
 
 
 def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_row, wscale,
-                     lens_f, g_x, accumulate_gx, g_cproj, need_gx):
+                     lens_f, g_x, accumulate_gx, g_cproj, need_gx, lanes=None):
     n_fft, hop, up, window = meta
     dev = g_pred.device
     B, T = x_shape
@@ -450,7 +454,11 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
         gemm(mat(gh0, rows, Cc), mat(bv.w_in.reshape(Cc, Cin)), gpacked, form=1)
         gxf = ops.empty(rows, N, device=dev)
         gemm(mat(gpacked, rows, Cin), mat(Wd), gxf, form=1)
+        if lanes is not None:
+            lanes.chain_enter()  # g_x is accumulated branch after branch
         ops.frames_fold(gxf, g_x, B, F, N, hop, T, accumulate_gx)
+        if lanes is not None:
+            lanes.chain_leave()
     # time path
     Dt, Ht = bv.Dt, bv.Ht
     g_tew = ops.zeros(NC, Dt, device=dev)
@@ -495,16 +503,19 @@ class ModelEvalFn(torch.autograd.Function):
         keep = any(ctx.needs_input_grad)
         saved, views, lens_list = [], [], []
         off = 0
-        for i in range(nb):
-            bv = _BranchView(list(flat[off: off + nparams[i]]))
+        for i in range(nb):  # everything the lanes share is created on the caller's stream
+            views.append(_BranchView(list(flat[off: off + nparams[i]])))
             off += nparams[i]
-            lens_f = frames_lens(lens_cpu, metas[i][1], dev)
+            lens_list.append(frames_lens(lens_cpu, metas[i][1], dev))
+            dft_matrices(metas[i][0], dev)
+        lanes = ops.Lanes(dev, nb)  # one launch lane (HIP stream) per Fourier branch
+        for i in range(nb):
             wrow = None if wbranch is None else wbranch[i]
-            sv = _branch_forward(bv, metas[i], x, t, cprojs[i], wrow, 1.0 / nb, pred, i > 0, lens_f,
-                                 training, keep)
+            with lanes.lane(i):
+                sv = _branch_forward(views[i], metas[i], x, t, cprojs[i], wrow, 1.0 / nb, pred,
+                                     i > 0, lens_list[i], training, keep, lanes)
             saved.append(sv)
-            views.append(bv)
-            lens_list.append(lens_f)
+        lanes.join()
         if keep:
             ctx.saved = saved
             ctx.views = views
@@ -525,15 +536,18 @@ class ModelEvalFn(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]
         g_x = ops.empty(B, T, device=dev) if need_gx else None
         g_cprojs, g_flat = [], []
+        lanes = ops.Lanes(dev, nb)  # branch i runs on the lane that holds its saved activations
         for i in range(nb):
             cproj = ctx.cprojs[i]
             need_gc = ctx.needs_input_grad[7 + i]
-            g_cp = ops.zeros(cproj.shape[0], cproj.shape[1], device=dev) if need_gc else None
             wrow = None if ctx.wbranch is None else ctx.wbranch[i]
-            g_flat += _branch_backward(ctx.views[i], ctx.metas[i], ctx.saved[i], (B, T), cproj,
-                                       g_pred, wrow, 1.0 / nb, ctx.lens[i], g_x, i > 0, g_cp,
-                                       need_gx)
+            with lanes.lane(i):
+                g_cp = ops.zeros(cproj.shape[0], cproj.shape[1], device=dev) if need_gc else None
+                g_flat += _branch_backward(ctx.views[i], ctx.metas[i], ctx.saved[i], (B, T), cproj,
+                                           g_pred, wrow, 1.0 / nb, ctx.lens[i], g_x, i > 0, g_cp,
+                                           need_gx, lanes)
             g_cprojs.append(g_cp)
+        lanes.join()
         ctx.saved = None
         return tuple([g_x, None, None, None, None, None, None] + g_cprojs + g_flat)
 
@@ -592,7 +606,7 @@ def filterbank_spec(x, n_fft: int, hop: int, fb, power: int):
 
 
 def filterbank_spec_bwd(gS, packed, n_fft: int, hop: int, fb, power: int, B: int, T: int, F: int,
-                        g_x, accumulate: bool):
+                        g_x, accumulate: bool, lanes=None):
     dev = gS.device
     rows = packed.shape[0]
     nb = n_fft // 2 + 1
@@ -603,7 +617,11 @@ def filterbank_spec_bwd(gS, packed, n_fft: int, hop: int, fb, power: int, B: int
     Wd, _ = dft_matrices(n_fft, dev)
     gfr = ops.empty(rows, n_fft, device=dev)
     gemm(mat(gpacked, rows, n_fft + 2), mat(Wd), gfr, form=1)
+    if lanes is not None:
+        lanes.chain_enter()  # g_x is accumulated scale after scale
     ops.frames_fold(gfr, g_x, B, F, n_fft, hop, T, accumulate)
+    if lanes is not None:
+        lanes.chain_leave()
 
 
 @torch.no_grad()

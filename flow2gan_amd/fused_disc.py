@@ -130,7 +130,9 @@ class MPDLossFn(torch.autograd.Function):
         x2 = stack_pair(real, fake)
         losses = ops.zeros(2, device=dev)
         saved = []
+        lanes = ops.Lanes(dev, len(periods))  # one launch lane per sub-discriminator
         for i, p in enumerate(periods):
+          with lanes.lane(i):
             prm = list(params[12 * i: 12 * i + 12])
             st = _mpd_forward_one(x2, p, prm)
             S, H5 = st["S"], st["hs"][5]
@@ -147,6 +149,7 @@ class MPDLossFn(torch.autograd.Function):
                     ops.l1_loss_ab(losses, None, y, 0, y, n, 1, n, n, 1.0 / n, loss_offset=1)
                 ops.l1_loss_ab(losses, None, sc, 0, sc, nh, 1, nh, nh, 1.0 / nh, loss_offset=1)
             saved.append(st)
+        lanes.join()
         ctx.saved = saved
         ctx.params = params
         ctx.meta = (B, T, train_disc, tuple(periods))
@@ -161,7 +164,9 @@ class MPDLossFn(torch.autograd.Function):
         g1 = g1.reshape(1).contiguous()
         pgrads: List = []
         g_fake = None if train_disc else ops.zeros(B, T, device=dev)
+        lanes = ops.Lanes(dev, len(periods))
         for i, p in enumerate(periods):
+          with lanes.lane(i):
             prm = list(params[12 * i: 12 * i + 12])
             st = ctx.saved[i]
             acts, hs, sc, S = st["acts"], st["hs"], st["scores"], st["S"]
@@ -212,8 +217,11 @@ class MPDLossFn(torch.autograd.Function):
                     g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin)
             if not train_disc:
                 # g: (B*p*H0, 1) gradient of the folded image of the generated half
+                lanes.chain_enter()  # g_fake is accumulated period after period
                 ops.period_fold_bwd(g_fake, g, B, T, p, hs[0], True)
+                lanes.chain_leave()
             pgrads += grads_p
+        lanes.join()
         ctx.saved = None
         return tuple([None, g_fake, None, None] + pgrads)
 
@@ -348,7 +356,11 @@ class MRDLossFn(torch.autograd.Function):
         x2 = stack_pair(real, fake)
         losses = ops.zeros(2, device=dev)
         saved = []
+        for win in fft_sizes:
+            dft_interleaved(win, dev)  # cached constants are created on the caller's stream
+        lanes = ops.Lanes(dev, len(fft_sizes))  # one launch lane per STFT resolution
         for i, win in enumerate(fft_sizes):
+          with lanes.lane(i):
             prm = list(params[N_MRD_PARAMS * i: N_MRD_PARAMS * (i + 1)])
             st = _mrd_forward_one(x2, win, prm)
             Ft, Wcat = st["Ft"], st["Wcat"]
@@ -376,6 +388,7 @@ class MRDLossFn(torch.autograd.Function):
                     foff += ws[5]
                 ops.l1_loss_ab(losses, None, sc, 0, sc, nh, 1, nh, nh, 1.0 / nh, loss_offset=1)
             saved.append(st)
+        lanes.join()
         ctx.saved = saved
         ctx.x2 = x2
         ctx.params = params
@@ -392,7 +405,9 @@ class MRDLossFn(torch.autograd.Function):
         pgrads: List = []
         g_fake = None if train_disc else ops.zeros(B, T, device=dev)
         C = MRD_CH
+        lanes = ops.Lanes(dev, len(fft_sizes))
         for i, win in enumerate(fft_sizes):
+          with lanes.lane(i):
             prm = list(params[N_MRD_PARAMS * i: N_MRD_PARAMS * (i + 1)])
             st = ctx.saved[i]
             Ft, Wcat, nb, ldp, hop = st["Ft"], st["Wcat"], st["nb"], st["ldp"], st["hop"]
@@ -498,8 +513,11 @@ class MRDLossFn(torch.autograd.Function):
                 # x2 = [real; fake]: the generated half starts at row B
                 ops.call("f2g_peaknorm_bwd", ops.ptr(gx2), ops.ptr(gxn),
                          ops.ptr(ctx.x2) + 4 * B * T, ops.ptr(st["stats"]) + 4 * 3 * B, B, T)
+                lanes.chain_enter()  # g_fake is accumulated resolution after resolution
                 ops.axpby_rows(g_fake, g_fake, gx2, sa=1.0, sb=1.0)
+                lanes.chain_leave()
             pgrads += grads_w
+        lanes.join()
         ctx.saved = None
         return tuple([None, g_fake, None, None] + pgrads)
 
@@ -527,10 +545,15 @@ class MelReconLossFn(torch.autograd.Function):
         loss = ops.zeros(1, device=dev)
         saved = []
         for n_fft, hop, fb in specs:
+            dft_matrices(n_fft, dev)
+        lanes = ops.Lanes(dev, len(specs))  # one launch lane per mel scale
+        for i, (n_fft, hop, fb) in enumerate(specs):
+          with lanes.lane(i):
             S, packed, spec, F = filterbank_spec(x2, n_fft, hop, fb, 1)
             n = B * F * fb.shape[1]
             ops.l1_loss_ab(loss, None, S, 0, S, n, 1, n, n, 1.0 / n, clip=1e-7)
             saved.append((S, packed, F))
+        lanes.join()
         ctx.saved = saved
         ctx.specs = specs
         ctx.dims = (B, T)
@@ -542,7 +565,9 @@ class MelReconLossFn(torch.autograd.Function):
         dev = g.device
         gw = g.reshape(1).contiguous()
         g_fake = ops.empty(B, T, device=dev)
+        lanes = ops.Lanes(dev, len(ctx.specs))
         for i, (n_fft, hop, fb) in enumerate(ctx.specs):
+          with lanes.lane(i):
             S, packed, F = ctx.saved[i]
             nm = fb.shape[1]
             n = B * F * nm
@@ -550,6 +575,8 @@ class MelReconLossFn(torch.autograd.Function):
             # gb follows b's layout: write straight into a fake-half-sized buffer via offsets
             ops.call("f2g_l1_loss", None, ops.ptr(gS), ops.ptr(S), ops.ptr(S) + 4 * n, 1, n, n,
                      1.0 / n, 1e-7, ops.ptr(gw))
-            filterbank_spec_bwd(gS, packed[B * F:], n_fft, hop, fb, 1, B, T, F, g_fake, i > 0)
+            filterbank_spec_bwd(gS, packed[B * F:], n_fft, hop, fb, 1, B, T, F, g_fake, i > 0,
+                                lanes)
+        lanes.join()
         ctx.saved = None
         return None, g_fake, None

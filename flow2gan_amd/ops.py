@@ -107,9 +107,11 @@ def win2d(t, nseq: int, H: int, W: int, Cin: int, W_out: int, kh: int, kw: int, 
 def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None, *, bias=None,
          res=None, ldres: Optional[int] = None, gamma=None, aux=None, ldaux: Optional[int] = None,
          alpha_n=None, colsum_alpha=None, colsum=None, lrelu: float = 0.0, scale: float = 0.0,
-         accumulate: bool = False, atomic: bool = False, split_k: int = 1, out_offset: int = 0,
+         accumulate: bool = False, atomic: bool = False, split_k: int = 0, out_offset: int = 0,
          rowmap=None):
-    """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None."""
+    """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None.
+    split_k: 0 = let the library decide (forms 0/1: split-K onto a zeroed output when the tile
+    grid would leave most of the last wave of CUs idle), 1 = off, > 1 = as given."""
     d = GemmDesc()
     d.A, d.B = A, Bm
     e = Epilogue()
@@ -202,6 +204,70 @@ def set_gemm_precision(name: str) -> None:
     if name not in ("fp32", "bf16x3"):
         raise ValueError("precision must be 'fp32' or 'bf16x3'")
     GEMM_PRECISION = 1 if name == "bf16x3" else 0
+
+
+# ------------------------------------------------------------------ concurrent launch lanes
+# The three Fourier branches (and the 5 + 3 sub-discriminators) are independent kernel sequences
+# whose mid-size GEMMs each leave part of the last wave of CUs idle (282 tiles for 512 resident
+# slots ...).  Launching them on separate HIP streams lets the hardware fill those holes with
+# another lane's blocks.  F2G_STREAMS=0 (or an active GemmTimer: per-kernel roofline timing wants
+# kernels in isolation) runs the lanes one after the other on the caller's stream.
+CONCURRENT = _os.environ.get("F2G_STREAMS", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_streams(device, n: int):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+class Lanes:
+    """Fork n launch lanes off the current stream, join them back.
+
+        lanes = Lanes(dev, 3)
+        for i in range(3):
+            with lanes.lane(i):
+                ...launches...
+        lanes.join()
+
+    Lane i always maps to the same persistent side stream, so tensors a lane allocates (and keeps
+    for its backward) stay in that stream's allocator pool and are only ever touched by that lane
+    or, after join(), by the caller's stream."""
+
+    def __init__(self, device, n: int):
+        self.main = torch.cuda.current_stream(device)
+        self.on = CONCURRENT and n > 1 and GEMM_TIMER is None
+        self.streams = _side_streams(device, n) if self.on else [self.main] * n
+        if self.on:
+            fork = torch.cuda.Event()
+            fork.record(self.main)
+            for s in self.streams:
+                s.wait_event(fork)
+        self._chain = None
+
+    def lane(self, i: int):
+        return torch.cuda.stream(self.streams[i])
+
+    def chain_enter(self):
+        """Serialise a read-modify-write of a buffer shared by the lanes (call inside a lane)."""
+        if self.on and self._chain is not None:
+            torch.cuda.current_stream().wait_event(self._chain)
+
+    def chain_leave(self):
+        if self.on:
+            self._chain = torch.cuda.Event()
+            self._chain.record(torch.cuda.current_stream())
+
+    def join(self):
+        if not self.on:
+            return
+        for s in self.streams:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.main.wait_event(ev)
 
 
 def split_for(reduction_rows: int, out_tiles: int) -> int:

@@ -100,6 +100,10 @@ typedef struct {
   f2g_operand A, B;
   f2g_epilogue E;
   int32_t form;
+  /* reduction split.  form 2: >= 1, needs E.atomic when > 1.  forms 0/1: 1 = off; > 1 = the K
+   * range is cut into that many chunks whose partial tiles are added atomically (the library
+   * zeroes C first unless E.accumulate; bias / residual enter once; linear epilogues only);
+   * 0 = the library picks (splits only deep reductions that would leave the last wave idle). */
   int32_t split_k;
   /* 0 = exact fp32 MFMA (bit-for-bit an fmaf chain); 1 = split-bf16: every fp32 operand is staged as
    * hi+lo bf16 and each product is hi*hi + hi*lo + lo*hi with fp32 accumulation (per-product
