@@ -508,7 +508,7 @@ class ModelEvalFn(torch.autograd.Function):
             off += nparams[i]
             lens_list.append(frames_lens(lens_cpu, metas[i][1], dev))
             dft_matrices(metas[i][0], dev)
-        lanes = ops.Lanes(dev, nb)  # one launch lane (HIP stream) per Fourier branch
+        lanes = ops.Lanes(dev, nb, "branch")  # one launch lane (HIP stream) per Fourier branch
         for i in range(nb):
             wrow = None if wbranch is None else wbranch[i]
             with lanes.lane(i):
@@ -536,7 +536,7 @@ class ModelEvalFn(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]
         g_x = ops.empty(B, T, device=dev) if need_gx else None
         g_cprojs, g_flat = [], []
-        lanes = ops.Lanes(dev, nb)  # branch i runs on the lane that holds its saved activations
+        lanes = ops.Lanes(dev, nb, "branch")  # branch i runs on the lane that holds its activations
         for i in range(nb):
             cproj = ctx.cprojs[i]
             need_gc = ctx.needs_input_grad[7 + i]

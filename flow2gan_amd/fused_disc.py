@@ -130,7 +130,7 @@ class MPDLossFn(torch.autograd.Function):
         x2 = stack_pair(real, fake)
         losses = ops.zeros(2, device=dev)
         saved = []
-        lanes = ops.Lanes(dev, len(periods))  # one launch lane per sub-discriminator
+        lanes = ops.Lanes(dev, len(periods), "mpd")  # one launch lane per sub-discriminator
         for i, p in enumerate(periods):
           with lanes.lane(i):
             prm = list(params[12 * i: 12 * i + 12])
@@ -164,7 +164,7 @@ class MPDLossFn(torch.autograd.Function):
         g1 = g1.reshape(1).contiguous()
         pgrads: List = []
         g_fake = None if train_disc else ops.zeros(B, T, device=dev)
-        lanes = ops.Lanes(dev, len(periods))
+        lanes = ops.Lanes(dev, len(periods), "mpd")
         for i, p in enumerate(periods):
           with lanes.lane(i):
             prm = list(params[12 * i: 12 * i + 12])
@@ -358,7 +358,7 @@ class MRDLossFn(torch.autograd.Function):
         saved = []
         for win in fft_sizes:
             dft_interleaved(win, dev)  # cached constants are created on the caller's stream
-        lanes = ops.Lanes(dev, len(fft_sizes))  # one launch lane per STFT resolution
+        lanes = ops.Lanes(dev, len(fft_sizes), "mrd")  # one launch lane per STFT resolution
         for i, win in enumerate(fft_sizes):
           with lanes.lane(i):
             prm = list(params[N_MRD_PARAMS * i: N_MRD_PARAMS * (i + 1)])
@@ -405,7 +405,7 @@ class MRDLossFn(torch.autograd.Function):
         pgrads: List = []
         g_fake = None if train_disc else ops.zeros(B, T, device=dev)
         C = MRD_CH
-        lanes = ops.Lanes(dev, len(fft_sizes))
+        lanes = ops.Lanes(dev, len(fft_sizes), "mrd")
         for i, win in enumerate(fft_sizes):
           with lanes.lane(i):
             prm = list(params[N_MRD_PARAMS * i: N_MRD_PARAMS * (i + 1)])
@@ -546,7 +546,7 @@ class MelReconLossFn(torch.autograd.Function):
         saved = []
         for n_fft, hop, fb in specs:
             dft_matrices(n_fft, dev)
-        lanes = ops.Lanes(dev, len(specs))  # one launch lane per mel scale
+        lanes = ops.Lanes(dev, len(specs), "mel")  # one launch lane per mel scale
         for i, (n_fft, hop, fb) in enumerate(specs):
           with lanes.lane(i):
             S, packed, spec, F = filterbank_spec(x2, n_fft, hop, fb, 1)
@@ -565,7 +565,7 @@ class MelReconLossFn(torch.autograd.Function):
         dev = g.device
         gw = g.reshape(1).contiguous()
         g_fake = ops.empty(B, T, device=dev)
-        lanes = ops.Lanes(dev, len(ctx.specs))
+        lanes = ops.Lanes(dev, len(ctx.specs), "mel")
         for i, (n_fft, hop, fb) in enumerate(ctx.specs):
           with lanes.lane(i):
             S, packed, F = ctx.saved[i]

@@ -63,6 +63,8 @@ class GAN(nn.Module):
                 pred_audio = self.generator.infer(cond=cond, audio_lens=audio_lens,
                                                   n_timesteps=n_timesteps, clamp_pred=False,
                                                   noise=noise)
+            # (each term forks one launch lane per sub-discriminator inside; running MPD and MRD
+            # side by side on top of that was measured to add nothing: the chip is already full)
             disc_loss_mp, _ = self._mp_terms(audio, pred_audio, True)
             disc_loss_mr, _ = self._mr_terms(audio, pred_audio, True)
             return disc_loss_mp, disc_loss_mr

@@ -216,8 +216,9 @@ CONCURRENT = _os.environ.get("F2G_STREAMS", "1") != "0"
 _SIDE_STREAMS: dict = {}
 
 
-def _side_streams(device, n: int):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def _side_streams(device, n: int, pool_name: str):
+    idx = torch.device(device).index
+    key = (idx if idx is not None else torch.cuda.current_device(), pool_name)
     pool = _SIDE_STREAMS.setdefault(key, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
@@ -233,14 +234,15 @@ class Lanes:
                 ...launches...
         lanes.join()
 
-    Lane i always maps to the same persistent side stream, so tensors a lane allocates (and keeps
-    for its backward) stay in that stream's allocator pool and are only ever touched by that lane
-    or, after join(), by the caller's stream."""
+    Lane i of a pool always maps to the same persistent side stream, so tensors a lane allocates
+    (and keeps for its backward) stay in that stream's allocator pool and are only ever touched by
+    that lane or, after join(), by the caller's stream.  Lanes nest (a lane may fork its own
+    lanes) as long as every nesting level names its own `pool`."""
 
-    def __init__(self, device, n: int):
+    def __init__(self, device, n: int, pool: str = "lanes"):
         self.main = torch.cuda.current_stream(device)
         self.on = CONCURRENT and n > 1 and GEMM_TIMER is None
-        self.streams = _side_streams(device, n) if self.on else [self.main] * n
+        self.streams = _side_streams(device, n, pool) if self.on else [self.main] * n
         if self.on:
             fork = torch.cuda.Event()
             fork.record(self.main)
