@@ -202,7 +202,10 @@ def main():
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     "traffic": traffic, "launches_per_step": n,
-                    "gemm_share_of_step": round(secs / (elapsed / args.steps), 3),
+                    # the extra step runs with the launch lanes off (ops.Lanes checks GEMM_TIMER):
+                    # every kernel alone on the chip, one stream -- a per-kernel figure; the timed
+                    # region above overlaps up to 7 lanes, so these durations sum to more than a step
+                    "gemm_ms_per_step_serialised": round(1e3 * secs, 2),
                     "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
 
     cpu = None

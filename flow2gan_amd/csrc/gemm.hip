@@ -482,8 +482,9 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
 
 // ---- exact fp32: v_mfma_f32_32x32x2_f32 --------------------------------------------------
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                      int kchunk) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2)
+void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int LDA = AKM ? BM : LDR;
@@ -513,10 +514,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const f2g_gemm_desc d, int
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  using SA = typename std::conditional<AKM, Loader<AMODE, true, BK, BM>,
-                                       Loader<AMODE, false, BM, BK>>::type;
-  using SB = typename std::conditional<BKM, Loader<BMODE, true, BK, BN>,
-                                       Loader<BMODE, false, BN, BK>>::type;
+  using SA = typename std::conditional<AKM, Loader<AMODE, true, BK, BM, NT>,
+                                       Loader<AMODE, false, BM, BK, NT>>::type;
+  using SB = typename std::conditional<BKM, Loader<BMODE, true, BK, BN, NT>,
+                                       Loader<BMODE, false, BN, BK, NT>>::type;
   SA sa;
   SB sb;
   if (AKM) sa.init(d.A, 0, m0, kbeg, tid); else sa.init(d.A, m0, 0, kbeg, tid);
@@ -742,7 +743,7 @@ int launch(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t s
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_done = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), smem, st, d, M, N, K, kchunk);
   }
   return f2g_check_launch();
 }
@@ -763,12 +764,21 @@ int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
       return launch<2, 2, 2, 2, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);
     return launch<2, 4, 2, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);  // 128 x 128
   }
-  if (AKM && M <= 32) return launch<1, 4, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
+  // 32 x 256 for the weight gradients of 32-channel convs: 8 waves of one 32x32 tile each
+  // (51 -> 57 TFLOP/s on the MRD band layers vs 4 waves of 32x64)
+  if (AKM && M <= 32) return launch<1, 8, 1, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   // 128 x 32 (46 KB of LDS -> 3 blocks per CU); a 256 x 32 tile needs 83 KB and leaves ONE block
   // = one wave per SIMD on the CU, which cannot hide anything (measured 50 TFLOP/s on the
   // 32-channel MRD convs)
   if (N <= 32) return launch<4, 1, 1, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   if (N <= 64) return launch<4, 1, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
+  // 128 x 128.  k-major LDS tiles (data / weight gradients) are read with four ds_read_b32 per
+  // fragment instead of one ds_read_b128: 8 waves of 32x64 (4 waves per SIMD) hide that latency
+  // (measured +5..20 % on every dgrad / wgrad shape); row-major forward tiles are best with 4
+  // waves of 64x64 (least LDS traffic per MFMA).
+  // (windowed forward operands -- the MPD convs -- spend VALU on im2col addressing: 8 waves too)
+  if (AKM || BKM || AMODE == GF)
+    return launch<4, 2, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   return launch<2, 2, 2, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
 }
 
