@@ -34,6 +34,19 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// n / d for 0 <= n < 2^31 with a per-kernel magic number (gfx950 has no integer divide: the
+// compiler's expansion costs ~35 VALU instructions, and the windowed loaders divide once per
+// K slab / per chunk): magic = ceil(2^32 / d) over-estimates the quotient by at most one.
+__device__ __forceinline__ unsigned magic_of(int d) {
+  return d > 1 ? (unsigned)((0x100000000ull + (unsigned)d - 1u) / (unsigned)d) : 0u;
+}
+__device__ __forceinline__ int fast_div(int n, int d, unsigned mg) {
+  if (d == 1) return n;
+  int q = (int)__umulhi((unsigned)n, mg);
+  q -= (q * d > n) ? 1 : 0;
+  return q;
+}
+
 static inline int f2g_grid_for(int64_t n, int block, int cap = 2048 * 4) {
   int64_t g = (n + block - 1) / block;
   if (g > cap) g = cap;

@@ -127,6 +127,10 @@ __device__ __forceinline__ float prelu1(float v, float a) { return v > 0.f ? v :
 // ------------------------------------------------------------------------------------------
 enum { PF = 0, GF = 1, SL = 2 };
 
+// what an out-of-window chunk of a GF operand reads (16 aligned bytes of zeros)
+// (not const: the compiler must keep the address select instead of folding a select of values)
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // v = hi + lo + O(2^-17 |v|): hi = round-to-nearest bf16 of v, lo = bf16 of the remainder
@@ -165,10 +169,17 @@ struct Loader {
   int c0;                               // first window column (RM: + k0 per slab; KM: fixed)
   int row0;                             // KM: first reduction row of this thread
   RowCtx rc[(MODE != PF && !KM) ? NLD : 1];  // generic RM: decoded rows
+  long long rb[(MODE != PF && !KM) ? NLD : 1];  // generic RM: offset of the row's window origin
   int seg, o;                           // generic KM: decoded fixed column
+  unsigned mg_seg, mg_p0, mg_p1;        // generic: magic numbers of seglen / P0 / P1
 
   __device__ __forceinline__ void init(const f2g_operand& S, int tr0, int tc0, int kbeg, int tid) {
     active = !PARTIAL || tid < NCHUNK;
+    if (MODE != PF) {
+      mg_seg = magic_of(S.seglen);
+      mg_p0 = magic_of(S.P0);
+      mg_p1 = magic_of(S.P1);
+    }
     const int ch = tid % CH, rr = active ? tid / CH : 0;
     rokm = 0; cmask = 0;
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -211,6 +222,7 @@ struct Loader {
           const bool ok = row < S.rows;
           rokm |= (ok ? 1u : 0u) << q;
           rc[q] = decode_row(S, ok ? row : 0);
+          rb[q] = rc[q].base + (long long)rc[q].l1b * S.line_stride + rc[q].e0;
         }
       } else {
         c0 = tc0 + ch * 4;
@@ -231,13 +243,15 @@ struct Loader {
   __device__ __forceinline__ void gchunk(const f2g_operand& S, Stg& g, int q, bool rowok,
                                          const RowCtx& rcx, int c, int sg, int oo) {
     if (MODE == GF) {
+      // out-of-window chunks are read from a 16-byte block of zeros: nothing to mask afterwards
+      // (off = offset of the chunk relative to S.base, precombined by the caller)
       const int l1 = rcx.l1b + sg, e = rcx.e0 + oo;
       const bool v = rowok && c < S.cols && (unsigned)l1 < (unsigned)S.L1 && e >= 0 &&
                      e + 3 < S.L0u;
-      const long long off = v ? rcx.base + (long long)l1 * S.line_stride + e : 0;
-      g.r[q] = *reinterpret_cast<const float4*>(S.base + off);
-      if (S.lrelu_src) g.r2[q] = *reinterpret_cast<const float4*>(S.lrelu_src + off);
-      g.vmask |= (v ? 1u : 0u) << q;
+      const long long off = rcx.base;
+      g.r[q] = *reinterpret_cast<const float4*>(v ? S.base + off : g_zero16);
+      if (S.lrelu_src)
+        g.r2[q] = *reinterpret_cast<const float4*>(v ? S.lrelu_src + off : g_zero16);
     } else {
       // SL: the same clamped-address scheme element by element (4 unconditional scalar loads, no
       // divergent branches); handles reflect padding, odd segment lengths and misaligned rows.
@@ -289,15 +303,20 @@ struct Loader {
       if (!KM) {
         const int c = c0 + k0;
         int sg = 0, oo = c;
-        if (S.seglen < S.cols) { sg = c / S.seglen; oo = c - sg * S.seglen; }
+        if (S.seglen < S.cols) { sg = fast_div(c, S.seglen, mg_seg); oo = c - sg * S.seglen; }
         if (MODE != PF && S.alpha) {
           g.a4.x = c < S.cols ? S.alpha[c] : 0.f;
           g.a4.y = c + 1 < S.cols ? S.alpha[c + 1] : 0.f;
           g.a4.z = c + 2 < S.cols ? S.alpha[c + 2] : 0.f;
           g.a4.w = c + 3 < S.cols ? S.alpha[c + 3] : 0.f;
         }
+        const int so = sg * (int)S.line_stride + oo;  // the slab's offset inside a row's window
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) gchunk(S, g, q, (rokm >> q) & 1, rc[q], c, sg, oo);
+        for (int q = 0; q < NLD; ++q) {
+          RowCtx rx = rc[q];
+          if (MODE == GF) rx.base = rb[q] + so;
+          gchunk(S, g, q, (rokm >> q) & 1, rx, c, sg, oo);
+        }
       } else {
         // the thread's NLD rows are consecutive pixels: decode the first (two divisions), then
         // step (p0, p1, s) with carries
@@ -306,7 +325,12 @@ struct Loader {
         {
           const int r = rfirst < S.rows ? rfirst : 0;
           if (S.P0 == 1 && S.P1 == 1) { s_ = r; p1_ = 0; p0_ = 0; }
-          else { const int qq = r / S.P0; p0_ = r - qq * S.P0; s_ = qq / S.P1; p1_ = qq - s_ * S.P1; }
+          else {
+            const int qq = fast_div(r, S.P0, mg_p0);
+            p0_ = r - qq * S.P0;
+            s_ = fast_div(qq, S.P1, mg_p1);
+            p1_ = qq - s_ * S.P1;
+          }
         }
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
@@ -315,6 +339,7 @@ struct Loader {
           rcx.base = (long long)s_ * S.seq_stride;
           rcx.l1b = p1_ * S.step1 - S.pad1;
           rcx.e0 = (p0_ * S.step0 - S.pad0) * S.unit;
+          if (MODE == GF) rcx.base += (long long)(rcx.l1b + seg) * S.line_stride + (rcx.e0 + o);
           gchunk(S, g, q, ok, rcx, c0, seg, o);
           ++p0_;
           const bool c0w = p0_ >= S.P0;
@@ -332,7 +357,7 @@ struct Loader {
   __device__ __forceinline__ float4 finalize(const f2g_operand& S, const Stg& g, int q) const {
     float4 v = g.r[q];
     const float4 a4 = g.a4;
-    if (!((g.vmask >> q) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE != GF && !((g.vmask >> q) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == PF && KM) {  // column tail of the fixed chunk
       if (!(cmask & 1)) v.x = 0.f;
       if (!(cmask & 2)) v.y = 0.f;

@@ -17,15 +17,29 @@ struct RowCtx {
   int l1b, e0;
 };
 
-__device__ __forceinline__ RowCtx decode_row(const f2g_operand& S, int r) {
+// magic numbers of an operand's divisors (common.h: fast_div), computed once per thread
+struct Mg {
+  unsigned seg, p0, p1;
+  int seglen;
+};
+__device__ __forceinline__ Mg magics(const f2g_operand& S) {
+  Mg m;
+  m.seglen = S.seglen < S.cols ? S.seglen : S.cols;
+  m.seg = magic_of(m.seglen);
+  m.p0 = magic_of(S.P0);
+  m.p1 = magic_of(S.P1);
+  return m;
+}
+
+__device__ __forceinline__ RowCtx decode_row(const f2g_operand& S, int r, const Mg& mg) {
   RowCtx rc;
   int s, p1, p0;
   if (S.P0 == 1 && S.P1 == 1) {
     s = r; p1 = 0; p0 = 0;
   } else {
-    int q = r / S.P0;
+    int q = fast_div(r, S.P0, mg.p0);
     p0 = r - q * S.P0;
-    s = q / S.P1;
+    s = fast_div(q, S.P1, mg.p1);
     p1 = q - s * S.P1;
   }
   rc.base = (long long)s * S.seq_stride;
@@ -35,9 +49,10 @@ __device__ __forceinline__ RowCtx decode_row(const f2g_operand& S, int r) {
 }
 
 // element (row, c) of an operand, branch-free clamped load; applies PReLU / leaky-ReLU transforms
-__device__ __forceinline__ float elem(const f2g_operand& S, const RowCtx& rc, bool rowok, int c) {
-  const int seglen = S.seglen < S.cols ? S.seglen : S.cols;
-  const int sg = c / seglen, oo = c - sg * seglen;
+__device__ __forceinline__ float elem(const f2g_operand& S, const RowCtx& rc, bool rowok, int c,
+                                      const Mg& mg) {
+  const int seglen = mg.seglen;
+  const int sg = fast_div(c, seglen, mg.seg), oo = c - sg * seglen;
   const int l1 = rc.l1b + sg;
   int off = rc.e0 + oo;
   bool ok = rowok && c < S.cols && (unsigned)l1 < (unsigned)S.L1;
@@ -65,17 +80,18 @@ __device__ __forceinline__ long long out_offset(const f2g_epilogue& E, int row, 
 
 // 4 consecutive window columns of a decoded row: one vector load when the chunk is interior and
 // 16-byte aligned, else element-wise
-__device__ __forceinline__ float4 chunk(const f2g_operand& S, const RowCtx& rc, int c) {
-  const int seglen = S.seglen < S.cols ? S.seglen : S.cols;
-  const int sg = c / seglen, oo = c - sg * seglen;
+__device__ __forceinline__ float4 chunk(const f2g_operand& S, const RowCtx& rc, int c,
+                                        const Mg& mg) {
+  const int seglen = mg.seglen;
+  const int sg = fast_div(c, seglen, mg.seg), oo = c - sg * seglen;
   const int l1 = rc.l1b + sg, e = rc.e0 + oo;
   if (!S.alpha && !S.lrelu_src && c + 3 < S.cols && oo + 3 < seglen &&
       (unsigned)l1 < (unsigned)S.L1 && e >= 0 && e + 3 < S.L0u) {
     const float* p = S.base + rc.base + (long long)l1 * S.line_stride + e;
     if ((((uintptr_t)p) & 15) == 0) return *reinterpret_cast<const float4*>(p);
   }
-  return make_float4(elem(S, rc, true, c), elem(S, rc, true, c + 1), elem(S, rc, true, c + 2),
-                     elem(S, rc, true, c + 3));
+  return make_float4(elem(S, rc, true, c, mg), elem(S, rc, true, c + 1, mg),
+                     elem(S, rc, true, c + 2, mg), elem(S, rc, true, c + 3, mg));
 }
 
 // forms 0 / 1 with N <= 4: the (K x N) weight panel is staged once per block in LDS as [n][k];
@@ -98,14 +114,15 @@ __global__ __launch_bounds__(256) void narrow_rows_kernel(const f2g_gemm_desc d,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f2g_epilogue& E = d.E;
   const float scale = E.scale != 0.f ? E.scale : 1.f;
+  const Mg mg = magics(d.A);
   const long long rbase = ((long long)blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
   for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
     const long long row = rbase + rr;
     if (row >= M) break;
-    const RowCtx rc = decode_row(d.A, (int)row);
+    const RowCtx rc = decode_row(d.A, (int)row, mg);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = lane * 4; k < K; k += 256) {
-      const float4 a = chunk(d.A, rc, k);
+      const float4 a = chunk(d.A, rc, k, mg);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         if (n < N) {
@@ -137,11 +154,12 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const f2g_gemm_desc d
   int r1 = r0 + rows_per;
   if (r1 > R) r1 = R;
   const long long lda = d.A.seq_stride;
+  const Mg mg = magics(d.B);
   for (int c = threadIdx.x; c < N; c += 256) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int r = r0; r < r1; ++r) {
-      const RowCtx rb = decode_row(d.B, r);
-      const float x = elem(d.B, rb, true, c);
+      const RowCtx rb = decode_row(d.B, r, mg);
+      const float x = elem(d.B, rb, true, c, mg);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
         if (m < M) acc[m] += d.A.base[(long long)r * lda + m] * x;
