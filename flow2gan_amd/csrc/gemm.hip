@@ -791,6 +791,8 @@ int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
   }
   // 32 x 256 for the weight gradients of 32-channel convs: 8 waves of one 32x32 tile each
   // (51 -> 57 TFLOP/s on the MRD band layers vs 4 waves of 32x64)
+  if (AKM && M <= 32 && N <= 64)  // first MRD layer (2 -> 32 channels, 54 taps): 32 x 64, 2 waves
+    return launch<1, 2, 1, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   if (AKM && M <= 32) return launch<1, 8, 1, 1, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   // 128 x 32 (46 KB of LDS -> 3 blocks per CU); a 256 x 32 tile needs 83 KB and leaves ONE block
   // = one wave per SIMD on the CU, which cannot hide anything (measured 50 TFLOP/s on the
