@@ -195,7 +195,7 @@ def main():
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                            "r01_pmc_gemm_traffic.json")
         if (args.workload == "gan_stage2" and args.gemm == "fp32" and args.model == "mel_24k_base"
-                and B == 64 and os.path.exists(pmc)):
+                and B == 64 and nts == 1 and os.path.exists(pmc)):
             with open(pmc) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch_fetch_x2"])
         roofline = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA implicit GEMM, all forms)",
