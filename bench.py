@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3"],
                     help="GEMM arithmetic of the headline number (fp32 = exact, the reference's)")
     ap.add_argument("--no-fast-mode", action="store_true")
+    ap.add_argument("--optimizer", action="store_true",
+                    help="also run the fused ScaledAdam + Eden2 step inside the timed region "
+                         "(a complete train step; the BASELINE metric itself is fwd/bwd)")
     return ap.parse_args()
 
 
@@ -105,6 +108,19 @@ def main():
     g_params = list(gan.generator.parameters())
     d_params = list(gan.discriminator.parameters())
 
+    opt_d = opt_g = sch_d = sch_g = None
+    if args.optimizer:  # finetune.py:917-921 / pretrain.py:794-799 settings
+        from flow2gan_amd.optim import Eden2, ScaledAdam
+        opt_g = ScaledAdam(gan.generator.named_parameters(), lr=1e-4, clipping_scale=2.0)
+        sch_g = Eden2(opt_g, lr_batches=50000, warmup_start=0.1)
+        opt_d = ScaledAdam(gan.discriminator.named_parameters(), lr=1e-4, clipping_scale=2.0)
+        sch_d = Eden2(opt_d, lr_batches=50000, warmup_start=0.1)
+
+    def optimize(opt, sch):
+        if opt is not None:
+            opt.step()
+            sch.step_batch()
+
     audio_d = synthetic_batch(B, T, 1234 + rank, device)
     audio_g = synthetic_batch(B, T, 4321 + rank, device)
     lens = torch.full((B,), T, dtype=torch.int64)
@@ -120,12 +136,14 @@ def main():
             mp, mr = gan(cond, audio_d, lens, nts, True)
             (D_WEIGHTS[0] * mp + D_WEIGHTS[1] * mr).backward()
             reducer.finish()
+            optimize(opt_d, sch_d)
             # generator step on a new batch
             reducer.prepare(g_params)
             cond = logmel(audio_g)
             ls = gan(cond, audio_g, lens, nts, False)
             sum(w * l for w, l in zip(G_WEIGHTS, ls)).backward()
             reducer.finish()
+            optimize(opt_g, sch_g)
             return 2 * B * (T / sr)
         if args.workload == "stage1":
             gen.train()
@@ -133,6 +151,7 @@ def main():
             cond = logmel(audio_g)
             gen(cond, audio_g, lens).backward()
             reducer.finish()
+            optimize(opt_g, sch_g)
             return B * (T / sr)
         gen.eval()
         with torch.no_grad():
@@ -234,11 +253,13 @@ def main():
             "config": {"workload": args.model + " " + {
                            "gan_stage2": "GAN stage-2 train step: D-step + G-step, "
                                          "each on its own batch (MPD+MRD+FM+multi-scale mel), "
-                                         "fwd+bwd+grad all-reduce, no optimizer (metric is fwd/bwd)",
+                                         "fwd+bwd+grad all-reduce" + (" + optimizer step" if args.optimizer
+                                                                    else ", no optimizer (metric is fwd/bwd)"),
                            "stage1": "flow-matching stage-1 fwd+bwd",
                            "infer4": "4-step Euler inference"}[args.workload],
                        "per_gpu_batch": B, "seconds_per_item": T / sr, "n_timesteps": nts,
-                       "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}"},
+                       "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}",
+                       "optimizer": "ScaledAdam + Eden2 (fused HIP)" if args.optimizer else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast,
         }
         # RCCL prints its version banner through C stdio (flushed at exit): push it out first so

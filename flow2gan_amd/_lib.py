@@ -76,6 +76,21 @@ class DwconvBwd(C.Structure):
     ]
 
 
+class SadamGroup(C.Structure):  # == f2g_sadam_group
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("scalar_lr_scale", C.c_float), ("eps", C.c_float), ("param_min_rms", C.c_float),
+                ("param_max_rms", C.c_float), ("scalar_max", C.c_float),
+                ("clipping_scale", C.c_float), ("size_update_period", C.c_int32),
+                ("clipping_update_period", C.c_int32), ("step", C.c_int32),
+                ("first", C.c_int32), ("count", C.c_int32)]
+
+
+# numpy layouts of the device tables (== f2g_sadam_tensor / f2g_sadam_chunk)
+SADAM_TENSOR_DTYPE = [("p", "<u8"), ("g", "<u8"), ("v", "<u8"), ("m", "<u8"), ("numel", "<i8"),
+                      ("group", "<i4"), ("is_scalar", "<i4")]
+SADAM_CHUNK_DTYPE = [("tensor", "<i4"), ("count", "<i4"), ("offset", "<i8")]
+SADAM_NCOEF, SADAM_TSTATE, SADAM_GSTATE = 12, 10, 1028
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (stream appended automatically)
@@ -114,9 +129,12 @@ _SIGS = {
     "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
     "f2g_fill": [_P, _F, _L],
     "f2g_log_clip": [_P, _L, _F],
+    "f2g_sadam_stats": [_P, _P, _I, _P, _I],
+    "f2g_sadam_prepare": [_P, C.POINTER(SadamGroup), _P, _P, _P, _P],
+    "f2g_sadam_update": [_P, _P, _I, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_dwnorm_bwd_workspace",
-                                 "f2g_dwconv_bwd_workspace"])
+                                 "f2g_dwconv_bwd_workspace", "f2g_sadam_chunk_elems"])
 
 
 class F2GError(RuntimeError):
@@ -137,6 +155,8 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = [C.c_int32] * 4
         fn.restype = C.c_int64
+    lib.f2g_sadam_chunk_elems.argtypes = []
+    lib.f2g_sadam_chunk_elems.restype = C.c_int32
     lib.f2g_version.restype = C.c_char_p
     lib.f2g_last_error.restype = C.c_char_p
     return lib

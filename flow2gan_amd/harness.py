@@ -5,8 +5,8 @@ flow2gan/bin/finetune.py:427-492: the mel condition is computed from the audio b
 step, the loss weights and D/G switch are the reference's, `GanStepper` reproduces the batch
 schedule of finetune.py:569-631 (discriminator-only until `gen_start_batch_idx`, then strict
 D / G alternation, each on a NEW batch), and gradients are averaged across ranks exactly for the
-sub-model being stepped.  Optimizer and LR schedule (ScaledAdam / Eden2) are out of scope for this
-path: callers plug their own `optimizer_{d,g}` callables.
+sub-model being stepped.  `optimizer_{d,g}` are callables run after the gradient exchange, e.g.
+`lambda: (opt.step(), sched.step_batch())` with flow2gan_amd.optim.ScaledAdam / Eden2.
 """
 from __future__ import annotations
 

@@ -312,6 +312,48 @@ int f2g_log_clip(float* x, int64_t n, float clip, f2g_stream_t stream);
 /* fill */
 int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
 
+/* ---- ScaledAdam (reference optim.py:125-255 basic/scaling/momentum steps,
+ * :451-507 step, :509-619 clipping) as multi-tensor launches over device-resident tables.
+ * The caller owns every buffer: params p, grads g (NULL = zeros, optim.py:111-113), second moment
+ * v and momentum m per tensor; stats (3 floats per tensor), tstate (F2G_SADAM_TSTATE per tensor:
+ * param_rms, scale_exp_avg_sq, scale_grads[8]), gstate (F2G_SADAM_GSTATE per group: model_norms
+ * ring, threshold, flags), coef (F2G_SADAM_NCOEF per tensor).  One optimizer step =
+ * stats -> prepare (once per group) -> update; group->step is the number of steps taken before. */
+#define F2G_SADAM_NCOEF 12
+#define F2G_SADAM_TSTATE 10
+#define F2G_SADAM_GSTATE 1028
+typedef struct {
+  float* p;
+  const float* g;
+  float* v;
+  float* m;
+  int64_t numel;
+  int32_t group;
+  int32_t is_scalar; /* numel == 1: no learned scale, lr * scalar_lr_scale, clamp to scalar_max */
+} f2g_sadam_tensor;
+typedef struct {
+  int32_t tensor; /* index into the tensor table */
+  int32_t count;  /* <= f2g_sadam_chunk_elems() */
+  int64_t offset; /* first element of the chunk inside the tensor */
+} f2g_sadam_chunk;
+typedef struct {
+  float lr, beta1, beta2, scalar_lr_scale, eps, param_min_rms, param_max_rms, scalar_max;
+  float clipping_scale;           /* <= 0: no clipping (optim.py:529) */
+  int32_t size_update_period;     /* <= 8 */
+  int32_t clipping_update_period; /* <= 1024 */
+  int32_t step;
+  int32_t first, count;           /* the group's tensors: table[first .. first+count) */
+} f2g_sadam_group;
+int32_t f2g_sadam_chunk_elems(void);
+/* tensors / chunks: DEVICE pointers to the tables; group: HOST pointer (passed by value) */
+int f2g_sadam_stats(const f2g_sadam_tensor* tensors, const f2g_sadam_chunk* chunks,
+                    int32_t nchunks, float* stats, int32_t ntensors, f2g_stream_t stream);
+int f2g_sadam_prepare(const f2g_sadam_tensor* tensors, const f2g_sadam_group* group,
+                      const float* stats, float* tstate, float* gstate, float* coef,
+                      f2g_stream_t stream);
+int f2g_sadam_update(const f2g_sadam_tensor* tensors, const f2g_sadam_chunk* chunks,
+                     int32_t nchunks, const float* coef, f2g_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,3 +116,28 @@ def test_full_width_init_and_infer(golden):
     with torch.no_grad():
         y = m.infer(T(g["mel"]), None, 1, True, noise=noise)
     assert float((y - T(g["audio_n1"])).pow(2).mean().sqrt()) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["p100", "p8", "noclip"])
+def test_scaled_adam_oracle_matches_reference_vectors(golden, case):
+    """oracle/scaled_adam_oracle.py against the reference optimizer's recorded trajectory
+    (tests/golden/scaled_adam.npz, written by oracle/make_golden_optim.py)."""
+    from scaled_adam_oracle import ScaledAdamOracle, eden2_lr
+    g = golden("scaled_adam")
+    n, steps = int(g["n_tensors"]), int(g["n_steps"])
+    clip, period, sup = g[f"{case}/kw"]
+    params = [T(g[f"init/{i}"]).clone() for i in range(n)]
+    opt = ScaledAdamOracle(params, lr=0.045, clipping_scale=(clip if clip > 0 else None),
+                           clipping_update_period=int(period), size_update_period=int(sup))
+    clipped = 0
+    for k in range(steps):
+        opt.g["lr"] = 0.045 if k == 0 else eden2_lr(0.045, k, 10, 8, 0.1)
+        assert k == 0 or abs(opt.g["lr"] - g[f"{case}/lrs"][k - 1]) < 1e-12
+        opt.step([T(g[f"grad/{k}/{i}"]) for i in range(n)])
+        clipped += opt.last_clip < 1.0
+        if f"{case}/step{k + 1}/0" in g:
+            for i in range(n):
+                want = T(g[f"{case}/step{k + 1}/{i}"])
+                err = float((params[i] - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+                assert err < 2e-6, (case, k + 1, i, err)
+    assert (clipped > 0) == (clip > 0)   # the trajectory exercises the clipping branch
