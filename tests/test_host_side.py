@@ -220,3 +220,70 @@ def test_gan_stepper_schedule_matches_reference():
     assert (w.disc_loss_mp_scale, w.disc_loss_mr_scale) == (1.0, 0.1)
     assert (w.gen_loss_mp_scale, w.gen_loss_mr_scale, w.feat_map_loss_mp_scale,
             w.feat_map_loss_mr_scale, w.mel_recon_loss_scale) == (1.0, 0.1, 1.0, 0.1, 45.0)
+
+
+def _small_net(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+
+
+def test_checkpoint_roundtrip_and_model_averaging(tmp_path):
+    """reference file layout, DDP prefix, running average, range average, plain
+    average of files; cross-checked against the reference's own functions where it is present."""
+    import copy
+    from flow2gan_amd import checkpoint as ck
+
+    cur = _small_net(1)
+    avg = copy.deepcopy(cur).to(torch.float64)
+    snaps, files = [], []
+    period = 2
+    for b in range(1, 9):                      # 8 "batches"; average every `period`
+        with torch.no_grad():
+            for p in cur.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        if b % period == 0:
+            ck.update_averaged_model({"average_period": period, "batch_idx_train": b}, cur, avg)
+            snaps.append({k: v.clone().double() for k, v in cur.state_dict().items()})
+            # the running average is the mean of the snapshots taken so far (plus the initial model
+            # at weight 0 after the first update: avg = cur * (period / b) + avg * (1 - period / b))
+            want = {k: sum(s[k] for s in snaps) / len(snaps) for k in snaps[0]}
+            for k, v in avg.state_dict().items():
+                assert torch.allclose(v, want[k], rtol=1e-6, atol=1e-7), (b, k)
+        if b in (4, 8):
+            f = tmp_path / f"checkpoint-{b}.pt"
+            ck.save_checkpoint(f, cur, model_avg=avg, params={"batch_idx_train": b, "epoch": 1})
+            files.append(f)
+    # file layout of the reference
+    raw = torch.load(files[0], weights_only=False)
+    assert {"model", "optimizer", "scheduler", "grad_scaler", "sampler", "model_avg",
+            "batch_idx_train", "epoch"} <= set(raw)
+    assert all(v.dtype == torch.float32 for v in raw["model_avg"].values())
+    # mean over (4, 8] from the two running averages == mean of snapshots 6 and 8
+    rng = ck.average_checkpoints_with_averaged_model(files[0], files[1])
+    for k, v in rng.items():
+        want = (snaps[2][k] + snaps[3][k]) / 2
+        assert torch.allclose(v.double(), want, rtol=1e-5, atol=1e-6), k
+    # plain mean of the "model" entries
+    plain = ck.average_checkpoints(files)
+    a, b_ = (torch.load(f, weights_only=False)["model"] for f in files)
+    for k in plain:
+        assert torch.allclose(plain[k], (a[k] + b_[k]) / 2)
+    # DDP prefix + full round trip incl. model_avg
+    raw["model"] = {"module." + k: v for k, v in raw["model"].items()}
+    torch.save(raw, tmp_path / "ddp.pt")
+    m2, avg2 = _small_net(2), _small_net(3)
+    rest = ck.load_checkpoint(tmp_path / "ddp.pt", m2, model_avg=avg2)
+    assert rest["batch_idx_train"] == 4 and "model" not in rest and "model_avg" not in rest
+    assert all(torch.equal(v, a[k]) for k, v in m2.state_dict().items())
+    # the reference's own implementation, when the build container has it
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_shims
+    if ref_shims.reference_available():
+        ref_shims.install()
+        from flow2gan import checkpoint as rck
+        ref = rck.average_checkpoints_with_averaged_model(str(files[0]), str(files[1]))
+        for k, v in rng.items():
+            assert torch.equal(v, ref[k]), k
+        ref_plain = rck.average_checkpoints([str(f) for f in files])
+        assert all(torch.equal(plain[k], ref_plain[k]) for k in plain)
