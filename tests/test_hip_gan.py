@@ -161,3 +161,77 @@ def test_concurrent_lanes_match_serial_launch_order(f2g, golden, monkeypatch):
         for key in ("gD", "gG"):
             for k, v in ref[key].items():
                 assert relerr(got[key][k], v) < 2e-4, (key, k, relerr(got[key][k], v))
+
+
+def test_full_width_gan_steps_vs_oracle_then_batch_64(f2g, monkeypatch):
+    """Full-width mel_24k_base GAN stage: D-step and G-step losses + selected gradients against the
+    CPU oracle at B=2, then B=64 (32 copies of that batch): every loss is a batch mean and every
+    sample is independent, so losses and gradients must not move."""
+    import flow2gan_oracle as O
+    from flow2gan_amd.models.config import get_generator_config
+    from flow2gan_amd.models.gan import GAN
+    monkeypatch.setattr(random, "random", lambda: 1.0)   # LimitParamValue off on both sides
+    torch.manual_seed(31)
+    og = O.build_generator("mel_24k_base")
+    og.branch_dropout = 0.0
+    ogan = O.GAN(og)
+    gen = f2g.MelAudioGenerator(**get_generator_config("mel_24k_base"))
+    gen.branch_dropout = 0.0
+    gan = GAN(gen)
+    missing = gan.load_state_dict(ogan.state_dict(), strict=False)
+    assert not [k for k in missing.missing_keys if "window" not in k and "fb" not in k], missing
+    gan = gan.to(DEV)
+    rg = torch.Generator().manual_seed(8)
+    Tn = 6000
+    audio = (0.1 * torch.randn(2, Tn, generator=rg)).clamp(-1, 1)
+    audio[1] *= 2.5
+    lens = torch.tensor([Tn, Tn])
+    noise = 0.1 * torch.randn(2, Tn, generator=rg)
+    mel = O.LogMelSpectrogram()(audio)
+    d_names = ["0.discriminators.0.convs.4.weight", "0.discriminators.3.conv_post.weight",
+               "1.discriminators.1.band_convs.2.1.weight", "1.discriminators.2.conv_post.bias"]
+    g_names = ["cond_encoder.in_proj.weight", "estimators.0.decoder.blocks.7.pwconv2.weight",
+               "estimators.2.decoder.out_proj.weight"]
+    # oracle
+    ogan.zero_grad()
+    od = ogan(mel, audio, lens, 1, True, noise=noise)
+    (od[0] + 0.1 * od[1]).backward()
+    od_g = {k: dict(ogan.discriminator.named_parameters())[k].grad.clone() for k in d_names}
+    ogan.zero_grad()
+    ogl = ogan(mel, audio, lens, 1, False, noise=noise)
+    sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ogl)).backward()
+    og_g = {k: dict(ogan.generator.named_parameters())[k].grad.clone() for k in g_names}
+
+    def run(rep):
+        a, m_, n_, ln = (audio.to(DEV).repeat(rep, 1), mel.to(DEV).repeat(rep, 1, 1),
+                         noise.to(DEV).repeat(rep, 1), lens.repeat(rep))
+        gan.zero_grad()
+        d = gan(m_, a, ln, 1, True, noise=n_)
+        (d[0] + 0.1 * d[1]).backward()
+        dg = {k: dict(gan.discriminator.named_parameters())[k].grad.detach().cpu().clone() for k in d_names}
+        gan.zero_grad()
+        ls = gan(m_, a, ln, 1, False, noise=n_)
+        sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ls)).backward()
+        gg = {k: dict(gan.generator.named_parameters())[k].grad.detach().cpu().clone() for k in g_names}
+        return [float(v.detach()) for v in d], [float(v.detach()) for v in ls], dg, gg
+
+    d2, l2, dg2, gg2 = run(1)
+    assert np.allclose(d2, [float(v) for v in od], rtol=1e-4, atol=1e-5), (d2, od)
+    assert np.allclose(l2, [float(v) for v in ogl], rtol=2e-4, atol=1e-5), (l2, ogl)
+    from flow2gan_amd import ops as _ops
+    gtol = 1e-1 if _ops.GEMM_PRECISION == 1 else 1e-2
+    def near(got, want, tol):   # exactly-zero references (cancelling hinge terms): absolute floor
+        err = float((got.detach().cpu().double() - want.detach().cpu().double()).abs().max())
+        return err < tol * float(want.abs().max()) + 1e-7
+
+    for k in d_names:
+        assert near(dg2[k], od_g[k], gtol), ("D", k, relerr(dg2[k], od_g[k]))
+    for k in g_names:
+        assert near(gg2[k], og_g[k], gtol), ("G", k, relerr(gg2[k], og_g[k]))
+    d64, l64, dg64, gg64 = run(32)   # B = 64
+    assert np.allclose(d64, d2, rtol=2e-5, atol=1e-6), (d64, d2)
+    assert np.allclose(l64, l2, rtol=5e-5, atol=1e-6), (l64, l2)
+    for k in d_names:
+        assert near(dg64[k], dg2[k], 5e-3), ("D64", k, relerr(dg64[k], dg2[k]))
+    for k in g_names:
+        assert near(gg64[k], gg2[k], 5e-3), ("G64", k, relerr(gg64[k], gg2[k]))

@@ -249,3 +249,72 @@ def test_harness_compute_loss_matches_oracle(f2g, golden):
             torch.randn = orig
         assert abs(float(loss) - want_total) < 1e-4 * abs(want_total), (train_disc, float(loss), want_total)
         assert info["samples"] == 2
+
+
+def test_full_size_batch_64_reproduces_reference_waveform(f2g, golden):
+    """BASELINE size (B=64, full-width mel_24k_base) through a size-independent property: items of a
+    batch are independent, so 64 copies of the reference's test mel must give 64 copies of the
+    reference's waveform -- exercised on the B=64 tile / split-K / launch-lane paths."""
+    g = golden("full_width")
+    torch.manual_seed(int(g["seed"]))
+    from flow2gan_amd.models.config import get_generator_config
+    m = f2g.MelAudioGenerator(**get_generator_config("mel_24k_base")).to(DEV).eval()
+    noise = 0.1 * torch.randn(1, 64 * 256, generator=torch.Generator().manual_seed(int(g["noise_seed"])))
+    mel = T(g["mel"]).to(DEV).expand(64, -1, -1).contiguous()
+    with torch.no_grad():
+        y = m.infer(mel, None, 4, True, noise=noise.to(DEV).expand(64, -1).contiguous())
+    want = T(g["audio_n4"])
+    assert y.shape == (64, want.shape[1])
+    worst = max(rms(y[b:b + 1], want) for b in (0, 17, 63))
+    assert worst < RMS_TOL, worst
+    assert float((y - y[:1]).abs().max()) < 1e-5   # rows agree with each other
+
+
+def test_full_width_stage1_loss_and_grads_vs_oracle_then_batch_64(f2g, monkeypatch):
+    """Full-width mel_24k_base stage-1 step: loss and gradients against the CPU oracle at B=2, then
+    the B=64 step on 32 copies of that batch must return the same loss and the same (mean) grads."""
+    import flow2gan_oracle as O
+    from flow2gan_amd.models.config import get_generator_config
+    monkeypatch.setattr(random, "random", lambda: 1.0)  # LimitParamValue off on both sides
+    torch.manual_seed(21)
+    o = O.build_generator("mel_24k_base")
+    o.branch_dropout = 0.0
+    m = f2g.MelAudioGenerator(**get_generator_config("mel_24k_base"))
+    m.load_state_dict(o.state_dict())
+    m.branch_dropout = 0.0
+    m = m.to(DEV).train()
+    gen = torch.Generator().manual_seed(5)
+    Tn = 24 * 256
+    audio = (0.1 * torch.randn(2, Tn, generator=gen)).clamp(-1, 1)
+    lens = torch.tensor([Tn, Tn - 700])
+    noise = 0.1 * torch.randn(2, Tn, generator=gen)
+    t = torch.rand(2, 1, generator=gen)
+    lm = O.LogMelSpectrogram()
+    mel = lm(audio)
+    o.train()
+    lo = o(mel, audio, lens, noise=noise, t=t)
+    lo.backward()
+    names = ["cond_encoder.in_proj.weight", "estimators.0.decoder.blocks.7.pwconv2.weight",
+             "estimators.1.decoder.in_norm.bias", "estimators.2.decoder.blocks.0.dwconv.weight",
+             "estimators.2.decoder.blocks.3.residual_scale.scale",
+             "estimators.0.decoder.time_mlp.0.weight", "estimators.1.decoder.out_proj.bias"]
+    po, pm = dict(o.named_parameters()), dict(m.named_parameters())
+
+    def run(rep):
+        m.zero_grad()
+        loss = m(mel.to(DEV).repeat(rep, 1, 1), audio.to(DEV).repeat(rep, 1), lens.repeat(rep),
+                 noise=noise.to(DEV).repeat(rep, 1), t=t.to(DEV).repeat(rep, 1))
+        loss.backward()
+        return float(loss), {k: pm[k].grad.detach().cpu().clone() for k in names}
+
+    l2, g2 = run(1)
+    assert abs(l2 - float(lo)) < 2e-5 * abs(float(lo)) + 1e-7, (l2, float(lo))
+    for k in names:
+        ref = po[k].grad
+        err = float((g2[k] - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        assert err < 3e-3, (k, err)
+    l64, g64 = run(32)   # B = 64
+    assert abs(l64 - l2) < 1e-5 * abs(l2) + 1e-7, (l64, l2)
+    for k in names:
+        err = float((g64[k] - g2[k]).abs().max()) / (float(g2[k].abs().max()) + 1e-12)
+        assert err < 2e-3, (k, err)
