@@ -392,7 +392,7 @@ struct Loader {
   // XOR-swizzled by (row>>2)&3): hi = bf16(v), lo = bf16(v - hi).  k-major tiles are transposed
   // here: a thread owns NLD consecutive k of 4 columns and packs them per column.
   __device__ __forceinline__ void store_split(const f2g_operand& S, const Stg& g, unsigned char* hi,
-                                              unsigned char* lo, int tid) const {
+                                              unsigned char* lo, int tid, bool with_lo) const {
     if (PARTIAL && !active) return;
     const int ch = tid % CH, rr = tid / CH;
     if (!KM) {
@@ -406,7 +406,8 @@ struct Loader {
         split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1);
         split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
         *reinterpret_cast<uint2*>(hi + off) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-        *reinterpret_cast<uint2*>(lo + off) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+        if (with_lo)
+          *reinterpret_cast<uint2*>(lo + off) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
       }
     } else {
       unsigned short hs[4][NLD], ls[4][NLD];
@@ -423,12 +424,13 @@ struct Loader {
         const int off = row * 64 + ((((k0 >> 3) ^ ((row >> 2) & 3))) << 4) + (k0 & 7) * 2;
         if (NLD == 1) {
           *reinterpret_cast<unsigned short*>(hi + off) = hs[c][0];
-          *reinterpret_cast<unsigned short*>(lo + off) = ls[c][0];
+          if (with_lo) *reinterpret_cast<unsigned short*>(lo + off) = ls[c][0];
         } else {
 #pragma unroll
           for (int q = 0; q < NLD; q += 2) {
             *reinterpret_cast<unsigned*>(hi + off + q * 2) = hs[c][q] | (hs[c][q + 1 < NLD ? q + 1 : q] << 16);
-            *reinterpret_cast<unsigned*>(lo + off + q * 2) = ls[c][q] | (ls[c][q + 1 < NLD ? q + 1 : q] << 16);
+            if (with_lo)
+              *reinterpret_cast<unsigned*>(lo + off + q * 2) = ls[c][q] | (ls[c][q + 1 < NLD ? q + 1 : q] << 16);
           }
         }
       }
@@ -661,6 +663,9 @@ void gemm_kernel_b3(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
   if (AKM) sa.init(d.A, 0, m0, kbeg, tid); else sa.init(d.A, m0, 0, kbeg, tid);
   if (BKM) sb.init(d.B, 0, n0, kbeg, tid); else sb.init(d.B, n0, 0, kbeg, tid);
 
+  // precision 1: hi/lo split, three MFMAs per product (fp32-class accuracy);
+  // precision 2: hi only, one MFMA per product = plain bf16 inputs with fp32 accumulation
+  const bool hl = d.precision == 1;
   auto compute = [&](const unsigned char* Ah) {
     const unsigned char* Al = Ah + ASZ;
     const unsigned char* Bh = Ah + 2 * ASZ;
@@ -676,18 +681,19 @@ void gemm_kernel_b3(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
         const int row = (wm * TM + mi) * 32 + li;
         const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
         ah[mi] = *reinterpret_cast<const bf16x8*>(Ah + off);
-        al[mi] = *reinterpret_cast<const bf16x8*>(Al + off);
+        if (hl) al[mi] = *reinterpret_cast<const bf16x8*>(Al + off);
       }
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         const int row = (wn * TN + ni) * 32 + li;
         const int off = row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
         bh[ni] = *reinterpret_cast<const bf16x8*>(Bh + off);
-        bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
+        if (hl) bl[ni] = *reinterpret_cast<const bf16x8*>(Bl + off);
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
+        if (term < 2 && !hl) continue;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -713,8 +719,8 @@ void gemm_kernel_b3(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     sa.load(d.A, kof(0), ga);
     sb.load(d.B, kof(0), gb);
     if (nt > 0) {
-      sa.store_split(d.A, ga, bufs[0], bufs[0] + ASZ, tid);
-      sb.store_split(d.B, gb, bufs[0] + 2 * ASZ, bufs[0] + 2 * ASZ + BSZ, tid);
+      sa.store_split(d.A, ga, bufs[0], bufs[0] + ASZ, tid, hl);
+      sb.store_split(d.B, gb, bufs[0] + 2 * ASZ, bufs[0] + 2 * ASZ + BSZ, tid, hl);
     }
   }
   __syncthreads();
@@ -729,8 +735,8 @@ void gemm_kernel_b3(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nt) {
       unsigned char* nb = bufs[cur ^ 1];
-      sa.store_split(d.A, ga, nb, nb + ASZ, tid);
-      sb.store_split(d.B, gb, nb + 2 * ASZ, nb + 2 * ASZ + BSZ, tid);
+      sa.store_split(d.A, ga, nb, nb + ASZ, tid, hl);
+      sb.store_split(d.B, gb, nb + 2 * ASZ, nb + 2 * ASZ + BSZ, tid, hl);
     }
     __syncthreads();
   }
@@ -778,7 +784,7 @@ int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
   // split-bf16 core: fast loader modes only; SL operands (small GEMMs) stay on exact fp32
   // (the reflect-padded STFT framing stays exact: small spectral bins are differences of large
   // terms, and the log-mel / spectral losses take their logarithm)
-  if (d.precision == 1 && !d.A.reflect && !d.B.reflect) {
+  if ((d.precision == 1 || d.precision == 2) && !d.A.reflect && !d.B.reflect) {
     if (AKM && M <= 32)
       return launch<1, 8, 1, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);  // 32 x 256
     if (N <= 32) return launch<8, 1, 1, 1, AKM, BKM, AMODE, BMODE, true>(d, M, N, K, split, st);

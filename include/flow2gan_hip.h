@@ -107,7 +107,9 @@ typedef struct {
   int32_t split_k;
   /* 0 = exact fp32 MFMA (bit-for-bit an fmaf chain); 1 = split-bf16: every fp32 operand is staged as
    * hi+lo bf16 and each product is hi*hi + hi*lo + lo*hi with fp32 accumulation (per-product
-   * relative error <= ~2^-16, i.e. ~100x tighter than plain bf16), ~3-5x the throughput. */
+   * relative error <= ~2^-16, i.e. ~100x tighter than plain bf16), ~3-5x the throughput;
+   * 2 = plain bf16 operands (hi part only, one MFMA per product), fp32 accumulation: the
+   * throughput mode of BASELINE config 2 (inference), not a parity mode. */
   int32_t precision;
   int32_t _pad3;
 } f2g_gemm_desc;

@@ -318,3 +318,36 @@ def test_full_width_stage1_loss_and_grads_vs_oracle_then_batch_64(f2g, monkeypat
     for k in names:
         err = float((g64[k] - g2[k]).abs().max()) / (float(g2[k].abs().max()) + 1e-12)
         assert err < 2e-3, (k, err)
+
+
+def test_plain_bf16_throughput_mode_stays_close_to_fp32(f2g, golden):
+    """precision 2 (bf16 operands, fp32 accumulate; BASELINE config 2's inference mode) is not a
+    parity mode; this pins its error level so that a broken kernel cannot hide behind it."""
+    from flow2gan_amd import ops
+    g = golden("full_width")
+    torch.manual_seed(int(g["seed"]))
+    from flow2gan_amd.models.config import get_generator_config
+    m = f2g.MelAudioGenerator(**get_generator_config("mel_24k_base")).to(DEV).eval()
+    noise = 0.1 * torch.randn(1, 64 * 256, generator=torch.Generator().manual_seed(int(g["noise_seed"])))
+    was = ops.GEMM_PRECISION
+    try:
+        ops.set_gemm_precision("bf16")
+        with torch.no_grad():
+            y = m.infer(T(g["mel"]).to(DEV), None, 4, True, noise=noise.to(DEV))
+    finally:
+        ops.GEMM_PRECISION = was
+    want = T(g["audio_n4"])
+    err = rms(y, want)
+    sig = float(want.double().pow(2).mean().sqrt())
+    assert 1e-6 < err < 0.05 * sig, (err, sig)   # bf16-level, far from broken
+    A = torch.randn(700, 512, generator=torch.Generator().manual_seed(1))
+    W = torch.randn(300, 512, generator=torch.Generator().manual_seed(2)) * 0.05
+    out = torch.empty(700, 300, device=DEV)
+    try:
+        ops.set_gemm_precision("bf16")
+        ops.gemm(ops.mat(A.to(DEV)), ops.mat(W.to(DEV)), out)
+    finally:
+        ops.GEMM_PRECISION = was
+    ref = A.double() @ W.double().t()
+    rel = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert 1e-5 < rel < 2e-2, rel
