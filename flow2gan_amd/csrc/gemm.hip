@@ -6,8 +6,9 @@
 // weight gradient.  Operands are described by f2g_operand (include/flow2gan_hip.h): a
 // channels-last tensor viewed as rows = pixels, cols = contiguous window (never materialised).
 //
-// Tiling (wave64): block = 4 waves; each wave owns TM x TN tiles of 32x32, accumulated in
-// f32x16 registers by mfma_f32_32x32x2f32.  The 2 k-slots of that instruction are fed from the
+// Tiling (wave64): block = WAVES_M x WAVES_N waves (2, 4 or 8, chosen per operand kind in
+// dispatch_tile); each wave owns TM x TN tiles of 32x32, accumulated in f32x16 registers by
+// mfma_f32_32x32x2f32.  The 2 k-slots of that instruction are fed from the
 // two lane halves: lanes 0-31 walk k in [0,16) of the BK=32 slab, lanes 32-63 walk [16,32), so a
 // lane's operands for 4 consecutive MFMAs are one ds_read_b128 (row-major LDS tile) or four
 // conflict-free ds_read_b32 (k-major tile).  Global->register->LDS double buffering, one
@@ -52,61 +53,6 @@ __device__ __forceinline__ RowCtx decode_row(const f2g_operand& S, int r) {
   rc.l1b = p1 * S.step1 - S.pad1;
   rc.e0 = (p0 * S.step0 - S.pad0) * S.unit;
   return rc;
-}
-
-__device__ __forceinline__ float fix_elem(const f2g_operand& S, float v, long long off, int c) {
-  if (S.lrelu_src) v *= (S.lrelu_src[off] > 0.f ? 1.f : S.lrelu_slope);
-  if (S.alpha) { float al = S.alpha[c]; v = v > 0.f ? v : al * v; }
-  return v;
-}
-
-__device__ __forceinline__ float load_elem(const f2g_operand& S, const RowCtx& rc, int c) {
-  if (c >= S.cols) return 0.f;
-  int seg = 0, o = c;
-  if (S.seglen < S.cols) { seg = c / S.seglen; o = c - seg * S.seglen; }
-  int l1 = rc.l1b + seg;
-  if ((unsigned)l1 >= (unsigned)S.L1) return 0.f;
-  int e = rc.e0 + o;
-  if (S.reflect) {
-    if (e < 0) e = -e;
-    else if (e >= S.L0u) e = 2 * (S.L0u - 1) - e;
-    if ((unsigned)e >= (unsigned)S.L0u) return 0.f;
-  } else if ((unsigned)e >= (unsigned)S.L0u) {
-    return 0.f;
-  }
-  long long off = rc.base + (long long)l1 * S.line_stride + e;
-  return fix_elem(S, S.base[off], off, c);
-}
-
-// 4 consecutive window columns c..c+3 of a decoded row; (seg, o) = decode of column c.
-__device__ __forceinline__ float4 load_chunk_generic(const f2g_operand& S, const RowCtx& rc, int c,
-                                                     int seg, int o) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c >= S.cols) return v;
-  const int seglen = S.seglen < S.cols ? S.seglen : S.cols;
-  const int l1 = rc.l1b + seg;
-  const int e = rc.e0 + o;
-  if (o + 3 < seglen && (unsigned)l1 < (unsigned)S.L1 && e >= 0 && e + 3 < S.L0u) {
-    const long long off = rc.base + (long long)l1 * S.line_stride + e;
-    const float* p = S.base + off;
-    if ((((uintptr_t)p) & 15) == 0) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
-    }
-    if (S.lrelu_src || S.alpha) {
-      v.x = fix_elem(S, v.x, off, c);
-      v.y = fix_elem(S, v.y, off + 1, c + 1);
-      v.z = fix_elem(S, v.z, off + 2, c + 2);
-      v.w = fix_elem(S, v.w, off + 3, c + 3);
-    }
-    return v;
-  }
-  v.x = load_elem(S, rc, c);
-  v.y = load_elem(S, rc, c + 1);
-  v.z = load_elem(S, rc, c + 2);
-  v.w = load_elem(S, rc, c + 3);
-  return v;
 }
 
 __device__ __forceinline__ float prelu1(float v, float a) { return v > 0.f ? v : a * v; }

@@ -94,9 +94,24 @@ __device__ __forceinline__ float4 chunk(const f2g_operand& S, const RowCtx& rc, 
                      elem(S, rc, true, c + 2, mg), elem(S, rc, true, c + 3, mg));
 }
 
+// same with the column decode (seg, o) of c done by the caller: it does not depend on the row, so
+// the kernels below compute it once per thread instead of once per row
+__device__ __forceinline__ float4 chunk_at(const f2g_operand& S, const RowCtx& rc, int c, int sg,
+                                           int oo, const Mg& mg) {
+  const int l1 = rc.l1b + sg, e = rc.e0 + oo;
+  if (!S.alpha && !S.lrelu_src && c + 3 < S.cols && oo + 3 < mg.seglen &&
+      (unsigned)l1 < (unsigned)S.L1 && e >= 0 && e + 3 < S.L0u) {
+    const float* p = S.base + rc.base + (long long)l1 * S.line_stride + e;
+    if ((((uintptr_t)p) & 15) == 0) return *reinterpret_cast<const float4*>(p);
+  }
+  return make_float4(elem(S, rc, true, c, mg), elem(S, rc, true, c + 1, mg),
+                     elem(S, rc, true, c + 2, mg), elem(S, rc, true, c + 3, mg));
+}
+
 // forms 0 / 1 with N <= 4: the (K x N) weight panel is staged once per block in LDS as [n][k];
 // each wave then walks ROWS_PER_WAVE rows, lanes striding K in float4 chunks, wave-shuffle reduce.
-constexpr int ROWS_PER_WAVE = 16;
+constexpr int ROWS_PER_WAVE = 16;  // (4 was measured: +10 % for the 1-column forward, -10 % for the
+                                   // 2-column data gradient whose strided weight staging it repeats)
 
 template <bool F1>
 __global__ __launch_bounds__(256) void narrow_rows_kernel(const f2g_gemm_desc d, int M, int N,
@@ -168,6 +183,61 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const f2g_gemm_desc d
   }
 }
 
+// same, N % 4 == 0 and N <= 4096: a thread owns up to 4 float4 chunks of the window (decoded once),
+// the row decode is block-uniform, every row costs each thread <= 4 independent dwordx4 loads
+template <int MM>  // gradient rows held in registers: 1 (conv_post: Cout = 1) or 4
+__global__ __launch_bounds__(256) void narrow_wgrad4_kernel(const f2g_gemm_desc d, int M, int N,
+                                                            int R, int rows_per) {
+  const int r0 = blockIdx.x * rows_per;
+  int r1 = r0 + rows_per;
+  if (r1 > R) r1 = R;
+  const long long lda = d.A.seq_stride;
+  const Mg mg = magics(d.B);
+  int sgj[4], ooj[4];
+  bool cj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = (threadIdx.x + 256 * j) * 4;
+    cj[j] = c < N;
+    sgj[j] = fast_div(cj[j] ? c : 0, mg.seglen, mg.seg);
+    ooj[j] = (cj[j] ? c : 0) - sgj[j] * mg.seglen;
+  }
+  float acc[MM][4][4];
+#pragma unroll
+  for (int m = 0; m < MM; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[m][j][e] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const RowCtx rb = decode_row(d.B, r, mg);
+    float a[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) a[m] = m < M ? d.A.base[(long long)r * lda + m] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (cj[j]) {
+        const float4 x = chunk_at(d.B, rb, (threadIdx.x + 256 * j) * 4, sgj[j], ooj[j], mg);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+          acc[m][j][0] += a[m] * x.x; acc[m][j][1] += a[m] * x.y;
+          acc[m][j][2] += a[m] * x.z; acc[m][j][3] += a[m] * x.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!cj[j]) continue;
+    const int c = (threadIdx.x + 256 * j) * 4;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (m < M) atomicAdd(d.E.C + out_offset(d.E, m, c + e), acc[m][j][e]);
+  }
+}
+
 bool plainish(const f2g_operand& S) {
   return S.P0 == 1 && S.P1 == 1 && S.seglen >= S.cols && S.L1 == 1 && S.pad0 == 0 &&
          S.pad1 == 0 && S.L0u >= S.cols && !S.reflect && !S.lrelu_src && !S.alpha;
@@ -198,7 +268,12 @@ int f2g_gemm_narrow(const f2g_gemm_desc& d, hipStream_t st) {
     if (rows_per < 64) rows_per = 64;
     if (rows_per > 512) rows_per = 512;
     dim3 grid((R + rows_per - 1) / rows_per);
-    hipLaunchKernelGGL(narrow_wgrad_kernel, grid, dim3(256), 0, st, d, M, N, R, rows_per);
+    if ((N & 3) == 0 && N <= 4096 && M == 1)
+      hipLaunchKernelGGL(narrow_wgrad4_kernel<1>, grid, dim3(256), 0, st, d, M, N, R, rows_per);
+    else if ((N & 3) == 0 && N <= 4096)
+      hipLaunchKernelGGL(narrow_wgrad4_kernel<4>, grid, dim3(256), 0, st, d, M, N, R, rows_per);
+    else
+      hipLaunchKernelGGL(narrow_wgrad_kernel, grid, dim3(256), 0, st, d, M, N, R, rows_per);
     int rc = f2g_check_launch();
     return rc ? rc : 1;
   }
