@@ -129,6 +129,8 @@ _SIGS = {
     "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
     "f2g_fill": [_P, _F, _L],
     "f2g_log_clip": [_P, _L, _F],
+    "f2g_wave_stats": [_P, _L, _L, _I, _I, _P, _P],
+    "f2g_wave_gain": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P],
     "f2g_sadam_stats": [_P, _P, _I, _P, _I],
     "f2g_sadam_prepare": [_P, C.POINTER(SadamGroup), _P, _P, _P, _P],
     "f2g_sadam_update": [_P, _P, _I, _P],

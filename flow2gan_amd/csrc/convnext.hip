@@ -775,7 +775,10 @@ int launch_dwnorm(const f2g_dwnorm_bwd_desc& d, hipStream_t st) {
   const f2g_dwnorm_fwd_desc& f = d.f;
   if (f.B <= 0 || f.F <= 0) return F2G_OK;
   // frames per wave: a multiple of the condition upsampling factor (4 | up)
-  const bool four = (BWD && f.cproj && f.up == 4) || (!BWD && (f.C % 4) == 0);
+  // backward: 4 frames per wave wherever the registers allow it (<= 512 channels: 2 chunks per
+  // lane); 768 channels would spill, so they keep 2 (the workspace query sizes for 2, the larger)
+  const bool four = (BWD && ((f.cproj && f.up == 4) || (f.C <= 512 && (f.C % 4) == 0))) ||
+                    (!BWD && (f.C % 4) == 0);
   const int FW = four ? 4 : 2;
   const int groups = (f.F + FW - 1) / FW;
   const int nxb = (groups + 3) / 4;

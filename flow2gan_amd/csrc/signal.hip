@@ -271,3 +271,86 @@ extern "C" int f2g_peaknorm_bwd(float* gx, const float* gy, const float* x, cons
                      stats, rows, T);
   return f2g_check_launch();
 }
+
+// ---- on-device data front end (reference flow2gan/dataset.py:122-175) -------------
+// x: (B, C, T) crops (item_stride, ch_stride in floats), lens[b] valid samples.
+//   wave_stats: stats[b] = { sqrt(mean over channels and time of x^2)  (the silence test of
+//               dataset.py:130-131 runs on the loaded multi-channel array),
+//               max_t |mean_c x[b,c,t]|  (peak of the mono mix, for sox `norm`) }
+//   wave_gain : out[b,t] = mean_c x[b,c,t] * target_peak[b] / peak[b]  (t < lens[b]; 0 beyond:
+//               pad_sequence of dataset.py:43); target_peak[b] <= 0 leaves the level untouched
+namespace {
+
+__global__ __launch_bounds__(256) void wave_stats_kernel(const float* x, long long item_stride,
+                                                         long long ch_stride, int C,
+                                                         const int* lens, float* stats) {
+  __shared__ float sh[8];
+  const int b = blockIdx.x;
+  const int n = lens[b];
+  const float* xb = x + (long long)b * item_stride;
+  float sq = 0.f, pk = 0.f;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    float m = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = xb[(long long)c * ch_stride + t];
+      sq += v * v;
+      m += v;
+    }
+    pk = fmaxf(pk, fabsf(m / (float)C));
+  }
+  sq = wave_sum(sq);
+  pk = wave_max(pk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sh[wave] = sq; sh[4 + wave] = pk; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = sh[0] + sh[1] + sh[2] + sh[3];
+    const float p = fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7]));
+    stats[2 * b] = n > 0 ? sqrtf(s / ((float)n * (float)C)) : 0.f;
+    stats[2 * b + 1] = p;
+  }
+}
+
+__global__ __launch_bounds__(256) void wave_gain_kernel(float* out, long long ldo, const float* x,
+                                                        long long item_stride, long long ch_stride,
+                                                        int C, int T, const int* lens,
+                                                        const float* stats,
+                                                        const float* target_peak) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float v = 0.f;
+  if (t < lens[b]) {
+    const float* xb = x + (long long)b * item_stride;
+    float m = 0.f;
+    for (int c = 0; c < C; ++c) m += xb[(long long)c * ch_stride + t];
+    m /= (float)C;
+    const float tp = target_peak ? target_peak[b] : 0.f;
+    const float pk = stats[2 * b + 1];
+    v = (tp > 0.f && pk > 0.f) ? m * (tp / pk) : m;
+  }
+  out[(long long)b * ldo + t] = v;
+}
+
+}  // namespace
+
+extern "C" int f2g_wave_stats(const float* x, int64_t item_stride, int64_t ch_stride, int32_t B,
+                              int32_t C, const int32_t* lens, float* stats, f2g_stream_t stream) {
+  if (!x || !lens || !stats || C < 1) return F2G_EINVAL;
+  if (B <= 0) return F2G_OK;
+  hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)item_stride, (long long)ch_stride, C, lens, stats);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_wave_gain(float* out, int64_t ldo, const float* x, int64_t item_stride,
+                             int64_t ch_stride, int32_t B, int32_t C, int32_t T,
+                             const int32_t* lens, const float* stats, const float* target_peak,
+                             f2g_stream_t stream) {
+  if (!out || !x || !lens || !stats || C < 1 || T < 1) return F2G_EINVAL;
+  if (B <= 0) return F2G_OK;
+  hipLaunchKernelGGL(wave_gain_kernel, dim3((T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream,
+                     out, (long long)ldo, x, (long long)item_stride, (long long)ch_stride, C, T, lens,
+                     stats, target_peak);
+  return f2g_check_launch();
+}

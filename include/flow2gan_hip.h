@@ -314,6 +314,21 @@ int f2g_log_clip(float* x, int64_t n, float clip, f2g_stream_t stream);
 /* fill */
 int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
 
+/* ---- on-device data front end (dataset.py:122-175).  x: (B, C, T) crops with
+ * explicit item / channel strides (floats); lens[b] = valid samples of item b.
+ *   f2g_wave_stats: stats[2b] = sqrt(mean_{c,t} x^2) (silence test, dataset.py:130-131),
+ *                   stats[2b+1] = max_t |mean_c x| (peak of the mono mix);
+ *   f2g_wave_gain : out[b,t] = mean_c x[b,c,t] * target_peak[b] / peak[b] for t < lens[b], 0 beyond
+ *                   (mono mix :160-162, sox `norm <dB>` :164-168 with target_peak = 10^(dB/20),
+ *                   zero padding of pad_sequence :43); target_peak NULL or <= 0: level untouched.
+ * Resampling (dataset.py:170-173) is an f2g_gemm over a windowed operand with the polyphase sinc
+ * kernel as weights (flow2gan_amd/frontend.py:resample). */
+int f2g_wave_stats(const float* x, int64_t item_stride, int64_t ch_stride, int32_t B, int32_t C,
+                   const int32_t* lens, float* stats, f2g_stream_t stream);
+int f2g_wave_gain(float* out, int64_t ldo, const float* x, int64_t item_stride, int64_t ch_stride,
+                  int32_t B, int32_t C, int32_t T, const int32_t* lens, const float* stats,
+                  const float* target_peak, f2g_stream_t stream);
+
 /* ---- ScaledAdam (reference optim.py:125-255 basic/scaling/momentum steps,
  * :451-507 step, :509-619 clipping) as multi-tensor launches over device-resident tables.
  * The caller owns every buffer: params p, grads g (NULL = zeros, optim.py:111-113), second moment
