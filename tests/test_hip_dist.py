@@ -1,0 +1,88 @@
+"""Data-parallel semantics of the real HIP path with two ranks: both processes drive the same MI355X
+(the test box has one GPU; RCCL refuses two ranks on one device, so the exchange goes through gloo,
+which accepts device tensors) through GanStepper + the overlapped GradReducer.  Every rank must end
+up with the mean over ranks of the per-rank gradients that a single process computes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(sampling_rate=24000, n_mels=100, mel_n_fft=1024, mel_hop_length=256,
+            n_ffts=(512, 256, 128), hop_lengths=(256, 128, 64), channels=(48, 32, 24),
+            time_embed_channels=32, hidden_factor=3, num_layers=(2, 2, 2),
+            cond_enc_channels=32, cond_enc_num_layers=1)
+
+
+def _build():
+    import flow2gan_amd
+    from flow2gan_amd.models.gan import GAN
+    torch.manual_seed(1234)                       # same weights on every rank
+    gen = flow2gan_amd.MelAudioGenerator(**TINY)
+    gen.branch_dropout = 0.0
+    gan = GAN(gen).to("cuda")
+    logmel = flow2gan_amd.LogMelSpectrogram(24000, 1024, 256, 100).to("cuda")
+    return gan, logmel
+
+
+def _batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return (0.1 * torch.randn(2, 6000, generator=g)).clamp(-1, 1).to("cuda"), torch.tensor([6000, 6000])
+
+
+def _steps(gan, logmel, rank, reducer):
+    """One D-step and one G-step (fixed generator noise); returns the gradients of both."""
+    import random
+    from flow2gan_amd.harness import GanStepper
+    random.seed(0)
+    audio, lens = _batch(rank)
+    st = GanStepper(gan, logmel, n_timesteps=1, gen_start_batch_idx=1, reducer=reducer)
+    out = {}
+    for name in ("D", "G"):
+        torch.manual_seed(7)                      # the step's own randn draw for the ODE noise
+        gan.zero_grad()
+        info = st.step(audio, lens)
+        assert info["train_disc"] == (name == "D")
+        sub = gan.discriminator if name == "D" else gan.generator
+        out[name] = {k: p.grad.detach().cpu().clone() for k, p in sub.named_parameters()}
+    return out
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    from flow2gan_amd import dist as fdist
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gan, logmel = _build()
+    red = fdist.GradReducer(bucket_mb=8.0)
+    got = _steps(gan, logmel, rank, red)
+    assert len(red._plans) == 2 and max(len(p.buckets) for p in red._plans.values()) >= 2
+    torch.save(got, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_average_the_single_rank_gradients(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import torch.multiprocessing as mp
+    from flow2gan_amd import dist as fdist
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # what each rank computes on its own (no exchange), in this process
+    singles = []
+    for r in range(2):
+        gan, logmel = _build()
+        singles.append(_steps(gan, logmel, r, fdist.GradReducer()))
+    for r in range(2):
+        got = torch.load(tmp_path / f"rank{r}.pt")
+        for name in ("D", "G"):
+            worst = 0.0
+            for k, v in got[name].items():
+                want = 0.5 * (singles[0][name][k] + singles[1][name][k])
+                err = float((v - want).abs().max()) / (float(want.abs().max()) + 1e-9)
+                worst = max(worst, err)
+            assert worst < 2e-3, (r, name, worst)   # atomics reorder sums between runs
