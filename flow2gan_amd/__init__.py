@@ -18,22 +18,27 @@ from .models.modules import LogMelSpectrogram
 __all__ = ["get_model", "MelAudioGenerator", "LogMelSpectrogram", "load_checkpoint"]
 
 
-def get_model(
-    model_name: str = "mel_24k_base",
-    hf_model_name: Optional[str] = "libritts-mel-4-step",
-    checkpoint: Optional[str] = None,
-) -> Tuple[MelAudioGenerator, AttributeDict]:
-    assert (checkpoint is not None) or (hf_model_name is not None), \
-        "Either checkpoint or hf_model_name must be provided."
-    model_cfg = get_generator_config(model_name)
-    model = MelAudioGenerator(**model_cfg)
+def _resolve_weights(hf_model_name: Optional[str], checkpoint: Optional[str]) -> str:
+    """A local file wins; otherwise the named checkpoint of the reference's hub repository
+    (network needed; same names and the same failure modes as the reference)."""
     if checkpoint is not None:
         print(f"Using local checkpoint: {checkpoint}")
-    else:
-        print("Using checkpoint from HF hub")
-        assert hf_model_name in HF_MODEL_NAMES, \
-            "Supported names are " + ", ".join(HF_MODEL_NAMES.keys())
-        from huggingface_hub import hf_hub_download
-        checkpoint = hf_hub_download(HF_REPO, filename=hf_model_name + ".pt")
-    load_checkpoint(checkpoint, model)
-    return model, model_cfg
+        return checkpoint
+    print("Using checkpoint from HF hub")
+    if hf_model_name not in HF_MODEL_NAMES:
+        raise AssertionError("Supported names are " + ", ".join(HF_MODEL_NAMES))
+    from huggingface_hub import hf_hub_download  # imported late: not needed for local files
+    return hf_hub_download(HF_REPO, filename=f"{hf_model_name}.pt")
+
+
+def get_model(model_name: str = "mel_24k_base",
+              hf_model_name: Optional[str] = "libritts-mel-4-step",
+              checkpoint: Optional[str] = None) -> Tuple[MelAudioGenerator, AttributeDict]:
+    """Same contract as the reference's `flow2gan.get_model`: build the named generator, load a
+    local `.pt` or a hub checkpoint into it, return (model, its config)."""
+    if checkpoint is None and hf_model_name is None:
+        raise AssertionError("Either checkpoint or hf_model_name must be provided.")
+    cfg = get_generator_config(model_name)
+    generator = MelAudioGenerator(**cfg)
+    load_checkpoint(_resolve_weights(hf_model_name, checkpoint), generator)
+    return generator, cfg
