@@ -1,0 +1,145 @@
+// Direct LDS-tiled convolution for the 32 -> 32 channel band layers of the multi-resolution STFT
+// discriminator (reference discriminators.py:171-181: Conv2d(32, 32, (3, 9), stride (1, 2),
+// padding (1, 4)) x 3 per band, 15 bands per step and pass).
+//
+// As an implicit GEMM these layers have N = 32 output columns: 16 FLOP per byte of im2col operand,
+// and the operand (27 overlapping taps) is re-gathered from L2 for every tap -- measured 70-80
+// TFLOP/s, L2-bandwidth bound.  Here a block stages the input patch of its 8 x 16 output pixels ONCE
+// in LDS (10 rows x 39 columns x 32 channels, split into even / odd columns so that a wave's
+// 16 consecutive output columns read a stride-1, bank-conflict-free run for every tap), streams the
+// 27 (32 x 32) weight tiles through a double buffer, and feeds the fp32 MFMAs straight from the
+// patch at tap-shifted addresses: global traffic per output tile drops from 27 x 16 KB to 50 KB.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8, TW = 16;          // output tile (rows x columns) = 128 pixels = 4 x 32 (x 2 tap halves = 8 waves)
+constexpr int C = 32;                   // channels in = out
+constexpr int PITCH = 36;               // floats per staged pixel (conflict-free ds_read_b128)
+constexpr int KH = 3, KW = 9;
+constexpr int IW = TW + (KW - 1) / 2;   // staged columns per parity: 16 + 4 = 20
+constexpr int IH = TH + KH - 1;         // staged rows: 10
+constexpr int SUB = IH * IW * PITCH;    // floats of one parity sub-tile
+constexpr int WB = C * PITCH;           // floats of one weight tile
+constexpr int TG = 2;                   // taps per barrier (weights double-buffered per group)
+
+__device__ __attribute__((aligned(16))) float c32_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+__global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* At = sm;                 // [2 parities][IH][IW][PITCH]
+  float* Bt = sm + 2 * SUB;       // [2 buffers][TG taps][C][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int tiles_w = (d.Wout + TW - 1) / TW;
+  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+  const int s = blockIdx.y;
+  const int h0 = th * TH, w0 = tw * TW;
+  const float* xs = d.x + (long long)s * d.x_seq;
+
+  // ---- stage the input patch: rows h0-1 .. h0+8, columns 2*w0-4 .. 2*w0+34 (39), zero outside
+  const int x0 = 2 * w0 - (KW - 1) / 2;
+  for (int i = tid; i < IH * (2 * IW - 1) * (C / 4); i += 512) {
+    const int c4 = i & 7;
+    const int px = i >> 3;
+    const int r = px / (2 * IW - 1), xr = px - r * (2 * IW - 1);
+    const int h = h0 - 1 + r, x = x0 + xr;
+    const bool ok = h >= 0 && h < d.H && x >= 0 && x < d.Win;
+    const float* p = ok ? xs + (long long)h * d.x_line + (long long)x * C + c4 * 4 : c32_zero;
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    *reinterpret_cast<float4*>(At + (xr & 1) * SUB + (r * IW + (xr >> 1)) * PITCH + c4 * 4) = v;
+  }
+  // weights: thread = (tap of the group, co, 4 input channels); group 0 -> buffer 0
+  const int wu = tid >> 8, wco = (tid & 255) >> 3, wc4 = tid & 7;
+  const float* wrow = d.w + (long long)wco * (KH * KW * C) + wc4 * 4;
+  *reinterpret_cast<float4*>(Bt + wu * WB + wco * PITCH + wc4 * 4) =
+      *reinterpret_cast<const float4*>(wrow + wu * C);
+  __syncthreads();
+
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
+  // 8 waves: waves 0-3 take the first tap of every group, waves 4-7 the second; pixel group = wave & 3
+  const int pg = wave & 3, myu = wave >> 2;
+  const int p = pg * 32 + li;             // this lane's output pixel inside the tile
+  const int ph = p >> 4, pw = p & 15;
+  const int kk0 = hh * 16;                // lane halves split the 32 input channels
+
+  // taps are processed in groups of TG per barrier (weights double-buffered per group); two
+  // accumulators alternate so that consecutive MFMAs never wait for each other
+  constexpr int NG = (KH * KW + TG - 1) / TG;
+  for (int gidx = 0; gidx < NG; ++gidx) {
+    const int cur = gidx & 1;
+    int tn = (gidx + 1) * TG + wu;
+    tn = tn < KH * KW ? tn : KH * KW - 1;
+    const float4 wn = *reinterpret_cast<const float4*>(wrow + tn * C);  // next group, in flight
+    {
+      const int u = myu;
+      const int t = gidx * TG + u;
+      if (t < KH * KW) {
+        const int dh = t / KW, j = t - dh * KW;
+        const float* Ab = At + (j & 1) * SUB + ((ph + dh) * IW + pw + (j >> 1)) * PITCH + kk0;
+        const float* Bb = Bt + (cur * TG + u) * WB + li * PITCH + kk0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const float4 a = *reinterpret_cast<const float4*>(Ab + s4 * 4);
+          const float4 b = *reinterpret_cast<const float4*>(Bb + s4 * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc2, 0, 0, 0);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(Bt + ((cur ^ 1) * TG + wu) * WB + wco * PITCH + wc4 * 4) = wn;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
+  // combine the two tap halves: waves 4-7 hand their partial tile over through LDS (the patch is dead)
+  float* red = At;  // [4 pixel groups][16][64 lanes]
+  if (myu == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(pg * 16 + e) * 64 + lane] = acc[e];
+  }
+  __syncthreads();
+  if (myu == 1) return;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] += red[(pg * 16 + e) * 64 + lane];
+
+  // ---- epilogue: bias + leaky ReLU; accumulator element e sits on pixel row (e&3)+8*(e>>2)+4*hh
+  const float bias = d.bias ? d.bias[li] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int q = pg * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+    const int oh = h0 + (q >> 4), ow = w0 + (q & 15);
+    if (oh < d.H && ow < d.Wout) {
+      float v = acc[e] + bias;
+      if (d.lrelu_slope != 0.f) v = v > 0.f ? v : d.lrelu_slope * v;
+      d.y[(long long)s * d.y_seq + (long long)oh * d.y_line + (long long)ow * C + li] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
+  if (!d || !d->x || !d->w || !d->y) return F2G_EINVAL;
+  if (d->S <= 0 || d->H <= 0 || d->Wout <= 0) return F2G_OK;
+  if (d->Wout != (d->Win + 8 - 9) / 2 + 1) return F2G_EINVAL;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
+  const size_t smem = (size_t)(2 * SUB + 2 * TG * WB) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int tiles = ((d->H + TH - 1) / TH) * ((d->Wout + TW - 1) / TW);
+  hipLaunchKernelGGL(conv32_s2_fwd_kernel, dim3(tiles, d->S), dim3(512), smem, (hipStream_t)stream,
+                     *d);
+  return f2g_check_launch();
+}

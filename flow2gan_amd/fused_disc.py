@@ -261,6 +261,12 @@ def mrd_params(mrd) -> list:
 N_MRD_PARAMS = 5 * 5 * 2 + 2
 
 
+import os as _os
+
+# F2G_DIRECT_CONV=0 routes the band layers through the implicit GEMM again (A/B switch)
+DIRECT_CONV32 = _os.environ.get("F2G_DIRECT_CONV", "1") != "0"
+
+
 def _band_edges(n_fft: int):
     nb = n_fft // 2 + 1
     return [(int(lo * nb), int(hi * nb)) for lo, hi in MRD_BANDS]
@@ -305,7 +311,11 @@ def _mrd_forward_one(x2, win: int, prm: list):
                           seq_stride=Ft * ldp, offset=lo * 2)
             else:
                 A = win2d(x, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2)
-            if l < 4:
+            if l in (1, 2, 3) and DIRECT_CONV32:
+                # 32 -> 32 channels, (3, 9) taps, stride (1, 2): direct LDS-tiled kernel (conv32.hip)
+                y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
+                ops.conv32_s2_fwd(x, S, Ft, Win, Wout, wp, b, SLOPE, y)
+            elif l < 4:
                 y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
                 gemm(A, mat(wp), y, bias=b, lrelu=SLOPE)
             else:

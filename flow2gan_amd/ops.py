@@ -145,6 +145,22 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     return out
 
 
+def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope: float, y):
+    """Conv2d(32, 32, (3, 9), stride (1, 2), padding (1, 4)) + bias + leaky ReLU on channels-last
+    images x (S*H*Win, 32) -> y (S*H*Wout, 32); w_packed = (32, 27*32) as pack_conv_weight gives."""
+    d = L.Conv32Desc()
+    d.x, d.x_seq, d.x_line = ptr(x), H * Win * 32, Win * 32
+    d.S, d.H, d.Win, d.Wout = S, H, Win, Wout
+    d.w, d.bias, d.lrelu_slope = ptr(w_packed), ptr(bias), slope
+    d.y, d.y_seq, d.y_line = ptr(y), H * Wout * 32, Wout * 32
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_conv32_s2_fwd", C.byref(d)),
+                        2.0 * S * H * Wout * 32 * 27 * 32, (0, S * H * Wout, 32, 27 * 32))
+    else:
+        call("f2g_conv32_s2_fwd", C.byref(d))
+    return y
+
+
 class GemmTimer:
     """bench.py instrumentation: HIP events around every f2g_gemm launch on the launch stream and
     the launch's algorithmic FLOPs (2 * M * N * K of the implicit GEMM it represents)."""
@@ -169,6 +185,16 @@ class GemmTimer:
         nn = Bm.rows if form == 0 else Bm.cols
         mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
         self.shapes.append((form, mm, nn, kk))
+
+    def time(self, fn, flops: float, shape):
+        """Any other launch that stands in for an f2g_gemm (the direct band-conv kernel)."""
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((s, e, flops))
+        self.shapes.append(shape)
 
     def report(self, top: int = 25) -> str:
         """Per-shape table (form, M, N, K): calls, total ms, TFLOP/s -- after a synchronise."""

@@ -314,6 +314,23 @@ int f2g_log_clip(float* x, int64_t n, float clip, f2g_stream_t stream);
 /* fill */
 int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
 
+/* ---- direct LDS-tiled conv for the MRD band layers (discriminators.py:171-181): Conv2d(32, 32,
+ * (3, 9), stride (1, 2), padding (1, 4)) + bias + leaky ReLU on channels-last images.
+ * x: (S, H, Win, 32), y: (S, H, Wout, 32) with Wout = (Win - 1) / 2 + 1; strides in floats
+ * (pixel pitch is 32); w: [32][27][32] = (Cout, kh*kw, Cin) as f2g_gemm's forward weights. */
+typedef struct {
+  const float* x;
+  int64_t x_seq, x_line;
+  int32_t S, H, Win, Wout;
+  const float* w;
+  const float* bias;  /* may be NULL */
+  float lrelu_slope;  /* 0 = none */
+  int32_t _pad;
+  float* y;
+  int64_t y_seq, y_line;
+} f2g_conv32_desc;
+int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream);
+
 /* ---- on-device data front end (dataset.py:122-175).  x: (B, C, T) crops with
  * explicit item / channel strides (floats); lens[b] = valid samples of item b.
  *   f2g_wave_stats: stats[2b] = sqrt(mean_{c,t} x^2) (silence test, dataset.py:130-131),

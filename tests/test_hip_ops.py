@@ -439,3 +439,23 @@ def test_spec_power_and_fm_loss(ops):
     ops.fm_spec_loss(loss, w, g(s_err), g(s_gt), B, Fr, nf, g(lens.int()), 1e-7, 0.5, 1e-2, 1e2, inv)
     close(loss, want.reshape(1), name="fm loss")
     close(w, sc * mask * inv, rtol=1e-4, name="fm loss weights")
+
+
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (4, 17, 26)])
+def test_direct_conv32_matches_implicit_gemm(ops, S, H, Win):
+    """conv32.hip (LDS-tiled direct conv of the MRD band layers) against the implicit-GEMM path and
+    torch.conv2d, incl. partial tiles on every edge."""
+    Wout = (Win - 1) // 2 + 1
+    x = rnd(S * H * Win, 32, seed=1)
+    w = rnd(32, 32, 3, 9, seed=2, scale=0.05)
+    b = rnd(32, seed=3)
+    wp = w.permute(0, 2, 3, 1).reshape(32, 27 * 32).contiguous()       # (Cout, kh*kw, Cin)
+    y = torch.full((S * H * Wout, 32), 7.0, device=DEV)
+    ops.conv32_s2_fwd(g(x), S, H, Win, Wout, g(wp), g(b), 0.1, y)
+    ref = torch.nn.functional.conv2d(x.reshape(S, H, Win, 32).permute(0, 3, 1, 2).double(), w.double(),
+                                     b.double(), stride=(1, 2), padding=(1, 4))
+    ref = torch.nn.functional.leaky_relu(ref, 0.1).permute(0, 2, 3, 1).reshape(S * H * Wout, 32)
+    close(y, ref, name="conv32")
+    y2 = torch.empty_like(y)
+    ops.gemm(ops.win2d(g(x), S, H, Win, 32, Wout, 3, 9, 2, 1, 4), ops.mat(g(wp)), y2, bias=g(b), lrelu=0.1)
+    close(y, y2.cpu().double(), name="conv32-vs-gemm")
