@@ -71,7 +71,7 @@ __device__ __forceinline__ float prelu1(float v, float a) { return v > 0.f ? v :
 //   SL  anything else (misaligned, reflect padding, odd extents): element-wise predicated.
 // store() runs after the slab's MFMAs, so the transforms never wait on the load latency.
 // ------------------------------------------------------------------------------------------
-enum { PF = 0, GF = 1, SL = 2 };
+enum { PF = 0, GF = 1, SL = 2, GR = 3 };  // GR = GF + reflect padding (STFT framing)
 
 // what an out-of-window chunk of a GF operand reads (16 aligned bytes of zeros)
 // (not const: the compiler must keep the address select instead of folding a select of values)
@@ -188,7 +188,7 @@ struct Loader {
 
   __device__ __forceinline__ void gchunk(const f2g_operand& S, Stg& g, int q, bool rowok,
                                          const RowCtx& rcx, int c, int sg, int oo) {
-    if (MODE == GF) {
+    if (MODE == GF || MODE == GR) {
       // out-of-window chunks are read from a 16-byte block of zeros: nothing to mask afterwards
       // (off = offset of the chunk relative to S.base, precombined by the caller)
       const int l1 = rcx.l1b + sg, e = rcx.e0 + oo;
@@ -198,7 +198,7 @@ struct Loader {
       g.r[q] = *reinterpret_cast<const float4*>(v ? S.base + off : g_zero16);
       if (S.lrelu_src)
         g.r2[q] = *reinterpret_cast<const float4*>(v ? S.lrelu_src + off : g_zero16);
-      if (S.reflect) {
+      if (MODE == GR) {
         // STFT framing (center=True, reflect): only the chunks that straddle an end of the
         // sequence -- the first / last two frames -- take this element-wise mirrored path
         const bool inwin = rowok && c < S.cols && (unsigned)l1 < (unsigned)S.L1;
@@ -278,7 +278,7 @@ struct Loader {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
           RowCtx rx = rc[q];
-          if (MODE == GF) rx.base = rb[q] + so;
+          if (MODE == GF || MODE == GR) rx.base = rb[q] + so;
           gchunk(S, g, q, (rokm >> q) & 1, rx, c, sg, oo);
         }
       } else {
@@ -303,7 +303,8 @@ struct Loader {
           rcx.base = (long long)s_ * S.seq_stride;
           rcx.l1b = p1_ * S.step1 - S.pad1;
           rcx.e0 = (p0_ * S.step0 - S.pad0) * S.unit;
-          if (MODE == GF) rcx.base += (long long)(rcx.l1b + seg) * S.line_stride + (rcx.e0 + o);
+          if (MODE == GF || MODE == GR)
+            rcx.base += (long long)(rcx.l1b + seg) * S.line_stride + (rcx.e0 + o);
           gchunk(S, g, q, ok, rcx, c0, seg, o);
           ++p0_;
           const bool c0w = p0_ >= S.P0;
@@ -321,7 +322,7 @@ struct Loader {
   __device__ __forceinline__ float4 finalize(const f2g_operand& S, const Stg& g, int q) const {
     float4 v = g.r[q];
     const float4 a4 = g.a4;
-    if (MODE != GF && !((g.vmask >> q) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE != GF && MODE != GR && !((g.vmask >> q) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == PF && KM) {  // column tail of the fixed chunk
       if (!(cmask & 1)) v.x = 0.f;
       if (!(cmask & 2)) v.y = 0.f;
@@ -774,7 +775,7 @@ int dispatch_tile(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
   // (measured +5..20 % on every dgrad / wgrad shape); row-major forward tiles are best with 4
   // waves of 64x64 (least LDS traffic per MFMA).
   // (windowed forward operands -- the MPD convs -- spend VALU on im2col addressing: 8 waves too)
-  if (AKM || BKM || AMODE == GF)
+  if (AKM || BKM || AMODE == GF || AMODE == GR)
     return launch<4, 2, 1, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
   return launch<2, 2, 2, 2, AKM, BKM, AMODE, BMODE>(d, M, N, K, split, st);
 }
@@ -858,6 +859,7 @@ inline int op_mode(const f2g_operand& S, bool red_is_cols) {
                    (S.seglen & 3) == 0 && (eu0 & 3) == 0 && (ep0 & 3) == 0 && (S.L0u & 3) == 0 &&
                    (S.cols & 3) == 0 && (!S.reflect || !S.lrelu_src) &&
                    (!S.lrelu_src || al16(S.lrelu_src)) && S.L0u >= 4;
+  if (vec && S.reflect) return red_is_cols ? GR : SL;  // instantiated for forward A operands only
   return vec ? GF : SL;
 }
 
@@ -903,6 +905,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     if (!f1) {
       if (am == PF && bm == PF) return dispatch_tile<false, false, PF, PF>(dd, M, N, K, s, st);
       if (am == GF && bm == PF) return dispatch_tile<false, false, GF, PF>(dd, M, N, K, s, st);
+      if (am == GR && bm == PF) return dispatch_tile<false, false, GR, PF>(dd, M, N, K, s, st);
       return dispatch_tile<false, false, SL, SL>(dd, M, N, K, s, st);
     }
     if (am == PF && bm == PF) return dispatch_tile<false, true, PF, PF>(dd, M, N, K, s, st);

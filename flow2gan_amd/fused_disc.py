@@ -311,7 +311,7 @@ def _mrd_forward_one(x2, win: int, prm: list):
                           seq_stride=Ft * ldp, offset=lo * 2)
             else:
                 A = win2d(x, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2)
-            if l in (1, 2, 3) and DIRECT_CONV32:
+            if l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
                 # 32 -> 32 channels, (3, 9) taps, stride (1, 2): direct LDS-tiled kernel (conv32.hip)
                 y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
                 ops.conv32_s2_fwd(x, S, Ft, Win, Wout, wp, b, SLOPE, y)

@@ -12,9 +12,9 @@ def stats(path, out, header):
         n = re.sub(r"\(anonymous namespace\)::", "", r["Name"]); n = re.sub(r"\(.*", "", n)[:66]
         L.append(f"{n:66s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:9.1f} "
                  f"{float(r['MinNs'])/1e3:8.1f} {float(r['MaxNs'])/1e3:9.1f} {float(r['Percentage']):6.2f}")
-    g = [r for r in rows if "gemm_kernel" in r["Name"] or "narrow_" in r["Name"]]
+    g = [r for r in rows if "gemm_kernel" in r["Name"] or "narrow_" in r["Name"] or "conv32_" in r["Name"]]
     gc = sum(int(r["Calls"]) for r in g); gt = sum(float(r["TotalDurationNs"]) for r in g)
-    L.append(f"# all gemm_kernel<...> + narrow_* dispatches: {gc} calls, {gt/1e6:.1f} ms, average {gt/gc/1e3:.1f} us, "
+    L.append(f"# all gemm_kernel<...> + narrow_* + conv32_* dispatches (= the f2g_gemm-class launches bench.py times): {gc} calls, {gt/1e6:.1f} ms, average {gt/gc/1e3:.1f} us, "
              f"{100*gt/tot:.1f} % of kernel time")
     open(out, "w").write("\n".join(L) + "\n")
     print(L[1]); print(L[-1])
@@ -38,12 +38,13 @@ res = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     tot = 0.0; n = 0
     for row in csv.DictReader(open(f"{G}/pmcb_{name}/p_counter_collection.csv")):
-        if "gemm_kernel" in row["Kernel_Name"] or "narrow_" in row["Kernel_Name"]:
+        if ("gemm_kernel" in row["Kernel_Name"] or "narrow_" in row["Kernel_Name"]
+                or "conv32_" in row["Kernel_Name"]):
             tot += float(row["Counter_Value"]); n += 1
     res[name] = (tot, n)
 f, nf = res["FETCH_SIZE"]; w, nw = res["WRITE_SIZE"]
 json.dump({"source": "F2G_STREAMS=0 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py "
-                     "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode; all gemm_kernel / narrow_* dispatches (2 steps)",
+                     "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode; all gemm_kernel / narrow_* / conv32_* dispatches (2 steps)",
            "launches": nf, "fetch_kib_per_launch": f / nf, "write_kib_per_launch": w / nw,
            "hbm_bytes_per_launch_raw": (f / nf + w / nw) * 1024, "hbm_bytes_per_launch_fetch_x2": (2 * f / nf + w / nw) * 1024,
            "note": "gfx950 FETCH_SIZE under-reports wide coalesced reads by up to 2x (MI355X_MICROARCH.md, HBM); both raw and "
