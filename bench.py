@@ -237,7 +237,7 @@ def main():
                     "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: ranks must not wait on it
         # separate process (fresh OpenMP pool, no GPU context) under a hard time limit, so that the
         # reported baseline can never stall the benchmark
         import subprocess
