@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void sadam_prepare_kernel(const f2g_sadam_tens
                                                             const float* stats, float* tstate,
                                                             float* gstate, float* coef) {
   __shared__ float sh[4];
-  __shared__ float srt[1024];
+  __shared__ unsigned srt[1024];
   __shared__ float s_clip;
   const int tid = threadIdx.x;
   const int step = G.step;
@@ -99,14 +99,23 @@ __global__ __launch_bounds__(256) void sadam_prepare_kernel(const f2g_sadam_tens
       // sorted_norms = model_norms.sort(); irregular steps keep the last `step` of them
       int n2 = 1;
       while (n2 < period) n2 <<= 1;
-      for (int i = tid; i < n2; i += 256) srt[i] = i < period ? norms[i] : INFINITY;
+      // norms are >= 0, +inf or NaN: their bit patterns order like torch.sort does (NaN last);
+      // the power-of-two padding sorts behind everything
+      for (int i = tid; i < n2; i += 256) {
+        unsigned key = 0xffffffffu;
+        if (i < period) {
+          const float v = norms[i];
+          key = (v != v) ? 0x7fc00000u : __float_as_uint(v);
+        }
+        srt[i] = key;
+      }
       __syncthreads();
       for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
           for (int i = tid; i < n2; i += 256) {
             const int ixj = i ^ j;
             if (ixj > i) {
-              const float a = srt[i], b = srt[ixj];
+              const unsigned a = srt[i], b = srt[ixj];
               const bool up = (i & k) == 0;
               if ((a > b) == up) { srt[i] = b; srt[ixj] = a; }
             }
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) void sadam_prepare_kernel(const f2g_sadam_tens
         const int base = period - num;
         int idx = (num / 4) * 2;
         if (idx > num - 1) idx = num - 1;
-        const float median = srt[base + idx];
+        const float median = __uint_as_float(srt[base + idx]);
         if (median - median != 0.f) thr[2] = 1.f;  // "Too many grads were not finite"
         thr[0] = G.clipping_scale * median * (irregular ? 2.f : 1.f);
         thr[1] = 1.f;
@@ -155,7 +164,9 @@ __global__ __launch_bounds__(256) void sadam_prepare_kernel(const f2g_sadam_tens
         st[1] = 0.f;
         for (int k = 0; k < P; ++k) st[2 + k] = 0.f;
       }
-      st[2 + step % P] = clip * pg;
+      // clip == 0 means a non-finite total norm: the reference zeroes p.grad (optim.py:615-617),
+      // so its scale_grads entry is 0, not 0 * NaN
+      st[2 + step % P] = (clip == 0.f) ? 0.f : clip * pg;
       const bool due = step % P == P - 1;
       if (due) st[0] = sqrtf(pp / numel);
       const float rms = st[0];

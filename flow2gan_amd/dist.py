@@ -11,8 +11,9 @@ Reference: flow2gan/dist.py:23-48 (process-group setup), pretrain.py:792, finetu
 """
 from __future__ import annotations
 
+import datetime
 import os
-from typing import Iterable, List, Optional
+from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -31,7 +32,11 @@ def setup_dist(rank: Optional[int] = None, world_size: Optional[int] = None,
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
-    dist.init_process_group(backend, rank=rank, world_size=world_size)
+    if backend == "gloo":
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # host names need not resolve
+    # a missing peer must surface as an error within minutes, not after torch's 30-minute default
+    timeout = datetime.timedelta(seconds=float(os.environ.get("F2G_DIST_TIMEOUT_S", "600")))
+    dist.init_process_group(backend, rank=rank, world_size=world_size, timeout=timeout)
 
 
 def cleanup_dist() -> None:
@@ -45,6 +50,28 @@ def get_world_size() -> int:
 
 def get_rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def reduce_metrics(totals: Dict[str, float], device=None, group=None) -> Dict[str, float]:
+    """Sum a small dict of validation totals over ranks -- the reference's
+    `MetricsTracker.reduce` (utils.py:318-327): keys in sorted order, one fp32 vector, all-reduce
+    SUM, written back.  A no-op with one rank."""
+    if get_world_size() == 1:
+        return dict(totals)
+    keys = sorted(totals.keys())
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) \
+            if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    vec = torch.tensor([float(totals[k]) for k in keys], dtype=torch.float32, device=device)
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+    return {k: float(v) for k, v in zip(keys, vec.cpu().tolist())}
+
+
+def end_barrier(group=None) -> None:
+    """The barrier the reference's trainers execute before tearing the group down
+    (pretrain.py:876, finetune.py:1010); nothing to wait for with one rank."""
+    if get_world_size() > 1:
+        dist.barrier(group=group)
 
 
 class GradReducer:
@@ -122,6 +149,11 @@ class GradReducer:
     #                             # moment autograd has accumulated its last gradient
     #   reducer.finish()          # flush the stragglers, make the compute stream wait
     #
+    # Contract: exactly ONE backward() between prepare() and finish() (a second one raises), and
+    # every rank must produce gradients for the same parameters (the reference's DDP has the same
+    # constraint, find_unused_parameters aside): buckets whose parameters got no gradient at all
+    # are skipped on every rank alike; a bucket that fires on one rank only would hang the group.
+    #
     # Buckets are cut in REVERSE parameter order (backward reaches the last layers first): in a
     # D-step the MRD bucket travels while the MPD data-gradient convs still run, in a G-step the
     # branch buckets travel under the remaining branches' backward.  The arenas are persistent
@@ -156,6 +188,12 @@ class GradReducer:
         b = plan.bucket_of.get(id(p))
         if b is None:
             return
+        if b.sent:
+            # a second backward() between prepare() and finish() would accumulate into an arena
+            # that has already been averaged and would never be exchanged: ranks would diverge
+            # silently.  One backward per prepare(); gradient accumulation needs reduce().
+            raise RuntimeError("GradReducer: gradient arrived for a bucket that has already been "
+                               "exchanged -- exactly one backward() per prepare()/finish() pair")
         b.fired.add(id(p))
         if len(b.fired) == len(b.params) and not b.sent:
             self._send(plan, b)

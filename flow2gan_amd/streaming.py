@@ -46,7 +46,10 @@ def streaming_infer(model, cond: Tensor, n_timesteps: int = 1, chunk_size: int =
             pred = runner(c, noise)
         else:
             pred = model.infer(cond=c, n_timesteps=n_timesteps, clamp_pred=clamp_pred, noise=noise)
-        outs.append(pred[:, lpad: pred.size(1) - rpad])
+        piece = pred[:, lpad: pred.size(1) - rpad]
+        # a runner returns its graph's static output buffer, which the next replay of the same
+        # chunk shape (every interior chunk) overwrites: take the samples out now
+        outs.append(piece.clone() if runner is not None else piece)
     return torch.cat(outs, dim=-1)
 
 

@@ -1,5 +1,17 @@
+"""Test plumbing.  Besides the golden-fixture loader this arms three safety nets so that the
+driver's single `pytest tests/ -x -q -m gpu` command can never end as a silent time-out again:
+
+* a per-test watchdog (`faulthandler.dump_traceback_later(..., exit=True)`): a hung test ends the
+  run NON-ZERO, with the test's name and every thread's stack on stderr, long before the driver's
+  own limit (F2G_TEST_TIMEOUT seconds per test, default 240);
+* a flushed progress line per test on stderr (`[f2g] start/done <nodeid> <seconds>`), so a killed
+  run still leaves a tail that says where it was;
+* multi-process tests are collected LAST, so a rendezvous problem cannot starve the parity tests.
+"""
+import faulthandler
 import os
 import sys
+import time
 
 import pytest
 
@@ -9,10 +21,47 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+TEST_TIMEOUT = float(os.environ.get("F2G_TEST_TIMEOUT", "240"))
+# gloo resolves the host name to pick an interface unless told otherwise; the GPU boxes' host
+# names do not resolve
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+try:
+    sys.stdout.reconfigure(line_buffering=True)
+    sys.stderr.reconfigure(line_buffering=True)
+except Exception:  # pragma: no cover - exotic stdio replacement
+    pass
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "multiproc: spawns worker processes (collected last)")
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: 1 if it.get_closest_marker("multiproc") else 0)   # stable sort
+
+
+def _say(msg):
+    # the real stderr: pytest's capture replaces sys.stderr while a test runs
+    try:
+        os.write(2, (msg + "\n").encode())
+    except OSError:  # pragma: no cover
+        pass
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_protocol(item, nextitem):
+    _say(f"[f2g] start {item.nodeid}")
+    t0 = time.time()
+    # the traceback goes to fd 2 itself (sys.__stderr__), not to pytest's capture file
+    faulthandler.dump_traceback_later(TEST_TIMEOUT, exit=True, file=sys.__stderr__)
+    try:
+        yield
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+        _say(f"[f2g] done  {item.nodeid} {time.time() - t0:.1f}s")
 
 
 @pytest.fixture(scope="session")

@@ -88,6 +88,36 @@ def test_scaled_adam_vs_oracle_large_tensors_groups_and_missing_grads(fopt):
     assert torch.equal(opt2._plan["v"], opt._plan["v"]) and torch.equal(opt2._plan["tstate"], opt._plan["tstate"])
 
 
+def test_non_finite_gradient_step_follows_the_reference(fopt):
+    """One batch with an inf gradient (clipping on): the reference's clipping factor becomes 0,
+    p.grad is zeroed (optim.py:606-617), so the size-update statistic of that step is 0 and the
+    trajectory stays finite afterwards -- checked against the oracle step by step."""
+    from scaled_adam_oracle import ScaledAdamOracle
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(40, 33), (), (700,)]
+    init = [torch.randn(s, generator=gen) * 0.3 for s in shapes]
+    ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    kw = dict(lr=0.04, clipping_scale=2.0, clipping_update_period=4, size_update_period=4)
+    opt = fopt.ScaledAdam(ps, **kw)
+    orc = ScaledAdamOracle([t.clone() for t in init], **kw)
+    for k in range(20):
+        gs = [torch.randn(s, generator=gen) for s in shapes]
+        if k == 6:
+            gs[0][3, 5] = float("inf")
+        if k == 11:
+            gs[2][10] = float("nan")
+        for p, g_ in zip(ps, gs):
+            p.grad = g_.to(DEV)
+        opt.step()
+        orc.step(gs)
+        if k in (6, 11):
+            assert orc.last_clip == 0.0
+        for got, want in zip(ps, orc.params):
+            assert torch.isfinite(want).all()
+            err = float((got.detach().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+            assert err < 3e-5, (k, tuple(want.shape), err)
+
+
 def test_scaled_adam_refuses_cpu_parameters(fopt):
     from flow2gan_amd._lib import F2GError
     opt = fopt.ScaledAdam([torch.nn.Parameter(torch.zeros(4))])

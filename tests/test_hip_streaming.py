@@ -78,3 +78,36 @@ def test_streaming_infer_matches_oracle_chunking_and_graph_replay(golden):
                                     noise_fn=noise_fn, runner=runner)
         assert float((via_graph - got).abs().max()) < 1e-6
     assert len(runner.graphs) == 4   # chunk shapes of 44, 64, 54 and 34 frames
+
+
+@pytest.mark.gpu
+def test_graph_replay_with_repeated_interior_chunk_shapes(golden):
+    """300 frames in chunks of 64: the three interior chunks share one shape (and one captured
+    graph whose static output buffer every replay overwrites) -- the chunks must still be their
+    own audio, i.e. the runner's waveform equals the eager one."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import flow2gan_amd
+    from flow2gan_amd.streaming import ChunkRunner, chunk_plan, streaming_infer
+    g = golden("tiny_forward")
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("w/")}
+    m = flow2gan_amd.MelAudioGenerator(**TINY)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    gen = torch.Generator().manual_seed(5)
+    mel = (torch.randn(1, 100, 300, generator=gen) * 2.0 - 5.0).to(DEV)
+    plan = chunk_plan(300, 64, 256)
+    shapes = [fe - fs for fs, fe, _, _ in plan]
+    assert len(plan) == 5 and shapes.count(112) == 3          # 88, 112, 112, 112, 68
+    noises = [0.1 * torch.randn(1, n * 256, generator=gen).to(DEV) for n in shapes]
+    eager = streaming_infer(m, mel, n_timesteps=1, chunk_size=64, noise_fn=lambda i, B, Tn: noises[i])
+    runner = ChunkRunner(m, n_timesteps=1)
+    for _ in range(2):
+        replay = streaming_infer(m, mel, n_timesteps=1, chunk_size=64,
+                                 noise_fn=lambda i, B, Tn: noises[i], runner=runner)
+        assert replay.shape == eager.shape == (1, 300 * 256)
+        assert float((replay - eager).abs().max()) < 1e-6
+    assert len(runner.graphs) == 3
+    # distinct chunks really are distinct audio (the aliasing bug produced repeated copies)
+    a, b = eager[:, 64 * 256: 128 * 256], eager[:, 128 * 256: 192 * 256]
+    assert float((a - b).abs().max()) > 1e-3

@@ -128,14 +128,17 @@ def _dp_worker(rank, world, port, out):
     moved = fdist.GradReducer(bucket_mb=0.5).reduce(params)
     ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params[:-1]))
     ok = ok and params[-1].grad is None and moved == 4 * (5 + 300000 + 7 + 1)
+    # validation totals summed over ranks, keys in sorted order (reference utils.py:318-327)
+    tot = fdist.reduce_metrics({"frames": 10.0 * (rank + 1), "loss": 0.5, "a_first": float(rank)})
+    ok = ok and tot == {"a_first": 1.0, "frames": 30.0, "loss": 1.0}
+    fdist.end_barrier()
     torch.save(ok, os.path.join(out, f"ok{rank}.pt"))
     fdist.cleanup_dist()
 
 
 def test_grad_reducer_world_size_2_gloo(tmp_path):
-    import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from _mp import run_workers
+    run_workers("test_host_side", "_dp_worker", 2, str(tmp_path), timeout=120.0)
     assert torch.load(tmp_path / "ok0.pt") and torch.load(tmp_path / "ok1.pt")
 
 
@@ -170,15 +173,23 @@ def _overlap_worker(rank, world, port, out):
         ok = ok and moved == 4 * sum(p.numel() for p in params)  # arenas travel whole
     ok = ok and len(red._plans) == 1 and len(next(iter(red._plans.values())).buckets) >= 3
     ok = ok and all(n >= 2 for n in sent_during_backward)  # left from the autograd hooks
+    # a second backward inside one prepare()/finish() pair must fail loudly, not diverge silently
+    red.prepare(params)
+    net(xs[rank]).pow(2).mean().backward()
+    try:
+        net(xs[rank]).pow(2).mean().backward()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "one backward" in str(e)
+    red.finish()
     torch.save(ok, os.path.join(out, f"ov{rank}.pt"))
     fdist.cleanup_dist()
 
 
 def test_overlapped_grad_reducer_world_size_2_gloo(tmp_path):
     """prepare() / finish(): buckets are exchanged from autograd hooks during backward."""
-    import torch.multiprocessing as mp
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from _mp import run_workers
+    run_workers("test_host_side", "_overlap_worker", 2, str(tmp_path), timeout=120.0)
     assert torch.load(tmp_path / "ov0.pt") and torch.load(tmp_path / "ov1.pt")
 
 

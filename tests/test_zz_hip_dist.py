@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.multiproc]
 
 TINY = dict(sampling_rate=24000, n_mels=100, mel_n_fft=1024, mel_hop_length=256,
             n_ffts=(512, 256, 128), hop_lengths=(256, 128, 64), channels=(48, 32, 24),
@@ -56,22 +56,26 @@ def _worker(rank, world, port, outdir):
     torch.cuda.set_device(0)
     from flow2gan_amd import dist as fdist
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fdist.setup_dist(rank, world, backend="gloo")     # bounded rendezvous (F2G_DIST_TIMEOUT_S)
     gan, logmel = _build()
     red = fdist.GradReducer(bucket_mb=8.0)
     got = _steps(gan, logmel, rank, red)
     assert len(red._plans) == 2 and max(len(p.buckets) for p in red._plans.values()) >= 2
     torch.save(got, os.path.join(outdir, f"rank{rank}.pt"))
+    totals = fdist.reduce_metrics({"b": float(rank + 1), "a": 10.0}, device=torch.device("cuda"))
+    assert totals == {"a": 20.0, "b": 3.0}, totals
+    fdist.end_barrier()
     dist.destroy_process_group()
 
 
 def test_two_ranks_average_the_single_rank_gradients(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    import torch.multiprocessing as mp
+    from _mp import run_workers
     from flow2gan_amd import dist as fdist
-    port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # fresh worker processes, free port, killed (and the test failed) after 150 s
+    run_workers("test_zz_hip_dist", "_worker", 2, str(tmp_path), timeout=150.0,
+                env={"F2G_DETERMINISTIC": "1"})
     # what each rank computes on its own (no exchange), in this process
     singles = []
     for r in range(2):
