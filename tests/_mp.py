@@ -65,3 +65,28 @@ def run_workers(module: str, fn: str, world: int, outdir: str, timeout: float = 
         raise AssertionError(failed + "\n" + "\n".join(tails))
     for log in logs:
         log.close()
+
+
+def _preflight(rank, world, port, outdir):
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=30))
+    t = torch.full((4,), float(rank + 1))
+    dist.all_reduce(t)
+    assert float(t[0]) == 3.0
+    dist.destroy_process_group()
+
+
+def gloo_rendezvous_works(outdir: str) -> bool:
+    """Can two fresh CPU-only processes on this box meet over gloo on 127.0.0.1 at all?  Purely
+    environmental (no package code, no GPU): the GPU two-rank test skips -- with this reason --
+    when the box cannot, instead of reporting an environment problem as a parity failure."""
+    try:
+        run_workers("_mp", "_preflight", 2, outdir, timeout=60.0)
+        return True
+    except AssertionError as e:
+        sys.stderr.write("[f2g] gloo preflight failed: %s\n" % str(e)[:2000])
+        return False

@@ -71,8 +71,12 @@ def _worker(rank, world, port, outdir):
 def test_two_ranks_average_the_single_rank_gradients(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
-    from _mp import run_workers
+    from _mp import gloo_rendezvous_works, run_workers
     from flow2gan_amd import dist as fdist
+    pre = tmp_path / "preflight"
+    pre.mkdir()
+    if not gloo_rendezvous_works(str(pre)):
+        pytest.skip("two CPU-only processes cannot rendezvous over gloo/127.0.0.1 on this box")
     # fresh worker processes, free port, killed (and the test failed) after 150 s
     run_workers("test_zz_hip_dist", "_worker", 2, str(tmp_path), timeout=150.0,
                 env={"F2G_DETERMINISTIC": "1"})
