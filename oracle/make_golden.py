@@ -261,11 +261,27 @@ def grad_stats(named):
             for n, p in named if p.grad is not None}
 
 
-def case_tiny_stage2():
+TINY44 = dict(sampling_rate=44100, n_mels=128, mel_n_fft=2048, mel_hop_length=512,
+              n_ffts=(1024, 512, 256), hop_lengths=(512, 256, 128), channels=(48, 32, 24),
+              time_embed_channels=32, hidden_factor=3, num_layers=(2, 2, 2),
+              cond_enc_channels=32, cond_enc_num_layers=1, loss_n_fft=2048, loss_hop_length=512)
+
+
+def case_tiny_stage2(cfg=None, name="tiny_stage2", T=6000, short=4600, seed=31):
     """GAN D-step and G-step losses/grads: tiny generator + FULL discriminators
-    (default torch init under a seed; regenerated from the seed by the oracle)."""
+    (default torch init under a seed; regenerated from the seed by the oracle).
+    With cfg=TINY44: the mel_44k_128band_512x_base geometry (BASELINE config 5) -- sr 44100 drives
+    the 7 mel-recon filterbanks (gan.py:44-55), 128 mels / n_fft 2048 / hop 512 the front end."""
+    global TINY
     out = {}
-    ref_g, orc_g = tiny_pair()
+    saved = TINY
+    if cfg is not None:
+        TINY = cfg
+    try:
+        ref_g, orc_g = tiny_pair()
+    finally:
+        TINY = saved
+    cfg = cfg or TINY
     ref_g.branch_dropout = orc_g.branch_dropout = 0.0
     torch.manual_seed(77)
     ref = rgan.GAN(ref_g, **rcfg.get_gan_config("gan_multi_scale_mel_recon"))
@@ -281,17 +297,18 @@ def case_tiny_stage2():
     out["d_seed"] = np.array(77)
     for k in ("0.discriminators.0.conv_post.weight", "1.discriminators.2.band_convs.1.0.weight"):
         out["dprobe/" + k] = npy(sd_ref_d[k])
-    g = torch.Generator().manual_seed(31)
-    B, T = 2, 6000
+    g = torch.Generator().manual_seed(seed)
+    B = 2
     audio = 0.1 * torch.randn(B, T, generator=g)
     audio[1] *= 2.0
-    mel = O.LogMelSpectrogram()(audio)
+    mel = O.LogMelSpectrogram(cfg["sampling_rate"], cfg["mel_n_fft"], cfg["mel_hop_length"],
+                              cfg["n_mels"])(audio)
     noise = 0.1 * torch.randn(B, T, generator=g)
     out.update(sd_np(ref_g.state_dict()))
     out.update(audio=npy(audio), mel=npy(mel), noise=npy(noise))
     w_d = (1.0, 0.1)
     w_g = (1.0, 0.1, 1.0, 0.1, 45.0)
-    for n_steps, lens in ((1, torch.tensor([T, T])), (2, torch.tensor([T, 4600]))):
+    for n_steps, lens in ((1, torch.tensor([T, T])), (2, torch.tensor([T, short]))):
         tag = f"n{n_steps}"
         out[f"{tag}/lens"] = lens.numpy()
         for train_disc in (True, False):
@@ -310,7 +327,7 @@ def case_tiny_stage2():
                 res.append(([l.detach() for l in ls], m))
             lr, lo = res[0][0], res[1][0]
             step = "D" if train_disc else "G"
-            print(f"[tiny_stage2 {tag} {step}] ref losses {[round(float(x), 6) for x in lr]} "
+            print(f"[{name} {tag} {step}] ref losses {[round(float(x), 6) for x in lr]} "
                   f"oracle diff {max(abs(float(a - b)) for a, b in zip(lr, lo)):.3e}")
             out[f"{tag}/{step}/losses"] = np.array([float(x) for x in lr], dtype=np.float32)
             if train_disc:
@@ -330,7 +347,7 @@ def case_tiny_stage2():
                     out[f"{tag}/G/g/{k}"] = npy(p.grad)
                     worst = max(worst, maxdiff(p.grad, go[k].grad) / (p.grad.abs().max().item() + 1e-12))
                 print("    G grad worst rel diff", worst)
-    np.savez_compressed(os.path.join(OUT, "tiny_stage2.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
 # ------------------------------------------------------------------ case 5
@@ -366,7 +383,7 @@ def case_full_width():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mel", "fwd", "s1", "s2", "full"]
+    which = sys.argv[1:] or ["mel", "fwd", "s1", "s2", "s2_44k", "full"]
     if "mel" in which:
         case_mel_frontend()
     if "fwd" in which:
@@ -375,6 +392,8 @@ if __name__ == "__main__":
         case_tiny_stage1()
     if "s2" in which:
         case_tiny_stage2()
+    if "s2_44k" in which:
+        case_tiny_stage2(TINY44, "tiny_stage2_44k", T=11025, short=9000, seed=32)
     if "full" in which:
         case_full_width()
     for f in sorted(os.listdir(OUT)):
