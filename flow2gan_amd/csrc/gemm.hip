@@ -27,6 +27,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef F2G_LABVAR
+#define F2G_LABVAR 0
+#endif
 constexpr int BK = 32;
 constexpr int LDR = BK + 4;  // row-major LDS tile leading dim (conflict-free ds_read_b128)
 
@@ -250,7 +253,7 @@ struct Loader {
   __device__ __forceinline__ void load(const f2g_operand& S, int k0, Stg& g) {
     g.a4 = a4fix;
     if (MODE == PF) {
-      if (!KM) {
+      if (!KM && !(F2G_LABVAR & 2)) {
         // PReLU slopes of this slab's columns (full slabs only: c+3 < cols); unconditional load
         // through a valid dummy address keeps it off the control-flow / waitcnt path
         const float* ap = S.alpha ? S.alpha + (c0 + k0) : S.base;
@@ -334,7 +337,7 @@ struct Loader {
       v.x *= g.r2[q].x > 0.f ? 1.f : sl; v.y *= g.r2[q].y > 0.f ? 1.f : sl;
       v.z *= g.r2[q].z > 0.f ? 1.f : sl; v.w *= g.r2[q].w > 0.f ? 1.f : sl;
     }
-    if (S.alpha) {
+    if (S.alpha && !(F2G_LABVAR & 2)) {
       v.x = prelu1(v.x, a4.x); v.y = prelu1(v.y, a4.y);
       v.z = prelu1(v.z, a4.z); v.w = prelu1(v.w, a4.w);
     }
@@ -474,7 +477,7 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
 
 // ---- exact fp32: v_mfma_f32_32x32x2_f32 --------------------------------------------------
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (F2G_LABVAR & 8) ? 1024 / (WAVES_M * WAVES_N * 64) : 2)
 void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * TM * 32;
@@ -529,7 +532,7 @@ void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     const int cur = t & 1;
     typename SA::Stg ga;
     typename SB::Stg gb;
-    {  // unconditional prefetch of the next slab (the last iteration re-reads slab 0, unused)
+    if (!(F2G_LABVAR & 4)) {  // unconditional prefetch of the next slab (the last iteration re-reads slab 0, unused)
       const int kn = (t + 1 < nt) ? kbeg + (t + 1) * BK : kbeg;
       sa.load(d.A, kn, ga);
       sb.load(d.B, kn, gb);
@@ -574,10 +577,28 @@ void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nt) {
+      if (F2G_LABVAR & 4) {
+        sa.load(d.A, kbeg + (t + 1) * BK, ga);
+        sb.load(d.B, kbeg + (t + 1) * BK, gb);
+      }
       sa.store(d.A, ga, As + (cur ^ 1) * ASZ, LDA, tid);
       sb.store(d.B, gb, Bs + (cur ^ 1) * BSZ, LDB, tid);
     }
     __syncthreads();
+  }
+  if (F2G_LABVAR & 1) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = n0 + (wn * TN + ni) * 32 + li;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (col < N && row < M) d.E.C[(long long)row * d.E.ldc + col] = acc[mi][ni][e];
+        }
+    }
+    return;
   }
   gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h);
 }
