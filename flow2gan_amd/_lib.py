@@ -38,6 +38,7 @@ class Epilogue(C.Structure):
         ("colsum_alpha", C.c_void_p), ("colsum", C.c_void_p),
         ("lrelu_slope", C.c_float), ("scale", C.c_float),
         ("accumulate", C.c_int32), ("atomic", C.c_int32),
+        ("prelu_slope", C.c_void_p), ("prelu_out", C.c_void_p), ("ld_prelu_out", C.c_int64),
     ]
 
 
@@ -141,6 +142,7 @@ _SIGS = {
     "f2g_wave_gain": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P],
     "f2g_sadam_stats": [_P, _P, _I, _P, _I],
     "f2g_sadam_prepare": [_P, C.POINTER(SadamGroup), _P, _P, _P, _P],
+    "f2g_zero_halo": [_P, _I, _I, _I, _I, _I],
     "f2g_sadam_update": [_P, _P, _I, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_dwnorm_bwd_workspace",

@@ -389,9 +389,34 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(float* g, const float* y
   }
 }
 
+// rows [0, lo) and [rows_per_seq - hi, rows_per_seq) of every sequence := 0 (float4 lanes)
+__global__ __launch_bounds__(256) void zero_halo_kernel(float* buf, int nseq, int rows_per_seq,
+                                                        int C4, int lo, int hi) {
+  const int per = (lo + hi) * C4;
+  const long long total = (long long)nseq * per;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int sq = (int)(i / per);
+    int r = (int)(i - (long long)sq * per);
+    const int hr = r / C4, c = r - hr * C4;
+    const int row = hr < lo ? hr : rows_per_seq - hi + (hr - lo);
+    reinterpret_cast<float4*>(buf)[((long long)sq * rows_per_seq + row) * C4 + c] =
+        make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int f2g_zero_halo(float* buf, int32_t nseq, int32_t rows_per_seq, int32_t C, int32_t lo,
+                             int32_t hi, f2g_stream_t stream) {
+  if (!buf || (C & 3) || lo < 0 || hi < 0 || lo + hi > rows_per_seq) return F2G_EINVAL;
+  if (nseq <= 0 || lo + hi == 0) return F2G_OK;
+  hipLaunchKernelGGL(zero_halo_kernel, dim3(f2g_grid_for((int64_t)nseq * (lo + hi) * (C / 4), 256)),
+                     dim3(256), 0, ST, buf, nseq, rows_per_seq, C / 4, lo, hi);
+  return f2g_check_launch();
+}
 
 extern "C" int f2g_axpby_rows(float* y, const float* x0, const float* x1, const float* ca,
                               const float* cb, float sa, float sb, int32_t rows, int32_t cols,

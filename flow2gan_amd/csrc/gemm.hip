@@ -27,9 +27,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef F2G_LABVAR
-#define F2G_LABVAR 0
-#endif
 constexpr int BK = 32;
 constexpr int LDR = BK + 4;  // row-major LDS tile leading dim (conflict-free ds_read_b128)
 
@@ -253,7 +250,7 @@ struct Loader {
   __device__ __forceinline__ void load(const f2g_operand& S, int k0, Stg& g) {
     g.a4 = a4fix;
     if (MODE == PF) {
-      if (!KM && !(F2G_LABVAR & 2)) {
+      if (!KM) {
         // PReLU slopes of this slab's columns (full slabs only: c+3 < cols); unconditional load
         // through a valid dummy address keeps it off the control-flow / waitcnt path
         const float* ap = S.alpha ? S.alpha + (c0 + k0) : S.base;
@@ -337,7 +334,7 @@ struct Loader {
       v.x *= g.r2[q].x > 0.f ? 1.f : sl; v.y *= g.r2[q].y > 0.f ? 1.f : sl;
       v.z *= g.r2[q].z > 0.f ? 1.f : sl; v.w *= g.r2[q].w > 0.f ? 1.f : sl;
     }
-    if (S.alpha && !(F2G_LABVAR & 2)) {
+    if (S.alpha) {
       v.x = prelu1(v.x, a4.x); v.y = prelu1(v.y, a4.y);
       v.z = prelu1(v.z, a4.z); v.w = prelu1(v.w, a4.w);
     }
@@ -429,8 +426,9 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
   for (int ni = 0; ni < TN; ++ni) {
     const int col = n0 + (wn * TN + ni) * 32 + li;
     const bool cok = col < N;
-    float bias = 0.f, gam = 0.f, aln = 0.f;
+    float bias = 0.f, gam = 0.f, aln = 0.f, pslope = 0.f;
     if (cok) {
+      if (E.prelu_slope) pslope = E.prelu_slope[col];
       if (E.bias && first) bias = E.bias[col];
       if (E.res && first) gam = E.gamma ? E.gamma[col] : 1.f;
       if (E.aux) aln = E.alpha_n[col];
@@ -450,6 +448,11 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
           v *= (av > 0.f ? 1.f : aln);
         }
         if (E.lrelu_slope != 0.f) v = v > 0.f ? v : E.lrelu_slope * v;
+        if (E.prelu_slope) {
+          const float pv = v > 0.f ? v : pslope * v;
+          if (E.prelu_out) E.prelu_out[(long long)row * E.ld_prelu_out + col] = pv;
+          else v = pv;
+        }
         cs += v;
         long long off;
         if (E.P0o > 0) {
@@ -477,7 +480,7 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
 
 // ---- exact fp32: v_mfma_f32_32x32x2_f32 --------------------------------------------------
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (F2G_LABVAR & 8) ? 1024 / (WAVES_M * WAVES_N * 64) : 2)
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2)
 void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * TM * 32;
@@ -532,7 +535,7 @@ void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     const int cur = t & 1;
     typename SA::Stg ga;
     typename SB::Stg gb;
-    if (!(F2G_LABVAR & 4)) {  // unconditional prefetch of the next slab (the last iteration re-reads slab 0, unused)
+    {  // unconditional prefetch of the next slab (the last iteration re-reads slab 0, unused)
       const int kn = (t + 1 < nt) ? kbeg + (t + 1) * BK : kbeg;
       sa.load(d.A, kn, ga);
       sb.load(d.B, kn, gb);
@@ -577,28 +580,10 @@ void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nt) {
-      if (F2G_LABVAR & 4) {
-        sa.load(d.A, kbeg + (t + 1) * BK, ga);
-        sb.load(d.B, kbeg + (t + 1) * BK, gb);
-      }
       sa.store(d.A, ga, As + (cur ^ 1) * ASZ, LDA, tid);
       sb.store(d.B, gb, Bs + (cur ^ 1) * BSZ, LDB, tid);
     }
     __syncthreads();
-  }
-  if (F2G_LABVAR & 1) {
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      const int col = n0 + (wn * TN + ni) * 32 + li;
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + (wm * TM + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (col < N && row < M) d.E.C[(long long)row * d.E.ldc + col] = acc[mi][ni][e];
-        }
-    }
-    return;
   }
   gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h);
 }
@@ -884,6 +869,264 @@ inline int op_mode(const f2g_operand& S, bool red_is_cols) {
   return vec ? GF : SL;
 }
 
+
+// ---- lean forward kernel --------------------------------------------------------------------
+// Measured on this part (tools/micro/gemm_lab.hip + PMC): v_mfma_f32_32x32x2_f32 occupies the
+// vector ALU for 64 cycles, and with two waves per SIMD keeping that pipe full every OTHER VALU
+// instruction issued on the SIMD costs ~37 cycles of it.  The generic loaders above spend 50-100
+// VALU instructions per K slab on addresses, masks and on-load transforms (108 TFLOP/s on the
+// 1024-channel MPD layers against 143 for the bare MFMA stream).  This kernel has NO vector
+// ALU instruction inside the K loop:
+//   * operands are read with buffer_load_dwordx4: resource (base, 2 GiB window) in SGPRs, a
+//     per-thread CONSTANT byte offset per staged row (decoded once: sequence / line / position of
+//     the im2col row), the K advance in a scalar register (SALU walks the window's segments);
+//     rows past the end carry the offset 0x80000000 = out of range = the hardware returns zeros;
+//   * LDS addresses are per-thread constants + immediates (K loop unrolled by two);
+//   * the next slab is requested before the MFMA phase and written to LDS after it;
+//   * the bias enters through the accumulator initialisation.
+// It serves form 0 with a row-major B ([n][k] weights) and an A operand whose windows never leave
+// their source (plain matrices, and conv windows over buffers that carry their zero padding as
+// halo rows): every 1x1 conv, the MPD convs and their data gradients (transposed weights).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r) {
+  if (r >= S.rows) return 0x80000000u;
+  long long off;
+  if (S.P0 == 1 && S.P1 == 1) {
+    off = (long long)r * S.seq_stride;
+  } else {
+    const int q = r / S.P0, p0 = r - q * S.P0;
+    const int sq = q / S.P1, p1 = q - sq * S.P1;
+    off = (long long)sq * S.seq_stride + (long long)(p1 * S.step1 - S.pad1) * S.line_stride +
+          (long long)(p0 * S.step0 - S.pad0) * S.unit;
+  }
+  return (unsigned)(off * 4);
+}
+
+__global__ __launch_bounds__(256, 2)
+void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
+  constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(BM, BN, m0, n0);
+  const int kbeg = blockIdx.z * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  const int nt = (kend - kbeg) / BK;
+
+  f32x16 acc[2][2];
+  {
+    const bool first = blockIdx.z == 0;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + (wn * 2 + ni) * 32 + li;
+      const float b = (d.E.bias && first && col < N) ? d.E.bias[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = b;
+    }
+  }
+  const int ch = tid & 7, rr = tid >> 3;
+  __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, 0x80000000u, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, 0x80000000u, 0x00020000);
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    offA[q] = lean_row_offset(d.A, m0 + rr + 32 * q);
+    const int rowb = n0 + rr + 32 * q;
+    offB[q] = rowb < N ? (unsigned)((long long)rowb * d.B.seq_stride * 4) : 0x80000000u;
+    if (offA[q] != 0x80000000u) offA[q] += ch * 16;
+    if (offB[q] != 0x80000000u) offB[q] += ch * 16;
+  }
+  // scalar K walk of A: segments of `seglen` columns, `line_stride` floats apart
+  const int seglen = d.A.seglen < d.A.cols ? d.A.seglen : d.A.cols;
+  const int spseg = seglen / BK;                                  // slabs per segment
+  const int segjump = (int)((d.A.line_stride - seglen) * 4);      // bytes skipped at a segment end
+  const int s0 = kbeg / BK;
+  int left = spseg - (s0 % spseg);
+  const int ka0 = (int)(((long long)(s0 / spseg) * d.A.line_stride + (long long)(s0 % spseg) * BK) * 4);
+  const int kb0 = kbeg * 4;
+  int ka = ka0, kb = kb0;
+
+  float* wA = smem + rr * LDR + ch * 4;
+  float* wB = smem + 2 * TSZ + rr * LDR + ch * 4;
+  const float* rA = smem + (wm * 64 + li) * LDR + h * 16;
+  const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * 16;
+
+  auto gload = [&](int soa, int sob, u32x4 (&la)[4], u32x4 (&lb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      la[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q], soa, 0);
+      lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB[q], sob, 0);
+    }
+  };
+  auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<u32x4*>(wA + bufoff + q * 32 * LDR) = la[q];
+      *reinterpret_cast<u32x4*>(wB + bufoff + q * 32 * LDR) = lb[q];
+    }
+  };
+  auto mfma_slab = [&](int bufoff) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *reinterpret_cast<const float4*>(rA + bufoff + mi * 32 * LDR + s4 * 4);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        b[ni] = *reinterpret_cast<const float4*>(rB + bufoff + ni * 32 * LDR + s4 * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const float av = q == 0 ? a[mi].x : q == 1 ? a[mi].y : q == 2 ? a[mi].z : a[mi].w;
+            const float bv = q == 0 ? b[ni].x : q == 1 ? b[ni].y : q == 2 ? b[ni].z : b[ni].w;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+          }
+    }
+  };
+  // (SALU) K offsets of the slab after the current one
+  auto advance = [&]() {
+    ka += BK * 4;
+    kb += BK * 4;
+    if (--left == 0) {
+      left = spseg;
+      ka += segjump;
+    }
+  };
+  if (nt > 0) {
+    u32x4 la[4], lb[4];
+    gload(ka, kb, la, lb);
+    lstore(0, la, lb);
+  }
+  __syncthreads();
+  auto step = [&](int t, int curoff, int nxtoff) {
+    u32x4 la[4], lb[4];
+    advance();
+    const bool more = t + 1 < nt;   // the last iteration re-reads the first slab (never used)
+    gload(more ? ka : ka0, more ? kb : kb0, la, lb);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_slab(curoff);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(nxtoff, la, lb);
+    __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    step(t, 0, TSZ);
+    step(t + 1, TSZ, 0);
+  }
+  if (t < nt) step(t, 0, TSZ);
+
+  const f2g_epilogue& E = d.E;
+  const bool simple = !E.res && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
+                      !E.atomic && !E.accumulate && E.scale == 0.f;
+  if (simple) {
+    // plain store (+ leaky ReLU / PReLU): uniform row bases, per-lane constant offset
+    const float sl = E.lrelu_slope;
+    const bool pre = E.prelu_slope != nullptr, two = pre && E.prelu_out != nullptr;
+    const unsigned coff = (unsigned)(((long long)(4 * h) * E.ldc + li) * 4);
+    const unsigned poff = (unsigned)(((long long)(4 * h) * E.ld_prelu_out + li) * 4);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col0 = n0 + (wn * 2 + ni) * 32;
+        const int row0 = m0 + (wm * 2 + mi) * 32;
+        const float ps = (pre && col0 + li < N) ? E.prelu_slope[col0 + li] : 0.f;
+        if (row0 + 32 <= M && col0 + 32 <= N) {
+          char* cb = reinterpret_cast<char*>(E.C + (long long)row0 * E.ldc + col0);
+          char* pb = reinterpret_cast<char*>(E.prelu_out + (long long)row0 * E.ld_prelu_out + col0);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[mi][ni][e];
+            if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
+            const long long ro = (e & 3) + 8 * (e >> 2);
+            if (pre) {
+              const float pv = fmaxf(v, 0.f) + ps * fminf(v, 0.f);
+              if (two) *reinterpret_cast<float*>(pb + ro * E.ld_prelu_out * 4 + poff) = pv;
+              else v = pv;
+            }
+            *reinterpret_cast<float*>(cb + ro * E.ldc * 4 + coff) = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            float v = acc[mi][ni][e];
+            if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
+            if (row < M && col0 + li < N) {
+              if (pre) {
+                const float pv = fmaxf(v, 0.f) + ps * fminf(v, 0.f);
+                if (two) E.prelu_out[(long long)row * E.ld_prelu_out + col0 + li] = pv;
+                else v = pv;
+              }
+              E.C[(long long)row * E.ldc + col0 + li] = v;
+            }
+          }
+        }
+      }
+    return;
+  }
+  f2g_epilogue E2 = E;
+  E2.bias = nullptr;   // already in the accumulators
+  gemm_epilogue<2, 2>(E2, acc, M, N, m0, n0, wm, wn, li, h);
+}
+
+// Can `S` (the A operand of a form-0 GEMM) be read by the lean kernel: aligned, no on-load
+// transform, reduction in whole 32-column slabs per segment, and every window inside its source?
+inline bool lean_a_ok(const f2g_operand& S) {
+  if (S.reflect || S.alpha || S.lrelu_src || S.rows <= 0 || S.cols < BK) return false;
+  if (!al16(S.base) || (S.seq_stride & 3) || (S.line_stride & 3)) return false;
+  const long long eu0 = (long long)S.step0 * S.unit, ep0 = (long long)S.pad0 * S.unit;
+  if ((eu0 & 3) || (ep0 & 3)) return false;
+  const int seglen = S.seglen < S.cols ? S.seglen : S.cols;
+  if (seglen % BK || S.cols % seglen) return false;
+  const int nseg = S.cols / seglen;
+  if (S.P0 < 1 || S.P1 < 1) return false;
+  if (S.rows % (S.P0 * S.P1)) return false;
+  // line range
+  if (S.pad1 > 0 || (long long)(S.P1 - 1) * S.step1 - S.pad1 + nseg - 1 >= S.L1) return false;
+  // element range inside a line
+  if (S.pad0 > 0 || ((long long)(S.P0 - 1) * S.step0 - S.pad0) * S.unit + seglen > S.L0u) return false;
+  if (nseg > 1 && S.line_stride < seglen) return false;
+  // byte offsets must stay below 2 GiB
+  const long long nseq = S.rows / (S.P0 * S.P1);
+  const long long last = (nseq - 1) * S.seq_stride + (long long)(S.L1 - 1) * S.line_stride + S.L0u;
+  return last * 4 < 0x7ff00000ll;
+}
+
+inline bool lean_b_ok(const f2g_operand& S) {
+  return host_plain(S) && !S.alpha && al16(S.base) && (S.seq_stride & 3) == 0 && S.cols % BK == 0 &&
+         (long long)S.rows * S.seq_stride * 4 < 0x7ff00000ll;
+}
+
+int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+  constexpr size_t smem = (size_t)4 * 128 * LDR * sizeof(float);
+  int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
+  // chunks must not straddle... (they may: the scalar K walk starts anywhere) -- only whole slabs
+  int zs = (K + kchunk - 1) / kchunk;
+  dim3 grid((M + 127) / 128, (N + 127) / 128, zs);
+  if (grid.x == 0 || grid.y == 0) return F2G_OK;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lean_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_lean_kernel, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  return f2g_check_launch();
+}
+
 }  // namespace
 
 extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
@@ -895,6 +1138,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     const int nr = f2g_gemm_narrow(d, st);  // <= 4 output columns / gradient rows: VALU kernels
     if (nr != 0) return nr < 0 ? nr : F2G_OK;
   }
+  if (d.E.prelu_slope && (d.E.atomic || d.E.accumulate || d.E.P0o > 0 || d.form == 2)) return F2G_EINVAL;
   if (d.form == 0 || d.form == 1) {
     const bool f1 = d.form == 1;
     if (f1 ? d.A.cols != d.B.rows : d.A.cols != d.B.cols) return F2G_EINVAL;
@@ -904,7 +1148,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     // split_k: 1 = off, > 1 = as asked, 0 = decide here (linear epilogues only)
     // (an epilogue input that aliases the output -- in-place residual or PReLU-derivative mask --
     // would be destroyed by the zero fill)
-    const bool linear = d.E.lrelu_slope == 0.f && d.E.res != d.E.C && d.E.aux != d.E.C;
+    const bool linear = d.E.lrelu_slope == 0.f && d.E.res != d.E.C && d.E.aux != d.E.C && !d.E.prelu_slope;
     int s = d.split_k;
     // (STFT framing GEMMs are never split: atomics would make the spectra -- the input of every
     // discriminator and loss -- differ in the last bit from run to run)
@@ -924,6 +1168,9 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       dd.E.accumulate = 0;
     }
     if (!f1) {
+      static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
+      if (lean_on && d.precision == 0 && N > 64 && lean_a_ok(d.A) && lean_b_ok(d.B))
+        return launch_lean(dd, M, N, K, s, st);
       if (am == PF && bm == PF) return dispatch_tile<false, false, PF, PF>(dd, M, N, K, s, st);
       if (am == GF && bm == PF) return dispatch_tile<false, false, GF, PF>(dd, M, N, K, s, st);
       if (am == GR && bm == PF) return dispatch_tile<false, false, GR, PF>(dd, M, N, K, s, st);

@@ -249,7 +249,7 @@ bool plainish(const f2g_operand& S) {
 // negative on error.
 int f2g_gemm_narrow(const f2g_gemm_desc& d, hipStream_t st) {
   const f2g_epilogue& E = d.E;
-  if (E.res || E.aux || E.colsum_alpha) return 0;
+  if (E.res || E.aux || E.colsum_alpha || E.prelu_slope) return 0;
   if (d.form == 0 || d.form == 1) {
     const bool f1 = d.form == 1;
     const int M = d.A.rows, N = f1 ? d.B.cols : d.B.rows, K = d.A.cols;

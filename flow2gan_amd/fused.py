@@ -70,12 +70,20 @@ def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0,
     z = ops.empty(rows, Cc, device=dev)
     ops.dwnorm_fwd(x, z, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta, bp.log_scale.reshape(1),
                    cproj, ldcp, Fc, up, cp_off, te, ldte, te_off)
+    # pwconv1 -> PReLU in the producing epilogue: the hidden activation p is written once (next to
+    # the pre-activation a when the backward will need it) instead of being re-derived from a by
+    # every column tile of pwconv2 inside its K loop
     a = ops.empty(rows, Hh, device=dev)
-    gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1)
+    if keep:
+        p = ops.empty(rows, Hh, device=dev)
+        gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha, prelu_out=p)
+    else:
+        p = a
+        gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha)
     out = ops.empty(rows, Cc, device=dev)
-    gemm(mat(a, rows, Hh, alpha=bp.alpha), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
+    gemm(mat(p, rows, Hh), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
          gamma=bp.gamma.reshape(Cc))
-    return out, z, a
+    return out, z, (a, p)
 
 
 def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale: bool,
@@ -83,6 +91,7 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
               g_te=None):
     """Backward of block_fwd.  Destroys z and a (reused as gradient buffers).
     Returns (gx, grads) with grads ordered like BLOCK_KEYS."""
+    a, p_act = a
     dev = x.device
     rows, Cc, Hh = B * F, bp.C, bp.H
     g_w2 = ops.zeros(Cc, Hh, device=dev)
@@ -97,7 +106,7 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
     g_gamma = ops.zeros(Cc, 1, device=dev)
     # pwconv2: out = W2 prelu(a) + b2 + gamma*x
     ops.colsum(g_b2, gout, rows, Cc)
-    ops.wgrad(gout, Cc, gout.stride(0), mat(a, rows, Hh, alpha=bp.alpha), g_w2)
+    ops.wgrad(gout, Cc, gout.stride(0), mat(p_act, rows, Hh), g_w2)
     # da = (gout W2) * prelu'(a)   (in place over a), d alpha, d b1
     gemm(mat(gout, rows, Cc), mat(bp.w2.reshape(Cc, Hh)), a, form=1, aux=a, alpha_n=bp.alpha,
          colsum_alpha=g_alpha, colsum=g_b1)
@@ -155,7 +164,7 @@ class CondEncoderFn(torch.autograd.Function):
         saved = []
         for bp in blks:
             fn = _limit_draw(training)
-            y, z, a = block_fwd(bp, x, B, Fm, None)
+            y, z, a = block_fwd(bp, x, B, Fm, None, keep=any(ctx.needs_input_grad))
             flags.append((fn, _limit_draw(training)))
             saved.append((x, z, a))
             x = y
@@ -250,22 +259,25 @@ class CondPathFn(torch.autograd.Function):
             ops.copy3(cext, Fce * Dc, Dc, cond, Fc * Dc, Dc, B, n, Dc)
         rows = B * Fce
         a = ops.empty(rows, Hc, device=dev)
-        gemm(mat(cext, rows, Dc), mat(w0.reshape(Hc, Dc)), a, bias=b0)
+        keep = any(ctx.needs_input_grad)
+        pact = ops.empty(rows, Hc, device=dev) if keep else a
+        gemm(mat(cext, rows, Dc), mat(w0.reshape(Hc, Dc)), a, bias=b0, prelu=alpha,
+             prelu_out=pact if keep else None)
         cm = ops.empty(rows, Dc, device=dev)
-        gemm(mat(a, rows, Hc, alpha=alpha), mat(w2.reshape(Dc, Hc)), cm, bias=b2)
+        gemm(mat(pact, rows, Hc), mat(w2.reshape(Dc, Hc)), cm, bias=b2)
         wstack = _stack_rows(wcs, Dc, dev)
         bstack = _stack_vecs(bcs, dev)
         cproj = ops.empty(rows, nblk * Cc, device=dev)
         gemm(mat(cm, rows, Dc), mat(wstack), cproj, bias=bstack)
-        if any(ctx.needs_input_grad):
-            ctx.saved = (cext, a, cm, wstack)
+        if keep:
+            ctx.saved = (cext, (a, pact), cm, wstack)
             ctx.params = params
             ctx.dims = (B, Fc, Fce, Dc, Hc, Cc, nblk)
         return cproj
 
     @staticmethod
     def backward(ctx, g):
-        cext, a, cm, wstack = ctx.saved
+        cext, (a, pact), cm, wstack = ctx.saved
         params = ctx.params
         B, Fc, Fce, Dc, Hc, Cc, nblk = ctx.dims
         w0, b0, alpha, w2, b2 = params[:5]
@@ -282,7 +294,7 @@ class CondPathFn(torch.autograd.Function):
         g_b2 = ops.zeros(Dc, device=dev)
         ops.colsum(g_b2, g_cm, rows, Dc)
         g_w2 = ops.zeros(Dc, Hc, device=dev)
-        ops.wgrad(g_cm, Dc, g_cm.stride(0), mat(a, rows, Hc, alpha=alpha), g_w2)
+        ops.wgrad(g_cm, Dc, g_cm.stride(0), mat(pact, rows, Hc), g_w2)
         g_alpha = ops.zeros(Hc, device=dev)
         g_b0 = ops.zeros(Hc, device=dev)
         gemm(mat(g_cm, rows, Dc), mat(w2.reshape(Dc, Hc)), a, form=1, aux=a, alpha_n=alpha,
@@ -381,7 +393,7 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     for j, bp in enumerate(bv.blks):
         fn = _limit_draw(training)
         y, z, a = block_fwd(bp, xcur, B, F, lens_f, cproj, NC, Fce, up, j * Cc, te_all, NC,
-                            j * Cc)
+                            j * Cc, keep=keep)
         flags.append((fn, _limit_draw(training)))
         if keep:
             saved_blocks.append((xcur, z, a))

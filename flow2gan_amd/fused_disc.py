@@ -77,8 +77,33 @@ def mpd_params(mpd) -> list:
     return p
 
 
+HALO = 2  # zero rows kept on both sides of every sequence of an MPD map (conv padding (2, 0))
+
+
+def _halo_rows(S: int, H: int, Cc: int, dev):
+    """(S, H + 2*HALO, Cc) channels-last map whose halo rows are zero: the (5,1)/(3,1) convs and
+    their data gradients read it as plain strided windows (no bounds tests in the GEMM K loop)."""
+    buf = ops.empty(S * (H + 2 * HALO), Cc, device=dev)
+    if Cc % 4 == 0:
+        ops.zero_halo(buf, S, H + 2 * HALO, Cc, HALO, HALO)
+    else:
+        ops.fill_(buf, 0.0)
+    return buf
+
+
+def _halo_map(H: int, Cc: int):
+    """Epilogue row map (sequence, position) -> row HALO + position of the padded layout."""
+    return (H, (H + 2 * HALO) * Cc, Cc, HALO * Cc)
+
+
+def unhalo(y, S: int, H: int):
+    """(S*(H+2*HALO), C) padded map -> (S, H, C) view of the valid rows."""
+    return y.view(S, H + 2 * HALO, y.shape[1])[:, HALO:HALO + H]
+
+
 def _mpd_forward_one(x2, p: int, prm: list):
-    """x2 (2B, T) -> dict with per-layer activations (channels-last), heights, scores."""
+    """x2 (2B, T) -> dict with per-layer activations (channels-last; layers 1..5 in the halo
+    layout, see _halo_rows), heights, scores."""
     dev = x2.device
     S2, T = x2.shape
     H = (T + p - 1) // p
@@ -91,32 +116,56 @@ def _mpd_forward_one(x2, p: int, prm: list):
         w, b = prm[2 * l], prm[2 * l + 1]
         Cin, Cout, st = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
         Hout = (H + 4 - 5) // st + 1
-        wp = pack_conv_weight(w)
-        y = ops.empty(S * Hout, Cout, device=dev)
-        gemm(win1d(x, S, H, Cin, Hout, st, 2, 5), mat(wp), y, bias=b, lrelu=SLOPE)
+        wp = ops.derived(w, "pack", pack_conv_weight)
+        y = _halo_rows(S, Hout, Cout, dev)
+        if l == 0:   # the folded waveform has no halo (one channel): bounds-tested windows
+            A = win1d(x, S, H, Cin, Hout, st, 2, 5)
+        else:        # window of output row h starts at padded row h*st
+            A = win1d(x, S, H + 2 * HALO, Cin, Hout, st, 0, 5)
+        gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout))
         acts.append(y)
         hs.append(Hout)
         x, H = y, Hout
     wpost, bpost = prm[10], prm[11]
-    wpp = pack_conv_weight(wpost)
+    wpp = ops.derived(wpost, "pack", pack_conv_weight)
     scores = ops.empty(S * H, 1, device=dev)
-    gemm(win1d(x, S, H, 1024, H, 1, 1, 3), mat(wpp), scores, bias=bpost)
+    gemm(win1d(x, S, H + 2 * HALO, 1024, H, 1, -(HALO - 1), 3), mat(wpp), scores, bias=bpost)
     return dict(acts=acts, hs=hs, scores=scores, S=S, p=p)
 
 
-def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0):
-    """g_x (S*Hin, Cin) from g_pre (rows S*Hout starting g_off floats in, Cout)."""
+def _dgrad_weight(w, stride: int, j0: int, nt: int):
+    """Weights of one stride residue of the transposed conv as a forward GEMM operand
+    [Cin][nt*Cout] (k index = tap-major, channel-minor, taps in window order)."""
+    def build(t):
+        Cout, Cin, K = t.shape[0], t.shape[1], t.shape[2] * t.shape[3]
+        out = ops.empty(Cin, nt * Cout, device=t.device)
+        ops.permute4(out, t, (Cin, nt, Cout, 1), (K, -stride, Cin * K, 0),
+                     in_offset=j0 + stride * (nt - 1))
+        return out
+    return ops.derived(w, ("dgradT", stride, j0, nt), build)
+
+
+def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=True, out_halo=True):
+    """g_x from g_pre (S sequences of Hout rows x Cout, starting g_off floats in; halo layout when
+    g_halo).  Returns g_x in the halo layout (S, Hin + 2*HALO, Cin) when out_halo, else (S*Hin, Cin).
+    One forward-form GEMM per stride residue against the cached re-laid weights."""
     Cin, K = w.shape[1], w.shape[2] * w.shape[3]
     dev = g_pre.device
-    gx = ops.empty(S * Hin, Cin, device=dev)
+    gx = _halo_rows(S, Hin, Cin, dev) if out_halo else ops.empty(S * Hin, Cin, device=dev)
     for rho, j0, nt, e0, Lq in _residues(K, stride, pad, Hin):
         if Lq == 0:
             continue
-        wq = ops.empty(nt * Cout, Cin, device=dev)
-        ops.permute4(wq, w, (nt, Cout, Cin, 1), (-stride, Cin * K, K, 0),
-                     in_offset=j0 + stride * (nt - 1))
-        A = win1d(g_pre, S, Hout, Cout, Lq, 1, (nt - 1) - e0, nt, offset=g_off)
-        gemm(A, mat(wq), gx, form=1, rowmap=(Lq, Hin * Cin, stride * Cin, rho * Cin))
+        wq = _dgrad_weight(w, stride, j0, nt)
+        wpad = (nt - 1) - e0
+        if g_halo:
+            A = win1d(g_pre, S, Hout + 2 * HALO, Cout, Lq, 1, wpad - HALO, nt, offset=g_off)
+        else:
+            A = win1d(g_pre, S, Hout, Cout, Lq, 1, wpad, nt, offset=g_off)
+        if out_halo:
+            rm = (Lq, (Hin + 2 * HALO) * Cin, stride * Cin, (HALO + rho) * Cin)
+        else:
+            rm = (Lq, Hin * Cin, stride * Cin, rho * Cin)
+        gemm(A, mat(wq), gx, rowmap=rm)
     return gx
 
 
@@ -145,8 +194,11 @@ class MPDLossFn(torch.autograd.Function):
                 ops.hinge_loss(losses, None, sc, nh, -1.0, 1.0 / nh, s_off=nh)
                 for l in range(2, 6):  # fmaps: conv layers 1..4 (discriminators.py:95-96)
                     y = st["acts"][l]
-                    n = y.numel() // 2
-                    ops.l1_loss_ab(losses, None, y, 0, y, n, 1, n, n, 1.0 / n, loss_offset=1)
+                    Hl, Cl = st["hs"][l], y.shape[1]
+                    nflat = (S // 2) * (Hl + 2 * HALO) * Cl     # halo rows are 0 on both sides
+                    nval = (S // 2) * Hl * Cl
+                    ops.l1_loss_ab(losses, None, y, 0, y, nflat, 1, nflat, nflat, 1.0 / nval,
+                                   loss_offset=1)
                 ops.l1_loss_ab(losses, None, sc, 0, sc, nh, 1, nh, nh, 1.0 / nh, loss_offset=1)
             saved.append(st)
         lanes.join()
@@ -189,32 +241,40 @@ class MPDLossFn(torch.autograd.Function):
             y5 = acts[5]
             if train_disc:
                 gwp = ops.zeros(1, 3 * 1024, device=dev)
-                ops.wgrad(gs, 1, 1, win1d(y5, S, H5, 1024, H5, 1, 1, 3), gwp)
+                ops.wgrad(gs, 1, 1, win1d(y5, S, H5 + 2 * HALO, 1024, H5, 1, -(HALO - 1), 3), gwp)
                 grads_p[10] = unpack_conv_grad(gwp, wpost.shape)
                 gb = ops.zeros(1, device=dev)
                 ops.colsum(gb, gs, S * H5, 1)
                 grads_p[11] = gb
-            g = _conv1d_dgrad(gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5)
+            g = _conv1d_dgrad(gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5, g_halo=False)
             for l in reversed(range(5)):
                 w = prm[2 * l]
                 Cin, Cout, stv = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
                 Hin, Hout = hs[l], hs[l + 1]
+                Hp = Hout + 2 * HALO
                 y = acts[l + 1]
-                yoff = roff * Hout * Cout
-                n = Sx * Hout * Cout
+                yoff = roff * Hp * Cout
+                n = Sx * Hp * Cout                    # flat, halo rows included (they stay 0)
+                nval = Sx * Hout * Cout
                 if (not train_disc) and l >= 1:
-                    ops.lrelu_bwd(g, y, y, 1.0 / n, SLOPE, 1, n, n, wdev=g1, y_off=yoff, r_off=0)
+                    ops.lrelu_bwd(g, y, y, 1.0 / nval, SLOPE, 1, n, n, wdev=g1, y_off=yoff, r_off=0)
                 else:
                     ops.lrelu_bwd(g, y, None, 0.0, SLOPE, 1, n, n, y_off=yoff)
                 if train_disc:
+                    # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
+                    # the windows they pair with -- partly outside the input -- contribute nothing)
                     gwp = ops.zeros(Cout, 5 * Cin, device=dev)
-                    ops.wgrad(g, Cout, Cout, win1d(acts[l], S, Hin, Cin, Hout, stv, 2, 5), gwp)
+                    if l == 0:
+                        X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
+                    else:
+                        X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5)
+                    ops.wgrad(g, Cout, Cout, X, gwp)
                     grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
                     gb = ops.zeros(Cout, device=dev)
-                    ops.colsum(gb, g, S * Hout, Cout)
+                    ops.colsum(gb, g, S * Hp, Cout)
                     grads_p[2 * l + 1] = gb
                 if l > 0 or not train_disc:
-                    g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin)
+                    g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=l > 0)
             if not train_disc:
                 # g: (B*p*H0, 1) gradient of the folded image of the generated half
                 lanes.chain_enter()  # g_fake is accumulated period after period

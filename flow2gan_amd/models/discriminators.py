@@ -54,7 +54,7 @@ class DiscriminatorP(nn.Module):
         for l in range(2, 6):
             y = st["acts"][l]
             H, Cc = st["hs"][l], y.shape[1]
-            fmap.append(y.view(B, p, H, Cc).permute(0, 3, 2, 1))
+            fmap.append(FD.unhalo(y, B * p, H).reshape(B, p, H, Cc).permute(0, 3, 2, 1))
         H5 = st["hs"][5]
         sc = st["scores"].view(B, p, H5, 1).permute(0, 3, 2, 1)
         fmap.append(sc)

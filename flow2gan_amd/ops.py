@@ -29,8 +29,61 @@ def fill_(t, v: float):
     return t
 
 
+def zero_halo(buf, nseq: int, rows_per_seq: int, Cc: int, lo: int, hi: int):
+    call("f2g_zero_halo", ptr(buf), nseq, rows_per_seq, Cc, lo, hi)
+    return buf
+
+
 def pad4(n: int) -> int:
     return (n + 3) // 4 * 4
+
+
+# ------------------------------------------------------------------ derived-weight cache
+# Re-laid copies of parameters (transposes for data gradients, window-major conv weights) are
+# rebuilt only when the parameter changed: keyed on the parameter object (weakly), its version
+# counter (every in-place torch write bumps it) and WEIGHT_EPOCH, which writers that go through
+# raw pointers (the HIP optimizer) bump.  In a D-step the generator's copies survive, and vice versa.
+import weakref
+
+WEIGHT_EPOCH = 0
+_DERIVED: dict = {}
+
+
+def bump_weight_epoch() -> None:
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def derived(t, tag, build):
+    """build(t) cached per (tensor object or its view base, tag) until the tensor changes."""
+    import os
+    if os.environ.get("F2G_WEIGHT_CACHE", "1") == "0":
+        return build(t)
+    owner = t._base if t._base is not None else t
+    oid = id(owner)          # (tensors compare element-wise: never use them as dictionary keys)
+    ent = _DERIVED.get(oid)
+    if ent is None or ent[0]() is not owner:
+        ent = (weakref.ref(owner, lambda _r, oid=oid: _DERIVED.pop(oid, None)), {})
+        _DERIVED[oid] = ent
+    slot = ent[1]
+    key = (tag, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+    stamp = (owner._version, WEIGHT_EPOCH)
+    hit = slot.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    out = build(t)
+    slot[key] = (stamp, out)
+    return out
+
+
+def transposed(w2d):
+    """(n, k) row-major -> cached (k, n) row-major copy."""
+    def build(t):
+        n, k = t.shape
+        out = torch.empty(k, n, device=t.device, dtype=torch.float32)
+        permute4(out, t, (k, n, 1, 1), (1, t.stride(0), 0, 0))
+        return out
+    return derived(w2d, "T", build)
 
 
 # ------------------------------------------------------------------ operands
@@ -56,6 +109,8 @@ def mat(t, rows: Optional[int] = None, cols: Optional[int] = None, ld: Optional[
     o.lrelu_src = None if lrelu_src is None else ptr(lrelu_src) + 4 * offset
     o.lrelu_slope = slope
     o._keep = (t, alpha, lrelu_src)
+    o._src = t if (offset == 0 and t.dim() == 2 and rows == t.shape[0] and cols == t.shape[1]
+                   and ld == t.stride(0) and alpha is None and lrelu_src is None) else None
     return o
 
 
@@ -108,10 +163,16 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
          res=None, ldres: Optional[int] = None, gamma=None, aux=None, ldaux: Optional[int] = None,
          alpha_n=None, colsum_alpha=None, colsum=None, lrelu: float = 0.0, scale: float = 0.0,
          accumulate: bool = False, atomic: bool = False, split_k: int = 0, out_offset: int = 0,
-         rowmap=None):
+         rowmap=None, prelu=None, prelu_out=None):
     """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None.
     split_k: 0 = let the library decide (forms 0/1: split-K onto a zeroed output when the tile
     grid would leave most of the last wave of CUs idle), 1 = off, > 1 = as given."""
+    if form == 1 and LEAN_DGRAD and GEMM_PRECISION == 0:
+        # data gradient C[r,n] = sum_k A[r,k] W[k,n] as a forward GEMM against the cached transpose
+        # W^T [n][k]: same products in the same order, and the lean forward kernel applies
+        src = getattr(Bm, "_src", None)
+        if src is not None and src.shape[0] % 32 == 0 and src.shape[1] > 64:
+            Bm, form = mat(transposed(src)), 0
     d = GemmDesc()
     d.A, d.B = A, Bm
     e = Epilogue()
@@ -134,6 +195,9 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     e.scale = scale
     e.accumulate = 1 if accumulate else 0
     e.atomic = 1 if atomic else 0
+    e.prelu_slope = ptr(prelu)
+    e.prelu_out = ptr(prelu_out)
+    e.ld_prelu_out = prelu_out.stride(0) if prelu_out is not None else 0
     d.E = e
     d.form = form
     d.split_k = split_k
@@ -143,6 +207,11 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     else:
         call("f2g_gemm", C.byref(d))
     return out
+
+
+import os as _os
+
+LEAN_DGRAD = _os.environ.get("F2G_LEAN_DGRAD", "1") != "0"
 
 
 def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope: float, y):

@@ -88,6 +88,13 @@ typedef struct {
   float scale;         /* v *= scale before everything else if != 0 (0 means 1) */
   int32_t accumulate;  /* C += v */
   int32_t atomic;      /* atomicAdd(C, v) (split-K / shared gradients) */
+  /* PReLU of the result fused into the producer (modules.py:444,488: act(pwconv1(x))):
+   * p = v > 0 ? v : prelu_slope[n]*v.  With prelu_out set, C receives v (the pre-activation the
+   * backward needs) and prelu_out the activation; with prelu_out NULL, C receives p.  Plain
+   * stores only (no row map / split-K / accumulate). */
+  const float* prelu_slope;
+  float* prelu_out;
+  int64_t ld_prelu_out;
 } f2g_epilogue;
 
 /* form: 0 = C[r,n] = sum_k A[r,k] * B[n,k]   (forward; B = weights [n][k])
@@ -313,6 +320,12 @@ int f2g_period_fold_bwd(float* gx, const float* gout, int32_t B, int32_t T, int3
 int f2g_log_clip(float* x, int64_t n, float clip, f2g_stream_t stream);
 /* fill */
 int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
+/* Zero padding carried by the data: buf is (nseq, rows_per_seq, C) channels-last, rows [0, lo) and
+ * [rows_per_seq - hi, rows_per_seq) of every sequence are set to 0 (C % 4 == 0).  Conv inputs
+ * laid out this way (the reference's `padding=` of discriminators.py:65-76 as halo rows) are read
+ * by f2g_gemm as plain strided windows, without bounds tests in the K loop. */
+int f2g_zero_halo(float* buf, int32_t nseq, int32_t rows_per_seq, int32_t C, int32_t lo,
+                  int32_t hi, f2g_stream_t stream);
 
 /* ---- direct LDS-tiled conv for the MRD band layers (discriminators.py:171-181): Conv2d(32, 32,
  * (3, 9), stride (1, 2), padding (1, 4)) + bias + leaky ReLU on channels-last images.
