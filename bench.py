@@ -163,6 +163,8 @@ def main():
         if world > 1 or force_dist:
             torch.distributed.barrier()
 
+    HOST_ISSUE = [0.0, 0]
+
     def timed(nwarm, nsteps):
         for _ in range(nwarm):
             step()
@@ -171,7 +173,10 @@ def main():
         t0 = time.perf_counter()
         done = 0.0
         for _ in range(nsteps):
+            ts = time.perf_counter()
             done += step()
+            HOST_ISSUE[0] += time.perf_counter() - ts    # host time to enqueue the step (no sync)
+            HOST_ISSUE[1] += 1
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -185,6 +190,7 @@ def main():
     ops.set_gemm_precision(args.gemm)
     audio_s, elapsed = timed(args.warmup, args.steps)
     value = world * audio_s / elapsed
+    host_issue_ms = round(1e3 * HOST_ISSUE[0] / max(1, HOST_ISSUE[1]), 2)
     fast = None
     if args.gemm == "fp32" and not args.no_fast_mode:
         # also report the split-bf16 GEMM mode (3 bf16 MFMAs per product, fp32 accumulate): same
@@ -256,6 +262,7 @@ def main():
             "metric": f"audio-seconds/sec (train step, G+D fwd/bwd) {args.model}",
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "host_issue_ms_per_step": host_issue_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (split-bf16 GEMM, fp32 accumulate)",
                       "bf16": "bf16 GEMM operands, fp32 accumulate / activations"}[args.gemm],

@@ -142,6 +142,7 @@ _SIGS = {
     "f2g_wave_gain": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P],
     "f2g_sadam_stats": [_P, _P, _I, _P, _I],
     "f2g_sadam_prepare": [_P, C.POINTER(SadamGroup), _P, _P, _P, _P],
+    "f2g_lrelu_bwd_colsum": [_P, _P, _P, _F, _P, _F, _I, _I, _L, _P],
     "f2g_zero_halo": [_P, _I, _I, _I, _I, _I],
     "f2g_sadam_update": [_P, _P, _I, _P],
 }
@@ -196,7 +197,15 @@ def ptr(t) -> int | None:
     return t.data_ptr()
 
 
+# F2G_DRYRUN=1 (measurement aid only): build every descriptor but launch nothing, to time the
+# pure host cost of issuing a step.  Results are garbage by construction.
+_DRYRUN = os.environ.get("F2G_DRYRUN", "0") == "1"
+
+
 def call(name: str, *args):
+    if _DRYRUN:
+        stream_ptr()
+        return
     rc = getattr(lib, name)(*args, stream_ptr())
     if rc != 0:
         raise F2GError(f"{name} failed with code {rc}: {lib.f2g_last_error().decode()}")

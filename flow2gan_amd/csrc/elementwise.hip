@@ -389,6 +389,59 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(float* g, const float* y
   }
 }
 
+// Leaky-ReLU backward of a (rows, C) map in place, g = (g + w*sign(y - f_real)) * lrelu'(y), fused
+// with the column sums of the result (= the bias gradient of the conv that produced y): one pass
+// over g instead of two.  Block = CS4 float4 column groups x (256/CS4) row lanes.
+__global__ __launch_bounds__(256) void lrelu_bwd_cs_kernel(float* g, const float* y_act,
+                                                           const float* f_real, float w,
+                                                           const float* wdev, float slope,
+                                                           int rows, int C4, long long ld4,
+                                                           int rows_per, int cs_log2,
+                                                           float* colsum) {
+  __shared__ float4 red[256];
+  const float wg = w * (wdev ? wdev[0] : 1.f);
+  const int CS = 1 << cs_log2, RS = 256 >> cs_log2;
+  const int cl = threadIdx.x & (CS - 1), rl = threadIdx.x >> cs_log2;
+  const int c = blockIdx.x * CS + cl;
+  const int r0 = blockIdx.y * rows_per;
+  int r1 = r0 + rows_per;
+  if (r1 > rows) r1 = rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C4) {
+    float4* g4 = reinterpret_cast<float4*>(g);
+    const float4* y4 = reinterpret_cast<const float4*>(y_act);
+    const float4* f4 = reinterpret_cast<const float4*>(f_real);
+    for (int r = r0 + rl; r < r1; r += RS) {
+      const long long off = (long long)r * ld4 + c;
+      const float4 y = y4[off];
+      float4 gv = g4[off];
+      if (f_real) {
+        const float4 f = f4[off];
+        const float dx = y.x - f.x, dy = y.y - f.y, dz = y.z - f.z, dw = y.w - f.w;
+        gv.x += wg * (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f));
+        gv.y += wg * (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f));
+        gv.z += wg * (dz > 0.f ? 1.f : (dz < 0.f ? -1.f : 0.f));
+        gv.w += wg * (dw > 0.f ? 1.f : (dw < 0.f ? -1.f : 0.f));
+      }
+      gv.x *= y.x > 0.f ? 1.f : slope; gv.y *= y.y > 0.f ? 1.f : slope;
+      gv.z *= y.z > 0.f ? 1.f : slope; gv.w *= y.w > 0.f ? 1.f : slope;
+      g4[off] = gv;
+      s.x += gv.x; s.y += gv.y; s.z += gv.z; s.w += gv.w;
+    }
+  }
+  if (!colsum) return;
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < C4) {
+    for (int i = 1; i < RS; ++i) {
+      const float4 t = red[(i << cs_log2) + cl];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    atomicAdd(colsum + 4 * c, s.x); atomicAdd(colsum + 4 * c + 1, s.y);
+    atomicAdd(colsum + 4 * c + 2, s.z); atomicAdd(colsum + 4 * c + 3, s.w);
+  }
+}
+
 // rows [0, lo) and [rows_per_seq - hi, rows_per_seq) of every sequence := 0 (float4 lanes)
 __global__ __launch_bounds__(256) void zero_halo_kernel(float* buf, int nseq, int rows_per_seq,
                                                         int C4, int lo, int hi) {
@@ -408,6 +461,23 @@ __global__ __launch_bounds__(256) void zero_halo_kernel(float* buf, int nseq, in
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int f2g_lrelu_bwd_colsum(float* g, const float* y_act, const float* f_real, float w,
+                                    const float* wdev, float slope, int32_t rows, int32_t C,
+                                    int64_t ld, float* colsum, f2g_stream_t stream) {
+  if (!g || !y_act || (C & 3) || (ld & 3)) return F2G_EINVAL;
+  if (rows <= 0 || C <= 0) return F2G_OK;
+  const int C4 = C / 4;
+  int cs_log2 = 0;
+  while ((1 << cs_log2) < C4 && cs_log2 < 8) ++cs_log2;
+  const int CS = 1 << cs_log2, RS = 256 >> cs_log2;
+  int rows_per = 16 * RS;  // 16 rows per thread
+  if (rows_per > rows) rows_per = rows;
+  dim3 grid((C4 + CS - 1) / CS, (rows + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(lrelu_bwd_cs_kernel, grid, dim3(256), 0, ST, g, y_act, f_real, w, wdev, slope,
+                     rows, C4, (long long)(ld / 4), rows_per, cs_log2, colsum);
+  return f2g_check_launch();
+}
 
 extern "C" int f2g_zero_halo(float* buf, int32_t nseq, int32_t rows_per_seq, int32_t C, int32_t lo,
                              int32_t hi, f2g_stream_t stream) {

@@ -19,6 +19,7 @@
 // GENERIC operands (windowed im2col views) decode rows once before the K loop and columns once
 // per slab.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "common.h"
@@ -903,7 +904,7 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
   return (unsigned)(off * 4);
 }
 
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(128)))
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
   constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -932,17 +933,19 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
   const int ch = tid & 7, rr = tid >> 3;
   __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, 0x80000000u, 0x00020000);
-  __amdgpu_buffer_rsrc_t rb =
-      __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, 0x80000000u, 0x00020000);
-  unsigned offA[4], offB[4];
+  // B is a plain [n][k] matrix: the resource ends with its last row, so the rows of a partial
+  // last tile (n >= N) are out of range = zeros, and ONE per-thread offset serves all four staged
+  // rows (their distance, 32 rows, is uniform and rides in the scalar offset)
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * 4), 0x00020000);
+  unsigned offA[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     offA[q] = lean_row_offset(d.A, m0 + rr + 32 * q);
-    const int rowb = n0 + rr + 32 * q;
-    offB[q] = rowb < N ? (unsigned)((long long)rowb * d.B.seq_stride * 4) : 0x80000000u;
     if (offA[q] != 0x80000000u) offA[q] += ch * 16;
-    if (offB[q] != 0x80000000u) offB[q] += ch * 16;
   }
+  const unsigned offB = (unsigned)((long long)(n0 + rr) * d.B.seq_stride * 4) + ch * 16;
+  const int qstepB = (int)(32 * d.B.seq_stride * 4);
   // scalar K walk of A: segments of `seglen` columns, `line_stride` floats apart
   const int seglen = d.A.seglen < d.A.cols ? d.A.seglen : d.A.cols;
   const int spseg = seglen / BK;                                  // slabs per segment
@@ -962,7 +965,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       la[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q], soa, 0);
-      lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB[q], sob, 0);
+      lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB, sob + q * qstepB, 0);
     }
   };
   auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {

@@ -94,16 +94,8 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
     a, p_act = a
     dev = x.device
     rows, Cc, Hh = B * F, bp.C, bp.H
-    g_w2 = ops.zeros(Cc, Hh, device=dev)
-    g_b2 = ops.zeros(Cc, device=dev)
-    g_alpha = ops.zeros(Hh, device=dev)
-    g_w1 = ops.zeros(Hh, Cc, device=dev)
-    g_b1 = ops.zeros(Hh, device=dev)
-    g_beta = ops.zeros(Cc, device=dev)
-    g_ls = ops.zeros(1, device=dev)
-    g_wdw = ops.zeros(Cc, 1, bp.K, device=dev)
-    g_bdw = ops.zeros(Cc, device=dev)
-    g_gamma = ops.zeros(Cc, 1, device=dev)
+    (g_w2, g_b2, g_alpha, g_w1, g_b1, g_beta, g_ls, g_wdw, g_bdw, g_gamma) = ops.zeros_many(
+        [(Cc, Hh), (Cc,), (Hh,), (Hh, Cc), (Hh,), (Cc,), (1,), (Cc, 1, bp.K), (Cc,), (Cc, 1)], dev)
     # pwconv2: out = W2 prelu(a) + b2 + gamma*x
     ops.colsum(g_b2, gout, rows, Cc)
     ops.wgrad(gout, Cc, gout.stride(0), mat(p_act, rows, Hh), g_w2)

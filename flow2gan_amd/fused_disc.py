@@ -240,10 +240,15 @@ class MPDLossFn(torch.autograd.Function):
             # conv_post (1024 -> 1, 3 taps, stride 1)
             y5 = acts[5]
             if train_disc:
-                gwp = ops.zeros(1, 3 * 1024, device=dev)
+                # every weight / bias gradient accumulator of this sub-discriminator: one fill
+                zshapes = [(1, 3 * 1024), (1,)]
+                for l in range(5):
+                    zshapes += [(MPD_CH[l + 1], 5 * MPD_CH[l]), (MPD_CH[l + 1],)]
+                zbuf = ops.zeros_many(zshapes, dev)
+                gwp = zbuf[0]
                 ops.wgrad(gs, 1, 1, win1d(y5, S, H5 + 2 * HALO, 1024, H5, 1, -(HALO - 1), 3), gwp)
                 grads_p[10] = unpack_conv_grad(gwp, wpost.shape)
-                gb = ops.zeros(1, device=dev)
+                gb = zbuf[1]
                 ops.colsum(gb, gs, S * H5, 1)
                 grads_p[11] = gb
             g = _conv1d_dgrad(gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5, g_halo=False)
@@ -256,23 +261,24 @@ class MPDLossFn(torch.autograd.Function):
                 yoff = roff * Hp * Cout
                 n = Sx * Hp * Cout                    # flat, halo rows included (they stay 0)
                 nval = Sx * Hout * Cout
-                if (not train_disc) and l >= 1:
+                if train_disc:     # + the bias gradient (column sums) in the same pass
+                    gb = zbuf[2 + 2 * l + 1]
+                    ops.lrelu_bwd_colsum(g, y, None, 0.0, SLOPE, S * Hp, Cout, Cout, gb, y_off=yoff)
+                    grads_p[2 * l + 1] = gb
+                elif l >= 1:
                     ops.lrelu_bwd(g, y, y, 1.0 / nval, SLOPE, 1, n, n, wdev=g1, y_off=yoff, r_off=0)
                 else:
                     ops.lrelu_bwd(g, y, None, 0.0, SLOPE, 1, n, n, y_off=yoff)
                 if train_disc:
                     # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
                     # the windows they pair with -- partly outside the input -- contribute nothing)
-                    gwp = ops.zeros(Cout, 5 * Cin, device=dev)
+                    gwp = zbuf[2 + 2 * l]
                     if l == 0:
                         X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
                     else:
                         X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5)
                     ops.wgrad(g, Cout, Cout, X, gwp)
                     grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
-                    gb = ops.zeros(Cout, device=dev)
-                    ops.colsum(gb, g, S * Hp, Cout)
-                    grads_p[2 * l + 1] = gb
                 if l > 0 or not train_disc:
                     g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=l > 0)
             if not train_disc:
@@ -365,7 +371,7 @@ def _mrd_forward_one(x2, win: int, prm: list):
             w, b = prm[(bi * 5 + l) * 2], prm[(bi * 5 + l) * 2 + 1]
             Cin = 2 if l == 0 else MRD_CH
             Win, Wout = ws[l], ws[l + 1]
-            wp = pack_conv_weight(w)
+            wp = ops.derived(w, "pack", pack_conv_weight)
             if x_is_spec:
                 A = win2d(x, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2, line_stride=ldp,
                           seq_stride=Ft * ldp, offset=lo * 2)
@@ -388,8 +394,8 @@ def _mrd_forward_one(x2, win: int, prm: list):
         foff += ws[5]
     wpost, bpost = prm[50], prm[51]
     scores = ops.empty(S * Ft * Wcat, 1, device=dev)
-    gemm(win2d(cat, S, Ft, Wcat, MRD_CH, Wcat, 3, 3, 1, 1, 1), mat(pack_conv_weight(wpost)), scores,
-         bias=bpost)
+    gemm(win2d(cat, S, Ft, Wcat, MRD_CH, Wcat, 3, 3, 1, 1, 1),
+         mat(ops.derived(wpost, "pack", pack_conv_weight)), scores, bias=bpost)
     return dict(xn=xn, stats=stats, packed=packed, ldp=ldp, Ft=Ft, nb=nb, hop=hop, bands=bands,
                 widths=widths, Wcat=Wcat, cat=cat, acts=acts, scores=scores)
 
@@ -407,9 +413,12 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
     for rho, j0, ntw, e0, Lq in _residues(kw, sw, pw, Win):
         if Lq == 0:
             continue
-        wq = ops.empty(kh * ntw * Cout, Cin, device=dev)
-        ops.permute4(wq, w, (kh, ntw, Cout, Cin), (-kw, -sw, Cin * kh * kw, kh * kw),
-                     in_offset=(kh - 1) * kw + j0 + sw * (ntw - 1))
+        def build(t, j0=j0, ntw=ntw):
+            out = ops.empty(kh * ntw * Cout, Cin, device=t.device)
+            ops.permute4(out, t, (kh, ntw, Cout, Cin), (-kw, -sw, Cin * kh * kw, kh * kw),
+                         in_offset=(kh - 1) * kw + j0 + sw * (ntw - 1))
+            return out
+        wq = ops.derived(w, ("dgrad2d", sw, j0, ntw), build)
         A = win2d(g_pre, S, H, Wout, Cout, Lq, kh, ntw, 1, 1, (ntw - 1) - e0, line_stride=g_line,
                   seq_stride=g_seq, offset=g_off)
         gemm(A, mat(wq), gx, form=1, rowmap=(Lq, x_line, sw * Cin, x_off + rho * Cin))
@@ -533,7 +542,11 @@ class MRDLossFn(torch.autograd.Function):
                         y = st["acts"][bi][l]
                         n = Sx * Ft * Wout * C
                         yoff = soff * Ft * Wout * C
-                        if (not train_disc) and l >= 1:
+                        if train_disc:   # + bias gradient (column sums) in the same pass
+                            gb_l = ops.zeros(C, device=dev)
+                            ops.lrelu_bwd_colsum(g, y, None, 0.0, SLOPE, S * Ft * Wout, C, C, gb_l,
+                                                 y_off=yoff)
+                        elif l >= 1:
                             ops.lrelu_bwd(g, y, y, 1.0 / n, SLOPE, 1, n, n, wdev=g1, y_off=yoff,
                                           r_off=0)
                         else:
@@ -559,11 +572,11 @@ class MRDLossFn(torch.autograd.Function):
                         gemm(dY, X, gwp, form=2, atomic=True,
                              split_k=ops.split_for(X.rows, tiles))
                         grads_w[(bi * 5 + l) * 2] = unpack_conv_grad(gwp, w.shape)
-                        gb = ops.zeros(C, device=dev)
                         if l == 4:
+                            gb = ops.zeros(C, device=dev)
                             _colsum_strided(gb, gcat, S * Ft, W4, C, ldc, foff * C)
                         else:
-                            ops.colsum(gb, g, S * Ft * Wout, C)
+                            gb = gb_l
                         grads_w[(bi * 5 + l) * 2 + 1] = gb
                     if l > 0:
                         gx = ops.empty(Sx * Ft * Win, Cin, device=dev)

@@ -599,6 +599,31 @@ def lrelu_bwd(g, y_act, f_real, w, slope, rows, cols, ld, wdev=None, g_off=0, y_
          rows, cols, ld)
 
 
+def lrelu_bwd_colsum(g, y_act, f_real, w, slope, rows, Cc, ld, colsum, wdev=None, g_off=0, y_off=0,
+                     r_off=0):
+    """In-place leaky-ReLU backward of a (rows, Cc) map + column sums of the result (bias grad)."""
+    call("f2g_lrelu_bwd_colsum", ptr(g) + 4 * g_off, ptr(y_act) + 4 * y_off,
+         None if f_real is None else ptr(f_real) + 4 * r_off, float(w), ptr(wdev), float(slope),
+         rows, Cc, ld, ptr(colsum))
+
+
+def zeros_many(shapes, device):
+    """Several zero-initialised tensors carved from ONE zeroed allocation (one fill launch instead
+    of one per tensor); every piece starts on a 64-float boundary."""
+    sizes = []
+    for sh in shapes:
+        n = 1
+        for v in sh:
+            n *= v
+        sizes.append(n)
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    flat = zeros(max(total, 1), device=device)
+    return [flat[o:o + n].view(*sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
 def period_fold(out, x, B, T, p, H):
     call("f2g_period_fold", ptr(out), ptr(x), B, T, p, H)
 

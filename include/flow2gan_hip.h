@@ -312,6 +312,12 @@ int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w, co
 /* MPD input shaping (discriminators.py:82-90): right reflect-pad to a multiple of p and lay the
  * (B,1,T'/p,p) image out channels-last per column: out[((b*p + w)*H + h)] = x[b, h*p + w].
  * Backward folds it back (gx +=). */
+/* The same on a (rows, C) map (C, ld multiples of 4) fused with the column sums of the result:
+ * colsum[c] += sum_r g[r,c] after the update -- the bias gradient of the conv that produced y_act
+ * (one pass over g instead of lrelu_bwd + colsum).  colsum may be NULL. */
+int f2g_lrelu_bwd_colsum(float* g, const float* y_act, const float* f_real, float w,
+                         const float* wdev, float slope, int32_t rows, int32_t C, int64_t ld,
+                         float* colsum, f2g_stream_t stream);
 int f2g_period_fold(float* out, const float* x, int32_t B, int32_t T, int32_t p, int32_t H,
                     f2g_stream_t stream);
 int f2g_period_fold_bwd(float* gx, const float* gout, int32_t B, int32_t T, int32_t p, int32_t H,
