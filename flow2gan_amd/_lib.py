@@ -84,6 +84,14 @@ class Conv32Desc(C.Structure):  # == f2g_conv32_desc
                 ("_pad", C.c_int32), ("y", C.c_void_p), ("y_seq", C.c_int64), ("y_line", C.c_int64)]
 
 
+class Conv2chDesc(C.Structure):  # == f2g_conv2ch_desc
+    _fields_ = [("x", C.c_void_p), ("x_seq", C.c_int64), ("x_line", C.c_int64),
+                ("S", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("_pad", C.c_int32),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("lrelu_slope", C.c_float),
+                ("_pad2", C.c_int32), ("y", C.c_void_p), ("gw", C.c_void_p), ("wt", C.c_void_p),
+                ("gx", C.c_void_p), ("gx_seq", C.c_int64), ("gx_line", C.c_int64)]
+
+
 class SadamGroup(C.Structure):  # == f2g_sadam_group
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("scalar_lr_scale", C.c_float), ("eps", C.c_float), ("param_min_rms", C.c_float),
@@ -138,6 +146,10 @@ _SIGS = {
     "f2g_fill": [_P, _F, _L],
     "f2g_log_clip": [_P, _L, _F],
     "f2g_conv32_s2_fwd": [C.POINTER(Conv32Desc)],
+    "f2g_conv32_s2_dgrad": [C.POINTER(Conv32Desc)],
+    "f2g_conv2ch_fwd": [C.POINTER(Conv2chDesc)],
+    "f2g_conv2ch_wgrad": [C.POINTER(Conv2chDesc)],
+    "f2g_conv2ch_dgrad": [C.POINTER(Conv2chDesc)],
     "f2g_wave_stats": [_P, _L, _L, _I, _I, _P, _P],
     "f2g_wave_gain": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P],
     "f2g_sadam_stats": [_P, _P, _I, _P, _I],

@@ -1,0 +1,240 @@
+// First layer of every band stack of the multi-resolution STFT discriminator: Conv2d(2, 32, (3, 9),
+// stride (1, 1), padding (1, 4)) over a frequency band of the complex spectrogram (reference
+// discriminators.py:171,195-203), forward, weight gradient and data gradient.
+//
+// As implicit GEMMs these are K = 54 / N = 2 problems (measured: 18 / 12 / 4 TFLOP/s, 15 ms of a
+// 290 ms step for 0.4 % of its FLOPs): the reduction is shorter than one K slab, the 27 taps of a
+// pixel overlap those of its neighbours, and the data gradient has two output columns.  Direct
+// kernels instead: a block stages the (rows+2) x (32+8) input patch of its tile once in LDS (a few
+// hundred floats per channel plane), the forward / weight gradient feed v_mfma_f32_32x32x2_f32
+// with ONE tap per instruction (its two k slots are the two input channels), the data gradient is
+// a VALU kernel (two outputs per pixel).  All three are bound by the 32-channel side of the layer
+// in HBM (128 B per pixel), not by arithmetic.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KH = 3, KW = 9, NTAP = KH * KW, CO = 32;
+constexpr int TW = 32;                 // tile columns (= MFMA rows: one pixel per lane)
+constexpr int PW = TW + KW - 1;        // staged columns: 40
+constexpr int FTH = 8;                 // forward / wgrad tile rows
+constexpr int FPH = FTH + KH - 1;      // staged rows: 10
+
+// stage plane[ci][r][c] = x[h0 - 1 + r][w0 - 4 + c][ci] (0 outside the band image)
+__device__ __forceinline__ void stage_patch(float* plane, const f2g_conv2ch_desc& d,
+                                            const float* xs, int h0, int w0, int rows, int tid,
+                                            int nthreads) {
+  for (int i = tid; i < rows * PW; i += nthreads) {
+    const int r = i / PW, c = i - r * PW;
+    const int h = h0 - 1 + r, w = w0 - 4 + c;
+    float2 v = make_float2(0.f, 0.f);
+    if (h >= 0 && h < d.H && w >= 0 && w < d.W)
+      v = *reinterpret_cast<const float2*>(xs + (long long)h * d.x_line + (long long)w * 2);
+    plane[i] = v.x;
+    plane[rows * PW + i] = v.y;
+  }
+}
+
+// ---- forward: y[px, co] = lrelu(b[co] + sum_{tap, ci} w[co][tap][ci] x[px + tap][ci]) ----------
+__global__ __launch_bounds__(256) void conv2ch_fwd_kernel(const f2g_conv2ch_desc d) {
+  __shared__ float plane[2 * FPH * PW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int tiles_w = (d.W + TW - 1) / TW;
+  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+  const int s = blockIdx.y;
+  const int h0 = th * FTH, w0 = tw * TW;
+  stage_patch(plane, d, d.x + (long long)s * d.x_seq, h0, w0, FPH, tid, 256);
+  // B fragments of all 27 taps: lane (co = li, k slot = ci = h) holds w[co][tap][ci]
+  float bw[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) bw[t] = d.w[li * (NTAP * 2) + t * 2 + h];
+  const float bias = d.bias ? d.bias[li] : 0.f;
+  __syncthreads();
+  const float* pl = plane + h * (FPH * PW);
+#pragma unroll
+  for (int rr = 0; rr < FTH / 4; ++rr) {
+    const int row = wave + 4 * rr;              // tile row of this wave
+    if (h0 + row >= d.H) break;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = bias;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      const int dh = t / KW, j = t - dh * KW;
+      const float a = pl[(row + dh) * PW + li + j];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[t], acc, 0, 0, 0);
+    }
+    float* yrow = d.y + ((long long)s * d.H + h0 + row) * (long long)d.W * CO;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int col = w0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (col < d.W) {
+        float v = acc[e];
+        if (d.lrelu_slope != 0.f) v = v > 0.f ? v : d.lrelu_slope * v;
+        yrow[(long long)col * CO + li] = v;
+      }
+    }
+  }
+}
+
+// ---- weight gradient: gw[co][tap*2+ci] += sum_px g[px][co] x[px + tap][ci] -----------------------
+// MFMA rows = co, columns = the 54 (tap, ci) pairs (two 32-column tiles), reduction = pixels: the A
+// fragment (g[px][co]) is read straight from global memory (coalesced 128-byte rows), the B
+// fragment is gathered from the staged patch.  A block walks `tiles_per_block` tiles and leaves
+// with one atomic per output element.
+__global__ __launch_bounds__(256) void conv2ch_wgrad_kernel(const f2g_conv2ch_desc d, int tiles_h,
+                                                            int tiles_w, int tiles_per_block) {
+  __shared__ float plane[2 * FPH * PW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int ntiles = d.S * tiles_h * tiles_w;
+  // this lane's two gather columns n = li, li + 32 -> (tap, ci) -> offset inside the patch
+  int boff[2];
+  bool bok[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = li + 32 * nt;
+    bok[nt] = n < NTAP * 2;
+    const int t = bok[nt] ? n >> 1 : 0, ci = n & 1;
+    const int dh = t / KW, j = t - dh * KW;
+    boff[nt] = ci * (FPH * PW) + dh * PW + j;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+  const int t0 = blockIdx.x * tiles_per_block;
+  for (int ti = t0; ti < t0 + tiles_per_block && ti < ntiles; ++ti) {
+    const int s = ti / (tiles_h * tiles_w), rem = ti - s * (tiles_h * tiles_w);
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int h0 = th * FTH, w0 = tw * TW;
+    __syncthreads();   // the previous tile's readers are done
+    stage_patch(plane, d, d.x + (long long)s * d.x_seq, h0, w0, FPH, tid, 256);
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < FTH / 4; ++rr) {
+      const int row = wave + 4 * rr;
+      if (h0 + row >= d.H) break;
+      const float* grow = d.y + (((long long)s * d.H + h0 + row) * (long long)d.W + w0) * CO + li;
+      const int wlim = d.W - w0;   // valid columns of this tile row
+#pragma unroll
+      for (int st = 0; st < TW / 2; ++st) {
+        const int col = 2 * st + h;                  // k slot h of step st = tile column
+        const float a = col < wlim ? grow[(long long)col * CO] : 0.f;
+        const float b0 = bok[0] ? plane[boff[0] + row * PW + col] : 0.f;
+        const float b1 = bok[1] ? plane[boff[1] + row * PW + col] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = li + 32 * nt;
+    if (n >= NTAP * 2) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+      atomicAdd(d.gw + co * (NTAP * 2) + n, acc[nt][e]);
+    }
+  }
+}
+
+// ---- data gradient: gx[px][ci] = sum_{tap, co} g[px - tap][co] w[co][tap][ci] ---------------------
+// Two outputs per pixel: VALU.  A block stages the gradient patch of its 8 x 32 pixels ((8+2) x
+// (32+8) pixels x 32 channels, 36-float pitch) and every thread walks the 27 taps x 32 channels of
+// its pixel with float4 LDS reads; the weights are wave-uniform (scalar operands).
+constexpr int DTH = 8;
+constexpr int DPH = DTH + KH - 1;
+constexpr int GP = 36;   // floats per staged pixel
+
+__global__ __launch_bounds__(256) void conv2ch_dgrad_kernel(const f2g_conv2ch_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float gp[];     // [DPH][PW][GP]
+  const int tid = threadIdx.x;
+  const int tiles_w = (d.W + TW - 1) / TW;
+  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+  const int s = blockIdx.y;
+  const int h0 = th * DTH, w0 = tw * TW;
+  const float* gs = d.y + (long long)s * d.H * d.W * CO;
+  // patch pixel (r, c) = g[h0 - 1 + r][w0 - 4 + c]
+  for (int i = tid; i < DPH * PW * (CO / 4); i += 256) {
+    const int c4 = i & 7, px = i >> 3;
+    const int r = px / PW, c = px - r * PW;
+    const int hh = h0 - 1 + r, ww = w0 - 4 + c;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W)
+      v = *reinterpret_cast<const float4*>(gs + ((long long)hh * d.W + ww) * CO + c4 * 4);
+    *reinterpret_cast<float4*>(gp + px * GP + c4 * 4) = v;
+  }
+  __syncthreads();
+  const int pw = tid & 31, ph = tid >> 5;        // 8 rows x 32 columns
+  float a0 = 0.f, a1 = 0.f;
+  // gx[h][x] takes g[h + 1 - dh][x + 4 - j]  ->  patch row ph + 2 - dh, column pw + 8 - j
+#pragma unroll
+  for (int dh = 0; dh < KH; ++dh)
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      const float* g0 = gp + ((ph + 2 - dh) * PW + pw + 8 - j) * GP;
+      const float* wt = d.wt + (dh * KW + j) * (2 * CO);     // [tap][ci][co], uniform
+#pragma unroll
+      for (int c4 = 0; c4 < CO / 4; ++c4) {
+        const float4 gv = *reinterpret_cast<const float4*>(g0 + c4 * 4);
+        a0 += gv.x * wt[c4 * 4] + gv.y * wt[c4 * 4 + 1] + gv.z * wt[c4 * 4 + 2] + gv.w * wt[c4 * 4 + 3];
+        a1 += gv.x * wt[CO + c4 * 4] + gv.y * wt[CO + c4 * 4 + 1] + gv.z * wt[CO + c4 * 4 + 2] +
+              gv.w * wt[CO + c4 * 4 + 3];
+      }
+    }
+  const int hh = h0 + ph, ww = w0 + pw;
+  if (hh < d.H && ww < d.W) {
+    float* o = d.gx + (long long)s * d.gx_seq + (long long)hh * d.gx_line + (long long)ww * 2;
+    *reinterpret_cast<float2*>(o) = make_float2(a0, a1);
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+static bool conv2ch_ok(const f2g_conv2ch_desc* d) {
+  return d && d->S > 0 && d->H > 0 && d->W > 0;
+}
+
+extern "C" int f2g_conv2ch_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
+  if (!d || !d->x || !d->w || !d->y || (d->x_line & 1) || (d->x_seq & 1)) return F2G_EINVAL;
+  if (!conv2ch_ok(d)) return F2G_OK;
+  const int tiles = ((d->H + FTH - 1) / FTH) * ((d->W + TW - 1) / TW);
+  hipLaunchKernelGGL(conv2ch_fwd_kernel, dim3(tiles, d->S), dim3(256), 0, ST, *d);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_conv2ch_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
+  if (!d || !d->x || !d->y || !d->gw || (d->x_line & 1) || (d->x_seq & 1)) return F2G_EINVAL;
+  if (!conv2ch_ok(d)) return F2G_OK;
+  const int tiles_h = (d->H + FTH - 1) / FTH, tiles_w = (d->W + TW - 1) / TW;
+  const int ntiles = d->S * tiles_h * tiles_w;
+  int per = (ntiles + 2047) / 2048;      // <= 2048 blocks: bounds the atomics at 3.5 M per launch
+  if (per < 1) per = 1;
+  hipLaunchKernelGGL(conv2ch_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(256), 0, ST, *d,
+                     tiles_h, tiles_w, per);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_conv2ch_dgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
+  if (!d || !d->y || !d->wt || !d->gx || (d->gx_line & 1) || (d->gx_seq & 1)) return F2G_EINVAL;
+  if ((((uintptr_t)d->y) & 15) || (((uintptr_t)d->gx) & 7)) return F2G_EINVAL;
+  if (!conv2ch_ok(d)) return F2G_OK;
+  const size_t smem = (size_t)DPH * PW * GP * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2ch_dgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int tiles = ((d->H + DTH - 1) / DTH) * ((d->W + TW - 1) / TW);
+  hipLaunchKernelGGL(conv2ch_dgrad_kernel, dim3(tiles, d->S), dim3(256), smem, ST, *d);
+  return f2g_check_launch();
+}

@@ -123,6 +123,103 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_
   }
 }
 
+// ---- data gradient of the same layer (transposed conv) -------------------------------------
+// gx[h, x, ci] = sum_{dh, j, co} g[h + 1 - dh, (x + 4 - j) / 2, co] * w[co, ci, dh, j]   over the taps
+// with x + 4 - j even.  Input columns of one parity e = x & 1 use the taps j = e + 2u (5 taps for even
+// x, 4 for odd) and read CONSECUTIVE gradient columns m + 2 - u (x = 2m + e), so per parity this is a
+// stride-1 direct convolution over g: a block stages the gradient patch of its 8 x 16 outputs once
+// (10 rows x 20 columns x 32 channels) and streams the 15 / 12 transposed 32 x 32 weight tiles.
+// As residue GEMMs (N = 32, windows re-gathered per tap) the same work ran at 65-70 TFLOP/s.
+// d.x = g (S, H, Wout, 32), d.y = gx (S, H, Win, 32), d.w = wT[27 taps][ci][co].
+constexpr int GW = TW + 4;               // staged gradient columns
+constexpr int GSUB = IH * GW * PITCH;
+
+__global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv32_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* At = sm;                 // [IH][GW][PITCH]
+  float* Bt = sm + GSUB;          // [2 buffers][TG taps][C][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int e = blockIdx.z;                      // parity of the input column
+  const int Wp = (d.Win + 1 - e) / 2;            // columns of this parity
+  const int tiles_w = ((d.Win + 1) / 2 + TW - 1) / TW;
+  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+  const int s = blockIdx.y;
+  const int h0 = th * TH, m0 = tw * TW;
+  if (m0 >= Wp) return;
+  const float* gs = d.x + (long long)s * d.x_seq;
+  for (int i = tid; i < IH * GW * (C / 4); i += 512) {
+    const int c4 = i & 7;
+    const int px = i >> 3;
+    const int r = px / GW, xc = px - r * GW;
+    const int h = h0 - 1 + r, c = m0 - 2 + xc;
+    const bool ok = h >= 0 && h < d.H && c >= 0 && c < d.Wout;
+    const float* p = ok ? gs + (long long)h * d.x_line + (long long)c * C + c4 * 4 : c32_zero;
+    *reinterpret_cast<float4*>(At + (r * GW + xc) * PITCH + c4 * 4) = *reinterpret_cast<const float4*>(p);
+  }
+  const int nu = e ? 4 : 5, NT = KH * nu;
+  // weights: thread = (tap of the group, ci, 4 output channels of the forward conv)
+  const int wu = tid >> 8, wci = (tid & 255) >> 3, wc4 = tid & 7;
+  auto wsrc = [&](int ti) {                      // tap index inside this parity -> weight tile
+    ti = ti < NT ? ti : NT - 1;
+    const int dh = ti / nu, u = ti - dh * nu;
+    return d.w + (long long)(dh * KW + e + 2 * u) * (C * C) + wci * C + wc4 * 4;
+  };
+  *reinterpret_cast<float4*>(Bt + wu * WB + wci * PITCH + wc4 * 4) =
+      *reinterpret_cast<const float4*>(wsrc(wu));
+  __syncthreads();
+
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc2[q] = 0.f; }
+  const int pg = wave & 3, myu = wave >> 2;
+  const int p = pg * 32 + li;
+  const int ph = p >> 4, pw = p & 15;
+  const int kk0 = hh * 16;
+  const int NG = (NT + TG - 1) / TG;
+  for (int gidx = 0; gidx < NG; ++gidx) {
+    const int cur = gidx & 1;
+    const float4 wn = *reinterpret_cast<const float4*>(wsrc((gidx + 1) * TG + wu));
+    {
+      const int ti = gidx * TG + myu;
+      if (ti < NT) {
+        const int dh = ti / nu, u = ti - dh * nu;
+        const float* Ab = At + ((ph + 2 - dh) * GW + pw + 4 - u) * PITCH + kk0;
+        const float* Bb = Bt + (cur * TG + myu) * WB + li * PITCH + kk0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const float4 a = *reinterpret_cast<const float4*>(Ab + s4 * 4);
+          const float4 b = *reinterpret_cast<const float4*>(Bb + s4 * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc2, 0, 0, 0);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(Bt + ((cur ^ 1) * TG + wu) * WB + wci * PITCH + wc4 * 4) = wn;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] += acc2[q];
+  float* red = At;  // [4 pixel groups][16][64 lanes] = 16 KB <= the patch
+  if (myu == 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[(pg * 16 + q) * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (myu == 1) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] += red[(pg * 16 + q) * 64 + lane];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int px = pg * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+    const int oh = h0 + (px >> 4), ox = 2 * (m0 + (px & 15)) + e;
+    if (oh < d.H && ox < d.Win)
+      d.y[(long long)s * d.y_seq + (long long)oh * d.y_line + (long long)ox * C + li] = acc[q];
+  }
+}
+
 }  // namespace
 
 extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
@@ -141,5 +238,24 @@ extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) 
   const int tiles = ((d->H + TH - 1) / TH) * ((d->Wout + TW - 1) / TW);
   hipLaunchKernelGGL(conv32_s2_fwd_kernel, dim3(tiles, d->S), dim3(512), smem, (hipStream_t)stream,
                      *d);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream) {
+  if (!d || !d->x || !d->w || !d->y) return F2G_EINVAL;
+  if (d->S <= 0 || d->H <= 0 || d->Win <= 0) return F2G_OK;
+  if (d->Wout != (d->Win + 8 - 9) / 2 + 1) return F2G_EINVAL;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
+  const size_t smem = (size_t)(GSUB + 2 * TG * WB) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int tiles = ((d->H + TH - 1) / TH) * (((d->Win + 1) / 2 + TW - 1) / TW);
+  hipLaunchKernelGGL(conv32_s2_dgrad_kernel, dim3(tiles, d->S, 2), dim3(512), smem,
+                     (hipStream_t)stream, *d);
   return f2g_check_launch();
 }

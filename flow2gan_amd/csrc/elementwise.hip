@@ -411,12 +411,8 @@ __global__ __launch_bounds__(256) void lrelu_bwd_cs_kernel(float* g, const float
     float4* g4 = reinterpret_cast<float4*>(g);
     const float4* y4 = reinterpret_cast<const float4*>(y_act);
     const float4* f4 = reinterpret_cast<const float4*>(f_real);
-    for (int r = r0 + rl; r < r1; r += RS) {
-      const long long off = (long long)r * ld4 + c;
-      const float4 y = y4[off];
-      float4 gv = g4[off];
+    auto upd = [&](float4 gv, const float4 y, const float4 f) {
       if (f_real) {
-        const float4 f = f4[off];
         const float dx = y.x - f.x, dy = y.y - f.y, dz = y.z - f.z, dw = y.w - f.w;
         gv.x += wg * (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f));
         gv.y += wg * (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f));
@@ -425,8 +421,30 @@ __global__ __launch_bounds__(256) void lrelu_bwd_cs_kernel(float* g, const float
       }
       gv.x *= y.x > 0.f ? 1.f : slope; gv.y *= y.y > 0.f ? 1.f : slope;
       gv.z *= y.z > 0.f ? 1.f : slope; gv.w *= y.w > 0.f ? 1.f : slope;
-      g4[off] = gv;
       s.x += gv.x; s.y += gv.y; s.z += gv.z; s.w += gv.w;
+      return gv;
+    };
+    // four rows per iteration, every load issued before anything is consumed (these kernels are a
+    // memory-level-parallelism problem)
+    int r = r0 + rl;
+    for (; r + 3 * RS < r1; r += 4 * RS) {
+      long long off[4];
+      float4 y[4], gv[4], f[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) off[k] = (long long)(r + k * RS) * ld4 + c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { y[k] = y4[off[k]]; gv[k] = g4[off[k]]; }
+      if (f_real) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = f4[off[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g4[off[k]] = upd(gv[k], y[k], f[k]);
+    }
+    for (; r < r1; r += RS) {
+      const long long off = (long long)r * ld4 + c;
+      const float4 f = f_real ? f4[off] : make_float4(0.f, 0.f, 0.f, 0.f);
+      g4[off] = upd(g4[off], y4[off], f);
     }
   }
   if (!colsum) return;
@@ -471,7 +489,7 @@ extern "C" int f2g_lrelu_bwd_colsum(float* g, const float* y_act, const float* f
   int cs_log2 = 0;
   while ((1 << cs_log2) < C4 && cs_log2 < 8) ++cs_log2;
   const int CS = 1 << cs_log2, RS = 256 >> cs_log2;
-  int rows_per = 16 * RS;  // 16 rows per thread
+  int rows_per = 32 * RS;  // 32 rows per thread
   if (rows_per > rows) rows_per = rows;
   dim3 grid((C4 + CS - 1) / CS, (rows + rows_per - 1) / rows_per);
   hipLaunchKernelGGL(lrelu_bwd_cs_kernel, grid, dim3(256), 0, ST, g, y_act, f_real, w, wdev, slope,

@@ -377,7 +377,11 @@ def _mrd_forward_one(x2, win: int, prm: list):
                           seq_stride=Ft * ldp, offset=lo * 2)
             else:
                 A = win2d(x, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2)
-            if l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+            if l == 0 and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+                # 2 -> 32 channels over the band of the spectrogram: direct kernel (conv2ch.hip)
+                y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
+                ops.conv2ch_fwd(packed, Ft * ldp, ldp, lo * 2, S, Ft, Win, wp, b, SLOPE, y)
+            elif l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
                 # 32 -> 32 channels, (3, 9) taps, stride (1, 2): direct LDS-tiled kernel (conv32.hip)
                 y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
                 ops.conv32_s2_fwd(x, S, Ft, Win, Wout, wp, b, SLOPE, y)
@@ -408,6 +412,16 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
     Cin, kh, kw = w.shape[1], w.shape[2], w.shape[3]
     dev = g_pre.device
     pw = kw // 2
+    if (DIRECT_CONV32 and ops.GEMM_PRECISION == 0 and Cin == MRD_CH and Cout == MRD_CH and kw == 9
+            and sw == 2 and x_line is None and x_off == 0):
+        # 32 -> 32 channels, (3, 9) taps, stride (1, 2): direct transposed convolution (conv32.hip)
+        def build_t(t):
+            out = ops.empty(kh * kw, Cin, Cout, device=t.device)
+            ops.permute4(out, t, (kh * kw, Cin, Cout, 1), (1, kh * kw, Cin * kh * kw, 0))
+            return out
+        wT = ops.derived(w, "dgrad_taps", build_t)
+        ops.conv32_s2_dgrad(g_pre, S, H, Win, Wout, wT, gx, g_seq=g_seq, g_line=g_line, g_off=g_off)
+        return gx
     if x_line is None:
         x_line = Win * Cin
     for rho, j0, ntw, e0, Lq in _residues(kw, sw, pw, Win):
@@ -569,8 +583,11 @@ class MRDLossFn(torch.autograd.Function):
                         else:
                             dY = mat(g, S * Ft * Wout, C)
                         tiles = ((3 * kw * Cin + 255) // 256)
-                        gemm(dY, X, gwp, form=2, atomic=True,
-                             split_k=ops.split_for(X.rows, tiles))
+                        if l == 0 and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+                            ops.conv2ch_wgrad(packed, Ft * ldp, ldp, lo * 2, S, Ft, Win, g, gwp)
+                        else:
+                            gemm(dY, X, gwp, form=2, atomic=True,
+                                 split_k=ops.split_for(X.rows, tiles))
                         grads_w[(bi * 5 + l) * 2] = unpack_conv_grad(gwp, w.shape)
                         if l == 4:
                             gb = ops.zeros(C, device=dev)
@@ -583,6 +600,13 @@ class MRDLossFn(torch.autograd.Function):
                         _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, gx, g_line=dy_line,
                                       g_seq=dy_seq, g_off=dy_off)
                         g = gx
+                    elif not train_disc and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+                        def build_c2t(t):
+                            out = ops.empty(27, 2, C, device=t.device)   # [tap][ci][co]
+                            ops.permute4(out, t, (27, 2, C, 1), (1, 27, 2 * 27, 0))
+                            return out
+                        ops.conv2ch_dgrad(g, Sx, Ft, Win, ops.derived(w, "c2t", build_c2t), g_packed,
+                                          Ft * ldp, ldp, lo * 2)
                     elif not train_disc:
                         _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, g_packed, g_line=dy_line,
                                       g_seq=dy_seq, g_off=dy_off, x_line=ldp, x_off=lo * 2)

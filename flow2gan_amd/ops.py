@@ -230,6 +230,67 @@ def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope:
     return y
 
 
+def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, g_line=None,
+                    g_off: int = 0):
+    """Data gradient of Conv2d(32, 32, (3, 9), stride (1, 2), padding (1, 4)): g (S, H, Wout, 32)
+    (optionally strided / offset) -> gx (S*H*Win, 32); wT = (27, 32, 32) tiles [tap][ci][co]."""
+    d = L.Conv32Desc()
+    d.x = ptr(g) + 4 * g_off
+    d.x_line = g_line if g_line is not None else Wout * 32
+    d.x_seq = g_seq if g_seq is not None else H * d.x_line
+    d.S, d.H, d.Win, d.Wout = S, H, Win, Wout
+    d.w, d.bias, d.lrelu_slope = ptr(wT), None, 0.0
+    d.y, d.y_seq, d.y_line = ptr(gx), H * Win * 32, Win * 32
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_conv32_s2_dgrad", C.byref(d)),
+                        2.0 * S * H * Wout * 32 * 27 * 32, (1, S * H * Win, 32, 27 * 32 // 2))
+    else:
+        call("f2g_conv32_s2_dgrad", C.byref(d))
+    return gx
+
+
+def _conv2ch_desc(x, x_seq, x_line, x_off, S, H, W):
+    d = L.Conv2chDesc()
+    d.x = None if x is None else ptr(x) + 4 * x_off
+    d.x_seq, d.x_line = x_seq, x_line
+    d.S, d.H, d.W = S, H, W
+    return d
+
+
+def _timed(name, d, flops, shape):
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call(name, C.byref(d)), flops, shape)
+    else:
+        call(name, C.byref(d))
+
+
+def conv2ch_fwd(x, x_seq, x_line, x_off, S, H, W, w_packed, bias, slope, y):
+    """Conv2d(2, 32, (3, 9), padding (1, 4)) + bias + leaky ReLU on a band (S, H, W, 2) of the
+    interleaved spectrogram -> y (S*H*W, 32); w_packed (32, 54) as pack_conv_weight gives."""
+    d = _conv2ch_desc(x, x_seq, x_line, x_off, S, H, W)
+    d.w, d.bias, d.lrelu_slope, d.y = ptr(w_packed), ptr(bias), slope, ptr(y)
+    _timed("f2g_conv2ch_fwd", d, 2.0 * S * H * W * 32 * 54, (0, S * H * W, 32, 54))
+    return y
+
+
+def conv2ch_wgrad(x, x_seq, x_line, x_off, S, H, W, g, gw):
+    """gw (32, 54) += weight gradient of that layer; g = (S*H*W, 32) pre-activation gradient."""
+    d = _conv2ch_desc(x, x_seq, x_line, x_off, S, H, W)
+    d.y, d.gw = ptr(g), ptr(gw)
+    _timed("f2g_conv2ch_wgrad", d, 2.0 * S * H * W * 32 * 54, (2, 32, 54, S * H * W))
+    return gw
+
+
+def conv2ch_dgrad(g, S, H, W, wt, gx, gx_seq, gx_line, gx_off):
+    """gx band (S, H, W, 2) (strided, overwritten) = data gradient; wt = (27, 2, 32)."""
+    d = _conv2ch_desc(None, 0, 0, 0, S, H, W)
+    d.y, d.wt = ptr(g), ptr(wt)
+    d.gx = ptr(gx) + 4 * gx_off
+    d.gx_seq, d.gx_line = gx_seq, gx_line
+    _timed("f2g_conv2ch_dgrad", d, 2.0 * S * H * W * 32 * 54, (1, S * H * W, 2, 864))
+    return gx
+
+
 class GemmTimer:
     """bench.py instrumentation: HIP events around every f2g_gemm launch on the launch stream and
     the launch's algorithmic FLOPs (2 * M * N * K of the implicit GEMM it represents)."""

@@ -349,6 +349,36 @@ typedef struct {
   int64_t y_seq, y_line;
 } f2g_conv32_desc;
 int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream);
+/* Data gradient of that layer as a direct transposed convolution (discriminators.py:171-181
+ * backward): x = gradient of the layer's pre-activation (S, H, Wout, 32), y = gradient of its input
+ * (S, H, Win, 32, fully overwritten), w = the weights as 27 transposed tiles [tap][ci][co]
+ * (tap = kh*9 + kw); bias / lrelu_slope unused. */
+int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream);
+
+/* First layer of every MRD band stack, Conv2d(2, 32, (3, 9), stride 1, padding (1, 4))
+ * (discriminators.py:171,195-203), as direct kernels (conv2ch.hip).  The input is a frequency band
+ * of the interleaved complex spectrogram: image (S, H frames, W bins, 2) with explicit sequence /
+ * line strides (floats); the 32-channel side is dense (S*H*W, 32).
+ *   fwd  : y = lrelu(conv(x; w) + bias),  w = (32, 27*2) window-major, channel-minor
+ *   wgrad: gw (32, 27*2) += sum_px y[px, :]^T (x) patch(px)      (y = gradient of the pre-activation)
+ *   dgrad: gx (same layout as x) = transposed conv of y with wt = [27 taps][2][32]   (overwrites) */
+typedef struct {
+  const float* x;
+  int64_t x_seq, x_line;
+  int32_t S, H, W, _pad;
+  const float* w;
+  const float* bias;
+  float lrelu_slope;
+  int32_t _pad2;
+  float* y;          /* fwd: output; wgrad / dgrad: the gradient map (read) */
+  float* gw;
+  const float* wt;
+  float* gx;
+  int64_t gx_seq, gx_line;
+} f2g_conv2ch_desc;
+int f2g_conv2ch_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream);
+int f2g_conv2ch_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream);
+int f2g_conv2ch_dgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream);
 
 /* ---- on-device data front end (dataset.py:122-175).  x: (B, C, T) crops with
  * explicit item / channel strides (floats); lens[b] = valid samples of item b.

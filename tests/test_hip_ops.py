@@ -459,3 +459,52 @@ def test_direct_conv32_matches_implicit_gemm(ops, S, H, Win):
     y2 = torch.empty_like(y)
     ops.gemm(ops.win2d(g(x), S, H, Win, 32, Wout, 3, 9, 2, 1, 4), ops.mat(g(wp)), y2, bias=g(b), lrelu=0.1)
     close(y, y2.cpu().double(), name="conv32-vs-gemm")
+
+
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (4, 17, 26), (1, 9, 33)])
+def test_direct_conv32_dgrad_matches_autograd(ops, S, H, Win):
+    """conv32.hip data gradient (direct transposed conv per column parity) against torch's conv2d
+    backward in fp64, incl. odd widths and partial tiles."""
+    Wout = (Win - 1) // 2 + 1
+    gy = rnd(S * H * Wout, 32, seed=4)
+    w = rnd(32, 32, 3, 9, seed=2, scale=0.05)
+    wT = w.permute(2, 3, 1, 0).reshape(27, 32, 32).contiguous()        # [tap][ci][co]
+    gx = torch.full((S * H * Win, 32), 7.0, device=DEV)
+    ops.conv32_s2_dgrad(g(gy), S, H, Win, Wout, g(wT), gx)
+    x = torch.zeros(S, 32, H, Win, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w.double(), None, stride=(1, 2), padding=(1, 4))
+    y.backward(gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
+    ref = x.grad.permute(0, 2, 3, 1).reshape(S * H * Win, 32)
+    close(gx, ref, name="conv32 dgrad")
+
+
+@pytest.mark.parametrize("S,H,W,lo,Wtot", [(2, 11, 34, 7, 50), (3, 8, 32, 0, 32), (1, 5, 3, 2, 9), (2, 21, 77, 10, 100)])
+def test_conv2ch_direct_kernels_match_autograd(ops, S, H, W, lo, Wtot):
+    """conv2ch.hip (first MRD layer, 2 -> 32 channels on a band of the interleaved spectrogram):
+    forward, weight gradient and data gradient against torch conv2d + autograd in fp64."""
+    ld = ops.pad4(2 * Wtot)
+    spec = torch.zeros(S * H, ld)
+    spec[:, :2 * Wtot] = rnd(S * H, 2 * Wtot, seed=1)
+    w, b = rnd(32, 2, 3, 9, seed=2, scale=0.2), rnd(32, seed=3)
+    wp = w.permute(0, 2, 3, 1).reshape(32, 54).contiguous()
+    y = torch.full((S * H * W, 32), 7.0, device=DEV)
+    sd = g(spec)
+    ops.conv2ch_fwd(sd, H * ld, ld, lo * 2, S, H, W, g(wp), g(b), 0.1, y)
+    x = spec[:, :2 * Wtot].reshape(S, H, Wtot, 2)[:, :, lo:lo + W].permute(0, 3, 1, 2).double()
+    x.requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    pre = torch.nn.functional.conv2d(x, wd, b.double(), padding=(1, 4))
+    ref = torch.nn.functional.leaky_relu(pre, 0.1)
+    close(y, ref.permute(0, 2, 3, 1).reshape(S * H * W, 32), name="conv2ch fwd")
+    gy = rnd(S * H * W, 32, seed=5)
+    pre.backward(gy.reshape(S, H, W, 32).permute(0, 3, 1, 2).double())
+    gw = torch.zeros(32, 54, device=DEV)
+    ops.conv2ch_wgrad(sd, H * ld, ld, lo * 2, S, H, W, g(gy), gw)
+    close(gw, wd.grad.permute(0, 2, 3, 1).reshape(32, 54), rtol=1e-4, name="conv2ch wgrad")
+    wt = w.permute(2, 3, 1, 0).reshape(27, 2, 32).contiguous()
+    gspec = torch.full((S * H, ld), 7.0, device=DEV)
+    ops.conv2ch_dgrad(g(gy), S, H, W, g(wt), gspec, H * ld, ld, lo * 2)
+    got = gspec[:, :2 * Wtot].reshape(S, H, Wtot, 2)[:, :, lo:lo + W]
+    close(got, x.grad.permute(0, 2, 3, 1), name="conv2ch dgrad")
+    rest = gspec[:, :2 * Wtot].reshape(S, H, Wtot, 2)
+    assert float(rest[:, :, :lo].min()) == 7.0 if lo > 0 else True     # outside the band: untouched
