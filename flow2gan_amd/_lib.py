@@ -150,6 +150,9 @@ _SIGS = {
     "f2g_conv2ch_fwd": [C.POINTER(Conv2chDesc)],
     "f2g_conv2ch_wgrad": [C.POINTER(Conv2chDesc)],
     "f2g_conv2ch_dgrad": [C.POINTER(Conv2chDesc)],
+    "f2g_convpost_fwd": [C.POINTER(Conv2chDesc)],
+    "f2g_convpost_wgrad": [C.POINTER(Conv2chDesc)],
+    "f2g_convpost_dgrad": [C.POINTER(Conv2chDesc)],
     "f2g_wave_stats": [_P, _L, _L, _I, _I, _P, _P],
     "f2g_wave_gain": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P],
     "f2g_sadam_stats": [_P, _P, _I, _P, _I],

@@ -195,6 +195,118 @@ __global__ __launch_bounds__(256) void conv2ch_dgrad_kernel(const f2g_conv2ch_de
   }
 }
 
+// ---- conv_post of a resolution: Conv2d(32, 1, (3, 3), padding (1, 1)) (discriminators.py:184) ----
+// One output channel: dot products of 288 floats per pixel.  As "narrow" implicit GEMMs (a wave per
+// output row, shuffle reduction) these cost 0.4 ms per call for 0.1 GFLOP; here a thread owns a
+// pixel and walks its 3 x 3 x 32 window in an LDS-staged patch (forward), a thread owns a weight
+// and walks the tile's pixels (weight gradient), or 8 threads share a pixel's 32 channels (data
+// gradient, bound by writing the 128-byte gradient rows).
+constexpr int QTH = 8, QTW = 32;
+constexpr int QPH = QTH + 2, QPW = QTW + 2;
+
+__device__ __forceinline__ void stage32(float* patch, const float* xs, int H, int W, int h0, int w0,
+                                        int tid) {
+  for (int i = tid; i < QPH * QPW * (CO / 4); i += 256) {
+    const int c4 = i & 7, px = i >> 3;
+    const int r = px / QPW, c = px - r * QPW;
+    const int hh = h0 - 1 + r, ww = w0 - 1 + c;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+      v = *reinterpret_cast<const float4*>(xs + ((long long)hh * W + ww) * CO + c4 * 4);
+    *reinterpret_cast<float4*>(patch + px * GP + c4 * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void convpost_fwd_kernel(const f2g_conv2ch_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];   // [QPH][QPW][GP]
+  const int tid = threadIdx.x;
+  const int tiles_w = (d.W + QTW - 1) / QTW;
+  const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
+  const int s = blockIdx.y;
+  const int h0 = th * QTH, w0 = tw * QTW;
+  stage32(patch, d.x + (long long)s * d.H * d.W * CO, d.H, d.W, h0, w0, tid);
+  __syncthreads();
+  const int pw = tid & 31, ph = tid >> 5;
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float* x0 = patch + ((ph + t / 3) * QPW + pw + t % 3) * GP;
+    const float* wt = d.w + t * CO;                      // [tap][ci], uniform
+#pragma unroll
+    for (int c4 = 0; c4 < CO / 4; c4 += 2) {
+      const float4 u = *reinterpret_cast<const float4*>(x0 + c4 * 4);
+      const float4 v = *reinterpret_cast<const float4*>(x0 + c4 * 4 + 4);
+      a0 += u.x * wt[c4 * 4] + u.y * wt[c4 * 4 + 1] + u.z * wt[c4 * 4 + 2] + u.w * wt[c4 * 4 + 3];
+      a1 += v.x * wt[c4 * 4 + 4] + v.y * wt[c4 * 4 + 5] + v.z * wt[c4 * 4 + 6] + v.w * wt[c4 * 4 + 7];
+    }
+  }
+  const int hh = h0 + ph, ww = w0 + pw;
+  if (hh < d.H && ww < d.W)
+    d.y[((long long)s * d.H + hh) * d.W + ww] = a0 + a1 + (d.bias ? d.bias[0] : 0.f);
+}
+
+// gw[tap*32 + ci] += sum_px g[px] * x[px + tap][ci]; thread = one of the 288 weights
+__global__ __launch_bounds__(256) void convpost_wgrad_kernel(const f2g_conv2ch_desc d, int tiles_h,
+                                                             int tiles_w, int tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];   // patch + the tile's 256 gradients
+  float* gt = patch + QPH * QPW * GP;
+  const int tid = threadIdx.x;
+  const int ntiles = d.S * tiles_h * tiles_w;
+  // weights owned by this thread: k0 = tid (tap tid/32, ci tid%32) and, for tid < 32, k1 = 256 + tid
+  const int t0k = tid >> 5, c0k = tid & 31;
+  const int off0 = ((t0k / 3) * QPW + t0k % 3) * GP + c0k;
+  const int off1 = ((8 / 3) * QPW + 8 % 3) * GP + c0k;      // tap 8
+  float acc0 = 0.f, acc1 = 0.f;
+  const int tb = blockIdx.x * tiles_per_block;
+  for (int ti = tb; ti < tb + tiles_per_block && ti < ntiles; ++ti) {
+    const int s = ti / (tiles_h * tiles_w), rem = ti - s * (tiles_h * tiles_w);
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int h0 = th * QTH, w0 = tw * QTW;
+    __syncthreads();
+    stage32(patch, d.x + (long long)s * d.H * d.W * CO, d.H, d.W, h0, w0, tid);
+    {
+      const int pw = tid & 31, ph = tid >> 5;
+      const int hh = h0 + ph, ww = w0 + pw;
+      gt[tid] = (hh < d.H && ww < d.W) ? d.y[((long long)s * d.H + hh) * d.W + ww] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int px = 0; px < QTH * QTW; ++px) {
+      const float gv = gt[px];
+      const int pb = ((px >> 5) * QPW + (px & 31)) * GP;
+      acc0 += gv * patch[pb + off0];
+      if (tid < 32) acc1 += gv * patch[pb + off1];
+    }
+  }
+  atomicAdd(d.gw + tid, acc0);
+  if (tid < 32) atomicAdd(d.gw + 256 + tid, acc1);
+}
+
+// gx[px][ci] = sum_tap g[px - tap] * w[tap][ci]: 8 threads per pixel, 4 channels each
+__global__ __launch_bounds__(256) void convpost_dgrad_kernel(const f2g_conv2ch_desc d) {
+  const long long npx = (long long)d.S * d.H * d.W;
+  const int c4 = threadIdx.x & 7;
+  float4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(d.w + t * CO + c4 * 4);
+  for (long long i = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); i < npx;
+       i += (long long)gridDim.x * 32) {
+    const int ww = (int)(i % d.W);
+    const long long q = i / d.W;
+    const int hh = (int)(q % d.H);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int sh = hh + 1 - t / 3, sw = ww + 1 - t % 3;
+      if (sh >= 0 && sh < d.H && sw >= 0 && sw < d.W) {
+        const float gv = d.y[i + (long long)(1 - t / 3) * d.W + (1 - t % 3)];
+        a.x += gv * wv[t].x; a.y += gv * wv[t].y; a.z += gv * wv[t].z; a.w += gv * wv[t].w;
+      }
+    }
+    *reinterpret_cast<float4*>(d.gx + i * CO + c4 * 4) = a;
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -216,7 +328,7 @@ extern "C" int f2g_conv2ch_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream)
   if (!conv2ch_ok(d)) return F2G_OK;
   const int tiles_h = (d->H + FTH - 1) / FTH, tiles_w = (d->W + TW - 1) / TW;
   const int ntiles = d->S * tiles_h * tiles_w;
-  int per = (ntiles + 2047) / 2048;      // <= 2048 blocks: bounds the atomics at 3.5 M per launch
+  int per = (ntiles + 511) / 512;        // <= 512 blocks: 0.9 M atomics on 1728 addresses per launch
   if (per < 1) per = 1;
   hipLaunchKernelGGL(conv2ch_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(256), 0, ST, *d,
                      tiles_h, tiles_w, per);
@@ -236,5 +348,51 @@ extern "C" int f2g_conv2ch_dgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream)
   }
   const int tiles = ((d->H + DTH - 1) / DTH) * ((d->W + TW - 1) / TW);
   hipLaunchKernelGGL(conv2ch_dgrad_kernel, dim3(tiles, d->S), dim3(256), smem, ST, *d);
+  return f2g_check_launch();
+}
+
+// conv_post (32 -> 1, 3x3): x = (S, H, W, 32) dense, w = (9, 32) tap-major, y = scores (S*H*W)
+extern "C" int f2g_convpost_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
+  if (!d || !d->x || !d->w || !d->y || (((uintptr_t)d->x) & 15)) return F2G_EINVAL;
+  if (!conv2ch_ok(d)) return F2G_OK;
+  const size_t smem = (size_t)QPH * QPW * GP * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpost_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int tiles = ((d->H + QTH - 1) / QTH) * ((d->W + QTW - 1) / QTW);
+  hipLaunchKernelGGL(convpost_fwd_kernel, dim3(tiles, d->S), dim3(256), smem, ST, *d);
+  return f2g_check_launch();
+}
+
+// gw (9*32) += weight gradient; y = gradient of the scores (S*H*W)
+extern "C" int f2g_convpost_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
+  if (!d || !d->x || !d->y || !d->gw || (((uintptr_t)d->x) & 15)) return F2G_EINVAL;
+  if (!conv2ch_ok(d)) return F2G_OK;
+  const size_t smem = (size_t)(QPH * QPW * GP + QTH * QTW) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpost_wgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int tiles_h = (d->H + QTH - 1) / QTH, tiles_w = (d->W + QTW - 1) / QTW;
+  const int ntiles = d->S * tiles_h * tiles_w;
+  int per = (ntiles + 1023) / 1024;
+  if (per < 1) per = 1;
+  hipLaunchKernelGGL(convpost_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(256), smem, ST, *d,
+                     tiles_h, tiles_w, per);
+  return f2g_check_launch();
+}
+
+// gx (S*H*W, 32) = data gradient (overwrites); y = gradient of the scores, w = (9, 32)
+extern "C" int f2g_convpost_dgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
+  if (!d || !d->y || !d->w || !d->gx || (((uintptr_t)d->gx) & 15) || (((uintptr_t)d->w) & 15))
+    return F2G_EINVAL;
+  if (!conv2ch_ok(d)) return F2G_OK;
+  const long long npx = (long long)d->S * d->H * d->W;
+  hipLaunchKernelGGL(convpost_dgrad_kernel, dim3(f2g_grid_for(npx, 32, 16384)), dim3(256), 0, ST, *d);
   return f2g_check_launch();
 }

@@ -398,8 +398,11 @@ def _mrd_forward_one(x2, win: int, prm: list):
         foff += ws[5]
     wpost, bpost = prm[50], prm[51]
     scores = ops.empty(S * Ft * Wcat, 1, device=dev)
-    gemm(win2d(cat, S, Ft, Wcat, MRD_CH, Wcat, 3, 3, 1, 1, 1),
-         mat(ops.derived(wpost, "pack", pack_conv_weight)), scores, bias=bpost)
+    w9 = ops.derived(wpost, "pack", pack_conv_weight)      # (1, 9*32): [tap][ci]
+    if DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+        ops.convpost_fwd(cat, S, Ft, Wcat, w9, bpost, scores)
+    else:
+        gemm(win2d(cat, S, Ft, Wcat, MRD_CH, Wcat, 3, 3, 1, 1, 1), mat(w9), scores, bias=bpost)
     return dict(xn=xn, stats=stats, packed=packed, ldp=ldp, Ft=Ft, nb=nb, hop=hop, bands=bands,
                 widths=widths, Wcat=Wcat, cat=cat, acts=acts, scores=scores)
 
@@ -521,14 +524,21 @@ class MRDLossFn(torch.autograd.Function):
             wpost = prm[50]
             if train_disc:
                 gwp = ops.zeros(1, 9 * C, device=dev)
-                ops.wgrad(gs, 1, 1, win2d(cat, S, Ft, Wcat, C, Wcat, 3, 3, 1, 1, 1), gwp)
+                if DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+                    ops.convpost_wgrad(cat, S, Ft, Wcat, gs, gwp)
+                else:
+                    ops.wgrad(gs, 1, 1, win2d(cat, S, Ft, Wcat, C, Wcat, 3, 3, 1, 1, 1), gwp)
                 grads_w[50] = unpack_conv_grad(gwp, wpost.shape)
                 gb = ops.zeros(1, device=dev)
                 ops.colsum(gb, gs, S * Ft * Wcat, 1)
                 grads_w[51] = gb
             # gradient of the concatenated layer-4 maps (only the sequences in backward)
             gcat = ops.empty(Sx * Ft * Wcat, C, device=dev)
-            _conv2d_dgrad(gs, Sx, Ft, Wcat, 1, wpost, 1, Wcat, gcat, g_off=soff * Ft * Wcat)
+            if DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+                ops.convpost_dgrad(gs, Sx, Ft, Wcat, ops.derived(wpost, "pack", pack_conv_weight),
+                                   gcat, g_off=soff * Ft * Wcat)
+            else:
+                _conv2d_dgrad(gs, Sx, Ft, Wcat, 1, wpost, 1, Wcat, gcat, g_off=soff * Ft * Wcat)
             g_packed = None
             if not train_disc:
                 g_packed = ops.empty(B * Ft, ldp, device=dev)

@@ -291,6 +291,28 @@ def conv2ch_dgrad(g, S, H, W, wt, gx, gx_seq, gx_line, gx_off):
     return gx
 
 
+def convpost_fwd(x, S, H, W, w9, bias, y):
+    """Conv2d(32, 1, (3, 3), padding 1): x (S*H*W, 32) -> y (S*H*W); w9 = (9, 32) tap-major."""
+    d = _conv2ch_desc(x, 0, 0, 0, S, H, W)
+    d.w, d.bias, d.y = ptr(w9), ptr(bias), ptr(y)
+    _timed("f2g_convpost_fwd", d, 2.0 * S * H * W * 288, (0, S * H * W, 1, 288))
+    return y
+
+
+def convpost_wgrad(x, S, H, W, g, gw):
+    d = _conv2ch_desc(x, 0, 0, 0, S, H, W)
+    d.y, d.gw = ptr(g), ptr(gw)
+    _timed("f2g_convpost_wgrad", d, 2.0 * S * H * W * 288, (2, 1, 288, S * H * W))
+    return gw
+
+
+def convpost_dgrad(g, S, H, W, w9, gx, g_off=0):
+    d = _conv2ch_desc(None, 0, 0, 0, S, H, W)
+    d.y, d.w, d.gx = ptr(g) + 4 * g_off, ptr(w9), ptr(gx)
+    _timed("f2g_convpost_dgrad", d, 2.0 * S * H * W * 288, (1, S * H * W, 32, 9))
+    return gx
+
+
 class GemmTimer:
     """bench.py instrumentation: HIP events around every f2g_gemm launch on the launch stream and
     the launch's algorithmic FLOPs (2 * M * N * K of the implicit GEMM it represents)."""

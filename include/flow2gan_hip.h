@@ -379,6 +379,14 @@ typedef struct {
 int f2g_conv2ch_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream);
 int f2g_conv2ch_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream);
 int f2g_conv2ch_dgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream);
+/* conv_post of an MRD resolution, Conv2d(32, 1, (3, 3), padding (1, 1)) (discriminators.py:184),
+ * same descriptor: x = (S, H, W, 32) dense feature map, w = (9, 32) tap-major weights.
+ *   fwd  : y (S*H*W) = conv + bias[0]
+ *   wgrad: gw (9*32) += sum_px y[px] * window(px)        (y = gradient of the scores)
+ *   dgrad: gx (S*H*W, 32) = transposed conv of y          (overwrites; x unused) */
+int f2g_convpost_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream);
+int f2g_convpost_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream);
+int f2g_convpost_dgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream);
 
 /* ---- on-device data front end (dataset.py:122-175).  x: (B, C, T) crops with
  * explicit item / channel strides (floats); lens[b] = valid samples of item b.

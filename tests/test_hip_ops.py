@@ -508,3 +508,26 @@ def test_conv2ch_direct_kernels_match_autograd(ops, S, H, W, lo, Wtot):
     close(got, x.grad.permute(0, 2, 3, 1), name="conv2ch dgrad")
     rest = gspec[:, :2 * Wtot].reshape(S, H, Wtot, 2)
     assert float(rest[:, :, :lo].min()) == 7.0 if lo > 0 else True     # outside the band: untouched
+
+
+@pytest.mark.parametrize("S,H,W", [(2, 11, 34), (3, 8, 32), (1, 5, 3), (2, 21, 77)])
+def test_convpost_direct_kernels_match_autograd(ops, S, H, W):
+    """conv_post of an MRD resolution (32 -> 1, 3x3) as direct kernels: forward, weight gradient,
+    data gradient against torch conv2d + autograd in fp64."""
+    xr = rnd(S * H * W, 32, seed=1)
+    w, b = rnd(1, 32, 3, 3, seed=2, scale=0.2), rnd(1, seed=3)
+    w9 = w.permute(0, 2, 3, 1).reshape(9, 32).contiguous()
+    y = torch.full((S * H * W,), 7.0, device=DEV)
+    ops.convpost_fwd(g(xr), S, H, W, g(w9), g(b), y)
+    x = xr.reshape(S, H, W, 32).permute(0, 3, 1, 2).double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    out = torch.nn.functional.conv2d(x, wd, b.double(), padding=1)
+    close(y, out.reshape(-1), name="convpost fwd")
+    gy = rnd(S * H * W, seed=5)
+    out.backward(gy.reshape(S, 1, H, W).double())
+    gw = torch.zeros(9 * 32, device=DEV)
+    ops.convpost_wgrad(g(xr), S, H, W, g(gy), gw)
+    close(gw, wd.grad.permute(0, 2, 3, 1).reshape(-1), rtol=1e-4, name="convpost wgrad")
+    gx = torch.full((S * H * W, 32), 7.0, device=DEV)
+    ops.convpost_dgrad(g(gy), S, H, W, g(w9), gx)
+    close(gx, x.grad.permute(0, 2, 3, 1).reshape(S * H * W, 32), name="convpost dgrad")
