@@ -220,6 +220,131 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
   }
 }
 
+// ---- weight gradient of the same layer ---------------------------------------------------------
+// gw[co][tap][ci] += sum_px g[px][co] * x[px -> tap][ci].  MFMA rows = co, columns = ci, reduction =
+// the pixels of an 8 x 16 output tile; a block walks many tiles with the 27 (32 x 32) accumulator
+// tiles spread over its 8 waves (wave w owns taps w, w+8, w+16 over all 128 pixels and pixels
+// [16w, 16w+16) of taps 24..26) and leaves with one atomic per (block, element).  Both fragments are
+// single-float LDS reads at per-lane base + immediate offsets (the tile's pixels are walked in a
+// fully unrolled loop): no address arithmetic next to the MFMAs.  The implicit GEMM (M = 32,
+// windows re-gathered per tap) ran this at 57-61 TFLOP/s.
+// d.x = layer input (S, H, Win, 32), d.y = gradient of the pre-activation (S, H, Wout, 32) (read),
+// d.w is unused, d.gw = (32, 27*32) accumulated atomically.
+constexpr int GT = TH * TW * C;          // floats of the staged gradient tile [px][co]
+
+__device__ __forceinline__ int px_off(int px) { return ((px >> 4) * IW + (px & 15)) * PITCH; }
+
+__global__ __launch_bounds__(512, 2) void conv32_s2_wgrad_kernel(const f2g_conv32_desc d, float* gw,
+                                                                 int tiles_h, int tiles_w,
+                                                                 int tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* At = sm;                 // x patch [2 parities][IH][IW][PITCH]
+  float* Gt = sm + 2 * SUB;       // g tile [128 px][32 co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int ntiles = d.S * tiles_h * tiles_w;
+  f32x16 acc[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  // per-lane bases: tap t -> patch offset; k slot hh = pixel parity inside a k step
+  int tb[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int t = wave + 8 * a;
+    const int dh = t / KW, j = t - dh * KW;
+    tb[a] = (j & 1) * SUB + (dh * IW + (j >> 1)) * PITCH + li + hh * PITCH;
+  }
+  int ts[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int t = 24 + a;
+    const int dh = t / KW, j = t - dh * KW;
+    ts[a] = (j & 1) * SUB + (dh * IW + (j >> 1)) * PITCH + li + hh * PITCH;
+  }
+  const int gb = hh * C + li;
+  const int t0 = blockIdx.x * tiles_per_block;
+  for (int ti = t0; ti < t0 + tiles_per_block && ti < ntiles; ++ti) {
+    const int s = ti / (tiles_h * tiles_w), rem = ti - s * (tiles_h * tiles_w);
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int h0 = th * TH, w0 = tw * TW;
+    const float* xs = d.x + (long long)s * d.x_seq;
+    const float* gs = d.y + (long long)s * d.y_seq;
+    __syncthreads();   // the previous tile's readers are done
+    const int x0 = 2 * w0 - (KW - 1) / 2;
+    for (int i = tid; i < IH * (2 * IW - 1) * (C / 4); i += 512) {
+      const int c4 = i & 7;
+      const int px = i >> 3;
+      const int r = px / (2 * IW - 1), xr = px - r * (2 * IW - 1);
+      const int h = h0 - 1 + r, x = x0 + xr;
+      const bool ok = h >= 0 && h < d.H && x >= 0 && x < d.Win;
+      const float* p = ok ? xs + (long long)h * d.x_line + (long long)x * C + c4 * 4 : c32_zero;
+      *reinterpret_cast<float4*>(At + (xr & 1) * SUB + (r * IW + (xr >> 1)) * PITCH + c4 * 4) =
+          *reinterpret_cast<const float4*>(p);
+    }
+    for (int i = tid; i < TH * TW * (C / 4); i += 512) {
+      const int c4 = i & 7, px = i >> 3;
+      const int h = h0 + (px >> 4), w = w0 + (px & 15);
+      const bool ok = h < d.H && w < d.Wout;
+      const float* p = ok ? gs + (long long)h * d.y_line + (long long)w * C + c4 * 4 : c32_zero;
+      *reinterpret_cast<float4*>(Gt + px * C + c4 * 4) = *reinterpret_cast<const float4*>(p);
+    }
+    __syncthreads();
+    // taps owned over the whole tile: 64 k steps of two pixels
+#pragma unroll
+    for (int st = 0; st < TH * TW / 2; ++st) {
+      const float a = Gt[gb + st * 2 * C];
+      const int po = px_off(2 * st);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, At[tb[q] + po], acc[q], 0, 0, 0);
+    }
+    // taps 24..26: this wave's 16 pixels (8 k steps); pixel index = 16*wave + 2*st + hh
+    {
+      const float* Gw = Gt + gb + wave * 16 * C;
+      const int pbase = ((wave)*IW) * PITCH;   // pixel row = wave (16 pixels per tile row)
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const float a = Gw[st * 2 * C];
+        const int po = pbase + (2 * st) * PITCH;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          acc[3 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, At[ts[q] + po], acc[3 + q], 0, 0, 0);
+      }
+    }
+  }
+  // ---- flush: taps owned by one wave go straight out; the three shared taps are summed over the
+  // waves through LDS first
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int t = wave + 8 * q;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      atomicAdd(gw + co * (KH * KW * C) + t * C + li, acc[q][e]);
+    }
+  }
+  float* red = sm;   // [8 waves][16][64]
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[3 + q][e];
+    __syncthreads();
+    if (wave == q) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += red[(w8 * 16 + e) * 64 + lane];
+        const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        atomicAdd(gw + co * (KH * KW * C) + (24 + q) * C + li, v);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
@@ -257,5 +382,28 @@ extern "C" int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream
   const int tiles = ((d->H + TH - 1) / TH) * (((d->Win + 1) / 2 + TW - 1) / TW);
   hipLaunchKernelGGL(conv32_s2_dgrad_kernel, dim3(tiles, d->S, 2), dim3(512), smem,
                      (hipStream_t)stream, *d);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stream_t stream) {
+  if (!d || !d->x || !d->y || !gw) return F2G_EINVAL;
+  if (d->S <= 0 || d->H <= 0 || d->Wout <= 0) return F2G_OK;
+  if (d->Wout != (d->Win + 8 - 9) / 2 + 1) return F2G_EINVAL;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (!al(d->x) || !al(d->y) || (d->x_line & 3) || (d->x_seq & 3) || (d->y_line & 3) || (d->y_seq & 3))
+    return F2G_EINVAL;
+  const size_t smem = (size_t)(2 * SUB + GT) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_wgrad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int tiles_h = (d->H + TH - 1) / TH, tiles_w = (d->Wout + TW - 1) / TW;
+  const int ntiles = d->S * tiles_h * tiles_w;
+  int per = (ntiles + 511) / 512;   // <= 512 blocks (two per CU): bounds the atomics
+  if (per < 1) per = 1;
+  hipLaunchKernelGGL(conv32_s2_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(512), smem,
+                     (hipStream_t)stream, *d, gw, tiles_h, tiles_w, per);
   return f2g_check_launch();
 }

@@ -595,6 +595,8 @@ class MRDLossFn(torch.autograd.Function):
                         tiles = ((3 * kw * Cin + 255) // 256)
                         if l == 0 and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
                             ops.conv2ch_wgrad(packed, Ft * ldp, ldp, lo * 2, S, Ft, Win, g, gwp)
+                        elif l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
+                            ops.conv32_s2_wgrad(x_in, g, S, Ft, Win, Wout, gwp)
                         else:
                             gemm(dY, X, gwp, form=2, atomic=True,
                                  split_k=ops.split_for(X.rows, tiles))

@@ -249,6 +249,22 @@ def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, 
     return gx
 
 
+def conv32_s2_wgrad(x, g, S: int, H: int, Win: int, Wout: int, gw):
+    """gw (32, 27*32) += weight gradient of Conv2d(32, 32, (3, 9), stride (1, 2), padding (1, 4));
+    x (S*H*Win, 32) layer input, g (S*H*Wout, 32) gradient of the pre-activation."""
+    d = L.Conv32Desc()
+    d.x, d.x_seq, d.x_line = ptr(x), H * Win * 32, Win * 32
+    d.S, d.H, d.Win, d.Wout = S, H, Win, Wout
+    d.w, d.bias, d.lrelu_slope = None, None, 0.0
+    d.y, d.y_seq, d.y_line = ptr(g), H * Wout * 32, Wout * 32
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_conv32_s2_wgrad", C.byref(d), ptr(gw)),
+                        2.0 * S * H * Wout * 32 * 27 * 32, (2, 32, 27 * 32, S * H * Wout))
+    else:
+        call("f2g_conv32_s2_wgrad", C.byref(d), ptr(gw))
+    return gw
+
+
 def _conv2ch_desc(x, x_seq, x_line, x_off, S, H, W):
     d = L.Conv2chDesc()
     d.x = None if x is None else ptr(x) + 4 * x_off

@@ -354,6 +354,9 @@ int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream);
  * (S, H, Win, 32, fully overwritten), w = the weights as 27 transposed tiles [tap][ci][co]
  * (tap = kh*9 + kw); bias / lrelu_slope unused. */
 int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream);
+/* Weight gradient of that layer: x = layer input (S, H, Win, 32), y = gradient of the
+ * pre-activation (S, H, Wout, 32) (read), gw (32, 27*32) [co][tap][ci] accumulated atomically. */
+int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stream_t stream);
 
 /* First layer of every MRD band stack, Conv2d(2, 32, (3, 9), stride 1, padding (1, 4))
  * (discriminators.py:171,195-203), as direct kernels (conv2ch.hip).  The input is a frequency band

@@ -531,3 +531,17 @@ def test_convpost_direct_kernels_match_autograd(ops, S, H, W):
     gx = torch.full((S * H * W, 32), 7.0, device=DEV)
     ops.convpost_dgrad(g(gy), S, H, W, g(w9), gx)
     close(gx, x.grad.permute(0, 2, 3, 1).reshape(S * H * W, 32), name="convpost dgrad")
+
+
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (5, 17, 26)])
+def test_direct_conv32_wgrad_matches_autograd(ops, S, H, Win):
+    """conv32.hip weight gradient (direct, taps spread over the waves) vs torch autograd in fp64."""
+    Wout = (Win - 1) // 2 + 1
+    xr, gy = rnd(S * H * Win, 32, seed=1), rnd(S * H * Wout, 32, seed=4)
+    w = rnd(32, 32, 3, 9, seed=2, scale=0.05).double().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xr.reshape(S, H, Win, 32).permute(0, 3, 1, 2).double(), w, None,
+                                   stride=(1, 2), padding=(1, 4))
+    y.backward(gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
+    gw = torch.zeros(32, 27 * 32, device=DEV)
+    ops.conv32_s2_wgrad(g(xr), g(gy), S, H, Win, Wout, gw)
+    close(gw, w.grad.permute(0, 2, 3, 1).reshape(32, 27 * 32), rtol=1e-4, name="conv32 wgrad")
