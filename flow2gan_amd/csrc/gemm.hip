@@ -420,9 +420,9 @@ __device__ __forceinline__ void tile_of_block(int BM, int BN, int& m0, int& n0) 
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&acc)[TM][TN], int M,
                                               int N, int m0, int n0, int wm, int wn, int li,
-                                              int h) {
+                                              int h, bool first) {
   const float scale = E.scale != 0.f ? E.scale : 1.f;
-  const bool first = blockIdx.z == 0;  // split-K: bias and residual enter once
+  // first: split-K / stream-K -- bias and residual enter once
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
     const int col = n0 + (wn * TN + ni) * 32 + li;
@@ -586,7 +586,7 @@ void gemm_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     }
     __syncthreads();
   }
-  gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h);
+  gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
 }
 
 // ---- split-bf16 ("bf16x3"): each fp32 operand is staged as hi + lo bf16 and every product is
@@ -712,7 +712,7 @@ void gemm_kernel_b3(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     }
     __syncthreads();
   }
-  gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h);
+  gemm_epilogue<TM, TN>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool AKM, bool BKM, int AMODE, int BMODE,
@@ -904,22 +904,75 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
   return (unsigned)(off * 4);
 }
 
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(128)))
-void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
+__global__ __launch_bounds__(256, 2)
+void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
   constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
-  int m0, n0;
-  tile_of_block(BM, BN, m0, n0);
-  const int kbeg = blockIdx.z * kchunk;
-  int kend = kbeg + kchunk;
-  if (kend > K) kend = K;
-  const int nt = (kend - kbeg) / BK;
+  const int ch = tid & 7, rr = tid >> 3;
+  __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, 0x80000000u, 0x00020000);
+  // B is a plain [n][k] matrix: the resource ends with its last row, so the rows of a partial
+  // last tile (n >= N) are out of range = zeros, and ONE per-thread offset serves all four staged
+  // rows (their distance, 32 rows, is uniform and rides in the scalar offset)
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * 4), 0x00020000);
+  const int qstepB = (int)(32 * d.B.seq_stride * 4);
+  // scalar K walk of A: segments of `seglen` columns, `line_stride` floats apart
+  const int seglen = d.A.seglen < d.A.cols ? d.A.seglen : d.A.cols;
+  const int spseg = seglen / BK;                                  // slabs per segment
+  const int segjump = (int)((d.A.line_stride - seglen) * 4);      // bytes skipped at a segment end
+  float* wA = smem + rr * LDR + ch * 4;
+  float* wB = smem + 2 * TSZ + rr * LDR + ch * 4;
+  const float* rA = smem + (wm * 64 + li) * LDR + h * 16;
+  const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * 16;
 
-  f32x16 acc[2][2];
-  {
-    const bool first = blockIdx.z == 0;
+  // ---- work of this block.  Classic: one tile (blockIdx.x/y), K chunk blockIdx.z.  Stream-K
+  // (upb > 0): the (tile, slab) units of the whole problem are numbered tile-major and every
+  // block takes `upb` consecutive ones -- a tile count just above a multiple of the 512 resident
+  // blocks no longer costs a nearly empty extra round; tiles cut between blocks are accumulated
+  // atomically onto a zeroed output, bias / residual entering with the part that holds slab 0.
+  const int nt_all = K / BK;
+  const int tiles_n = (N + BN - 1) / BN;
+  int u = 0, u_end = 0;
+  if (upb > 0) {
+    const int G = gridDim.x;
+    const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;  // XCD-contiguous
+    const int total = ((M + BM - 1) / BM) * tiles_n * nt_all;
+    u = b * upb;
+    u_end = u + upb < total ? u + upb : total;
+    if (u >= u_end) return;
+  }
+  bool more = true;
+  while (more) {
+    int m0, n0, s0, nt;
+    bool first, partial;
+    if (upb == 0) {
+      tile_of_block(BM, BN, m0, n0);
+      const int kbeg = blockIdx.z * kchunk;
+      int kend = kbeg + kchunk;
+      if (kend > K) kend = K;
+      s0 = kbeg / BK;
+      nt = (kend - kbeg) / BK;
+      first = blockIdx.z == 0;
+      partial = false;
+      more = false;
+    } else {
+      const int tl = u / nt_all;
+      s0 = u - tl * nt_all;
+      nt = nt_all - s0 < u_end - u ? nt_all - s0 : u_end - u;
+      first = s0 == 0;
+      partial = nt != nt_all;
+      const int tm = tl / tiles_n;
+      m0 = tm * BM;
+      n0 = (tl - tm * tiles_n) * BN;
+      u += nt;
+      more = u < u_end;
+    }
+
+    f32x16 acc[2][2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int col = n0 + (wn * 2 + ni) * 32 + li;
@@ -929,160 +982,146 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] = b;
     }
-  }
-  const int ch = tid & 7, rr = tid >> 3;
-  __amdgpu_buffer_rsrc_t ra =
-      __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, 0x80000000u, 0x00020000);
-  // B is a plain [n][k] matrix: the resource ends with its last row, so the rows of a partial
-  // last tile (n >= N) are out of range = zeros, and ONE per-thread offset serves all four staged
-  // rows (their distance, 32 rows, is uniform and rides in the scalar offset)
-  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * 4), 0x00020000);
-  unsigned offA[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    offA[q] = lean_row_offset(d.A, m0 + rr + 32 * q);
-    if (offA[q] != 0x80000000u) offA[q] += ch * 16;
-  }
-  const unsigned offB = (unsigned)((long long)(n0 + rr) * d.B.seq_stride * 4) + ch * 16;
-  const int qstepB = (int)(32 * d.B.seq_stride * 4);
-  // scalar K walk of A: segments of `seglen` columns, `line_stride` floats apart
-  const int seglen = d.A.seglen < d.A.cols ? d.A.seglen : d.A.cols;
-  const int spseg = seglen / BK;                                  // slabs per segment
-  const int segjump = (int)((d.A.line_stride - seglen) * 4);      // bytes skipped at a segment end
-  const int s0 = kbeg / BK;
-  int left = spseg - (s0 % spseg);
-  const int ka0 = (int)(((long long)(s0 / spseg) * d.A.line_stride + (long long)(s0 % spseg) * BK) * 4);
-  const int kb0 = kbeg * 4;
-  int ka = ka0, kb = kb0;
-
-  float* wA = smem + rr * LDR + ch * 4;
-  float* wB = smem + 2 * TSZ + rr * LDR + ch * 4;
-  const float* rA = smem + (wm * 64 + li) * LDR + h * 16;
-  const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * 16;
-
-  auto gload = [&](int soa, int sob, u32x4 (&la)[4], u32x4 (&lb)[4]) {
+    unsigned offA[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      la[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q], soa, 0);
-      lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB, sob + q * qstepB, 0);
+      offA[q] = lean_row_offset(d.A, m0 + rr + 32 * q);
+      if (offA[q] != 0x80000000u) offA[q] += ch * 16;
     }
-  };
-  auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {
+    const unsigned offB = (unsigned)((long long)(n0 + rr) * d.B.seq_stride * 4) + ch * 16;
+    int left = spseg - (s0 % spseg);
+    const int ka0 = (int)(((long long)(s0 / spseg) * d.A.line_stride + (long long)(s0 % spseg) * BK) * 4);
+    const int kb0 = s0 * BK * 4;
+    int ka = ka0, kb = kb0;
+
+    auto gload = [&](int soa, int sob, u32x4 (&la)[4], u32x4 (&lb)[4]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<u32x4*>(wA + bufoff + q * 32 * LDR) = la[q];
-      *reinterpret_cast<u32x4*>(wB + bufoff + q * 32 * LDR) = lb[q];
-    }
-  };
-  auto mfma_slab = [&](int bufoff) {
+      for (int q = 0; q < 4; ++q) {
+        la[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q], soa, 0);
+        lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB, sob + q * qstepB, 0);
+      }
+    };
+    auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      float4 a[2], b[2];
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<u32x4*>(wA + bufoff + q * 32 * LDR) = la[q];
+        *reinterpret_cast<u32x4*>(wB + bufoff + q * 32 * LDR) = lb[q];
+      }
+    };
+    auto mfma_slab = [&](int bufoff) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        a[mi] = *reinterpret_cast<const float4*>(rA + bufoff + mi * 32 * LDR + s4 * 4);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-        b[ni] = *reinterpret_cast<const float4*>(rB + bufoff + ni * 32 * LDR + s4 * 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int s4 = 0; s4 < 4; ++s4) {
+        float4 a[2], b[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
+          a[mi] = *reinterpret_cast<const float4*>(rA + bufoff + mi * 32 * LDR + s4 * 4);
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const float av = q == 0 ? a[mi].x : q == 1 ? a[mi].y : q == 2 ? a[mi].z : a[mi].w;
-            const float bv = q == 0 ? b[ni].x : q == 1 ? b[ni].y : q == 2 ? b[ni].z : b[ni].w;
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
-          }
-    }
-  };
-  // (SALU) K offsets of the slab after the current one
-  auto advance = [&]() {
-    ka += BK * 4;
-    kb += BK * 4;
-    if (--left == 0) {
-      left = spseg;
-      ka += segjump;
-    }
-  };
-  if (nt > 0) {
-    u32x4 la[4], lb[4];
-    gload(ka, kb, la, lb);
-    lstore(0, la, lb);
-  }
-  __syncthreads();
-  auto step = [&](int t, int curoff, int nxtoff) {
-    u32x4 la[4], lb[4];
-    advance();
-    const bool more = t + 1 < nt;   // the last iteration re-reads the first slab (never used)
-    gload(more ? ka : ka0, more ? kb : kb0, la, lb);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_slab(curoff);
-    __builtin_amdgcn_sched_barrier(0);
-    lstore(nxtoff, la, lb);
-    __syncthreads();
-  };
-  int t = 0;
-  for (; t + 1 < nt; t += 2) {
-    step(t, 0, TSZ);
-    step(t + 1, TSZ, 0);
-  }
-  if (t < nt) step(t, 0, TSZ);
-
-  const f2g_epilogue& E = d.E;
-  const bool simple = !E.res && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
-                      !E.atomic && !E.accumulate && E.scale == 0.f;
-  if (simple) {
-    // plain store (+ leaky ReLU / PReLU): uniform row bases, per-lane constant offset
-    const float sl = E.lrelu_slope;
-    const bool pre = E.prelu_slope != nullptr, two = pre && E.prelu_out != nullptr;
-    const unsigned coff = (unsigned)(((long long)(4 * h) * E.ldc + li) * 4);
-    const unsigned poff = (unsigned)(((long long)(4 * h) * E.ld_prelu_out + li) * 4);
+        for (int ni = 0; ni < 2; ++ni)
+          b[ni] = *reinterpret_cast<const float4*>(rB + bufoff + ni * 32 * LDR + s4 * 4);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col0 = n0 + (wn * 2 + ni) * 32;
-        const int row0 = m0 + (wm * 2 + mi) * 32;
-        const float ps = (pre && col0 + li < N) ? E.prelu_slope[col0 + li] : 0.f;
-        if (row0 + 32 <= M && col0 + 32 <= N) {
-          char* cb = reinterpret_cast<char*>(E.C + (long long)row0 * E.ldc + col0);
-          char* pb = reinterpret_cast<char*>(E.prelu_out + (long long)row0 * E.ld_prelu_out + col0);
+          for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = acc[mi][ni][e];
-            if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
-            const long long ro = (e & 3) + 8 * (e >> 2);
-            if (pre) {
-              const float pv = fmaxf(v, 0.f) + ps * fminf(v, 0.f);
-              if (two) *reinterpret_cast<float*>(pb + ro * E.ld_prelu_out * 4 + poff) = pv;
-              else v = pv;
+            for (int ni = 0; ni < 2; ++ni) {
+              const float av = q == 0 ? a[mi].x : q == 1 ? a[mi].y : q == 2 ? a[mi].z : a[mi].w;
+              const float bv = q == 0 ? b[ni].x : q == 1 ? b[ni].y : q == 2 ? b[ni].z : b[ni].w;
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
             }
-            *reinterpret_cast<float*>(cb + ro * E.ldc * 4 + coff) = v;
-          }
-        } else {
+      }
+    };
+    // (SALU) K offsets of the slab after the current one
+    auto advance = [&]() {
+      ka += BK * 4;
+      kb += BK * 4;
+      if (--left == 0) {
+        left = spseg;
+        ka += segjump;
+      }
+    };
+    if (nt > 0) {
+      u32x4 la[4], lb[4];
+      gload(ka, kb, la, lb);
+      lstore(0, la, lb);
+    }
+    __syncthreads();
+    auto step = [&](int t, int curoff, int nxtoff) {
+      u32x4 la[4], lb[4];
+      advance();
+      const bool again = t + 1 < nt;   // the last iteration re-reads the first slab (never used)
+      gload(again ? ka : ka0, again ? kb : kb0, la, lb);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_slab(curoff);
+      __builtin_amdgcn_sched_barrier(0);
+      lstore(nxtoff, la, lb);
+      __syncthreads();
+    };
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+      step(t, 0, TSZ);
+      step(t + 1, TSZ, 0);
+    }
+    if (t < nt) {
+      step(t, 0, TSZ);
+      // an odd slab count leaves the (unused) restaged slab in buffer 1; the next segment starts in
+      // buffer 0, which every wave has finished reading (barrier above)
+    }
+
+    const f2g_epilogue& E = d.E;
+    const bool simple = !partial && !E.res && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
+                        !E.atomic && !E.accumulate && E.scale == 0.f;
+    if (simple) {
+      // plain store (+ leaky ReLU / PReLU): uniform row bases, per-lane constant offset
+      const float sl = E.lrelu_slope;
+      const bool pre = E.prelu_slope != nullptr, two = pre && E.prelu_out != nullptr;
+      const unsigned coff = (unsigned)(((long long)(4 * h) * E.ldc + li) * 4);
+      const unsigned poff = (unsigned)(((long long)(4 * h) * E.ld_prelu_out + li) * 4);
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            float v = acc[mi][ni][e];
-            if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
-            if (row < M && col0 + li < N) {
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col0 = n0 + (wn * 2 + ni) * 32;
+          const int row0 = m0 + (wm * 2 + mi) * 32;
+          const float ps = (pre && col0 + li < N) ? E.prelu_slope[col0 + li] : 0.f;
+          if (row0 + 32 <= M && col0 + 32 <= N) {
+            char* cb = reinterpret_cast<char*>(E.C + (long long)row0 * E.ldc + col0);
+            char* pb = reinterpret_cast<char*>(E.prelu_out + (long long)row0 * E.ld_prelu_out + col0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              float v = acc[mi][ni][e];
+              if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
+              const long long ro = (e & 3) + 8 * (e >> 2);
               if (pre) {
                 const float pv = fmaxf(v, 0.f) + ps * fminf(v, 0.f);
-                if (two) E.prelu_out[(long long)row * E.ld_prelu_out + col0 + li] = pv;
+                if (two) *reinterpret_cast<float*>(pb + ro * E.ld_prelu_out * 4 + poff) = pv;
                 else v = pv;
               }
-              E.C[(long long)row * E.ldc + col0 + li] = v;
+              *reinterpret_cast<float*>(cb + ro * E.ldc * 4 + coff) = v;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              float v = acc[mi][ni][e];
+              if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
+              if (row < M && col0 + li < N) {
+                if (pre) {
+                  const float pv = fmaxf(v, 0.f) + ps * fminf(v, 0.f);
+                  if (two) E.prelu_out[(long long)row * E.ld_prelu_out + col0 + li] = pv;
+                  else v = pv;
+                }
+                E.C[(long long)row * E.ldc + col0 + li] = v;
+              }
             }
           }
         }
-      }
-    return;
+    } else {
+      f2g_epilogue E2 = E;
+      E2.bias = nullptr;   // already in the accumulators
+      if (partial) { E2.atomic = 1; E2.accumulate = 0; }
+      gemm_epilogue<2, 2>(E2, acc, M, N, m0, n0, wm, wn, li, h, first);
+    }
   }
-  f2g_epilogue E2 = E;
-  E2.bias = nullptr;   // already in the accumulators
-  gemm_epilogue<2, 2>(E2, acc, M, N, m0, n0, wm, wn, li, h);
 }
 
 // Can `S` (the A operand of a form-0 GEMM) be read by the lean kernel: aligned, no on-load
@@ -1113,21 +1152,47 @@ inline bool lean_b_ok(const f2g_operand& S) {
          (long long)S.rows * S.seq_stride * 4 < 0x7ff00000ll;
 }
 
-int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st) {
   constexpr size_t smem = (size_t)4 * 128 * LDR * sizeof(float);
   int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
-  // chunks must not straddle... (they may: the scalar K walk starts anywhere) -- only whole slabs
   int zs = (K + kchunk - 1) / kchunk;
   dim3 grid((M + 127) / 128, (N + 127) / 128, zs);
   if (grid.x == 0 || grid.y == 0) return F2G_OK;
+  if (upb > 0) {
+    const long long total = (long long)grid.x * grid.y * (K / BK);
+    grid = dim3((unsigned)((total + upb - 1) / upb), 1, 1);
+  }
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lean_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_lean_kernel, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  hipLaunchKernelGGL(gemm_lean_kernel, grid, dim3(256), smem, st, d, M, N, K, kchunk, upb);
   return f2g_check_launch();
+}
+
+// Stream-K decision for the lean kernel: units per block, or 0 to keep the classic tile grid.
+// Measured on the stage-2 step (B = 64): evening out the rounds lifts the kernels alone on the chip
+// (GEMM class 283.8 -> 275.4 ms serialised) but not the step itself, whose launch lanes already
+// fill one kernel's idle CUs with another lane's work (266.5 -> 269.0 ms: the zero fill and the
+// atomic epilogues remain).  Default: only the latency regime (fewer tiles than half the CUs:
+// batch-1 chunked synthesis, the per-item MLPs), where nothing else runs beside the kernel;
+// F2G_STREAMK=2 applies it to every ragged tile grid.
+inline int lean_stream_k(int M, int N, int K, bool all_grids) {
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const int nt = K / BK;
+  if (nt < 16) return 0;
+  const long long total = tiles * nt;
+  if (tiles * 2 > 256) {
+    if (!all_grids) return 0;
+    const double rounds = (double)tiles / 512.0;
+    const double eff = rounds / (double)((tiles + 511) / 512);
+    if (eff > 0.9) return 0;                     // the tile grid already fills its rounds
+  }
+  long long upb = (total + 511) / 512;
+  if (upb < 8) upb = 8;                          // at least 8 slabs per block (prologue / epilogue)
+  return (int)upb;
 }
 
 }  // namespace
@@ -1157,6 +1222,19 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     // discriminator and loss -- differ in the last bit from run to run)
     // F2G_DETERMINISTIC=1: never split on the library's own initiative (bit-reproducible forward)
     static const bool no_auto = getenv("F2G_DETERMINISTIC") && atoi(getenv("F2G_DETERMINISTIC")) != 0;
+    static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
+    const bool lean = !f1 && lean_on && d.precision == 0 && N > 64 && lean_a_ok(d.A) && lean_b_ok(d.B);
+    if (lean && d.split_k == 0) {
+      // library-chosen work split on the lean kernel: stream-K (same linear-epilogue condition as
+      // split-K; F2G_DETERMINISTIC=1 keeps the plain tile grid)
+      static const int sk_mode = getenv("F2G_STREAMK") ? atoi(getenv("F2G_STREAMK")) : 1;
+      int upb = 0;
+      if (sk_mode > 0 && linear && !no_auto && !d.E.atomic) upb = lean_stream_k(M, N, K, sk_mode > 1);
+      if (upb > 0 && !d.E.accumulate)
+        hipLaunchKernelGGL(zero_out_kernel, dim3(f2g_grid_for((int64_t)M * N, 256)), dim3(256), 0,
+                           st, d.E, M, N);
+      return launch_lean(d, M, N, K, 1, upb, st);
+    }
     if (s == 0)
       s = (linear && am != SL && bm != SL && M > 0 && !d.A.reflect && !no_auto) ? auto_split(M, N, K)
                                                                                  : 1;
@@ -1171,9 +1249,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       dd.E.accumulate = 0;
     }
     if (!f1) {
-      static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
-      if (lean_on && d.precision == 0 && N > 64 && lean_a_ok(d.A) && lean_b_ok(d.B))
-        return launch_lean(dd, M, N, K, s, st);
+      if (lean) return launch_lean(dd, M, N, K, s, 0, st);
       if (am == PF && bm == PF) return dispatch_tile<false, false, PF, PF>(dd, M, N, K, s, st);
       if (am == GF && bm == PF) return dispatch_tile<false, false, GF, PF>(dd, M, N, K, s, st);
       if (am == GR && bm == PF) return dispatch_tile<false, false, GR, PF>(dd, M, N, K, s, st);
