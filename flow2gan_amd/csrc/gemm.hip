@@ -904,6 +904,7 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
   return (unsigned)(off * 4);
 }
 
+template <bool SK>
 __global__ __launch_bounds__(256, 2)
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
   constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
@@ -936,7 +937,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   const int nt_all = K / BK;
   const int tiles_n = (N + BN - 1) / BN;
   int u = 0, u_end = 0;
-  if (upb > 0) {
+  if (SK) {
     const int G = gridDim.x;
     const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;  // XCD-contiguous
@@ -949,7 +950,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   while (more) {
     int m0, n0, s0, nt;
     bool first, partial;
-    if (upb == 0) {
+    if (!SK) {
       tile_of_block(BM, BN, m0, n0);
       const int kbeg = blockIdx.z * kchunk;
       int kend = kbeg + kchunk;
@@ -1164,11 +1165,16 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   }
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lean_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lean_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lean_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_lean_kernel, grid, dim3(256), smem, st, d, M, N, K, kchunk, upb);
+  if (upb > 0)
+    hipLaunchKernelGGL(gemm_lean_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, kchunk, upb);
+  else
+    hipLaunchKernelGGL(gemm_lean_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, kchunk, upb);
   return f2g_check_launch();
 }
 

@@ -9,7 +9,12 @@ from typing import List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+import os
+
 from .. import fused_disc as FD
+from .. import ops
+
+DISC_LANES = os.environ.get("F2G_DISC_LANES", "1") == "1"
 from .discriminators import MultiPeriodDiscriminator, MultiResolutionDiscriminator
 from .modules import MelSpectrogram
 
@@ -63,17 +68,35 @@ class GAN(nn.Module):
                 pred_audio = self.generator.infer(cond=cond, audio_lens=audio_lens,
                                                   n_timesteps=n_timesteps, clamp_pred=False,
                                                   noise=noise)
-            # (each term forks one launch lane per sub-discriminator inside; running MPD and MRD
-            # side by side on top of that was measured to add nothing: the chip is already full)
-            disc_loss_mp, _ = self._mp_terms(audio, pred_audio, True)
-            disc_loss_mr, _ = self._mr_terms(audio, pred_audio, True)
+            # MPD and MRD side by side (F2G_DISC_LANES=0 turns it off): each term forks one launch lane per
+            # sub-discriminator inside; autograd runs each node's backward on its forward stream
+            if DISC_LANES:
+                lanes = ops.Lanes(audio.device, 2, "disc")
+                with lanes.lane(0):
+                    disc_loss_mp, _ = self._mp_terms(audio, pred_audio, True)
+                with lanes.lane(1):
+                    disc_loss_mr, _ = self._mr_terms(audio, pred_audio, True)
+                lanes.join()
+            else:
+                disc_loss_mp, _ = self._mp_terms(audio, pred_audio, True)
+                disc_loss_mr, _ = self._mr_terms(audio, pred_audio, True)
             return disc_loss_mp, disc_loss_mr
         # generator step (gan.py:133-166)
         self.discriminator.eval()
         self.generator.train()
         pred_audio = self.generator.infer(cond=cond, audio_lens=audio_lens,
                                           n_timesteps=n_timesteps, clamp_pred=False, noise=noise)
-        gen_loss_mp, feat_map_loss_mp = self._mp_terms(audio, pred_audio, False)
-        gen_loss_mr, feat_map_loss_mr = self._mr_terms(audio, pred_audio, False)
-        mel_recon_loss = self.mel_recon_loss(real=audio, fake=pred_audio)
+        if DISC_LANES:
+            lanes = ops.Lanes(audio.device, 3, "disc")
+            with lanes.lane(0):
+                gen_loss_mp, feat_map_loss_mp = self._mp_terms(audio, pred_audio, False)
+            with lanes.lane(1):
+                gen_loss_mr, feat_map_loss_mr = self._mr_terms(audio, pred_audio, False)
+            with lanes.lane(2):
+                mel_recon_loss = self.mel_recon_loss(real=audio, fake=pred_audio)
+            lanes.join()
+        else:
+            gen_loss_mp, feat_map_loss_mp = self._mp_terms(audio, pred_audio, False)
+            gen_loss_mr, feat_map_loss_mr = self._mr_terms(audio, pred_audio, False)
+            mel_recon_loss = self.mel_recon_loss(real=audio, fake=pred_audio)
         return gen_loss_mp, gen_loss_mr, feat_map_loss_mp, feat_map_loss_mr, mel_recon_loss
