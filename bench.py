@@ -215,32 +215,60 @@ def main():
     roofline = None
     if not args.no_roofline:
         torch.cuda.synchronize()
-        ops.GEMM_TIMER = ops.GemmTimer()
+        timer = ops.GEMM_TIMER = ops.GemmTimer()
         step()
         torch.cuda.synchronize()
-        n, flops, secs = ops.GEMM_TIMER.summary()
+        n, flops, secs = timer.summary()
         if os.environ.get("F2G_GEMM_REPORT") and rank == 0:
-            print(ops.GEMM_TIMER.report(int(os.environ["F2G_GEMM_REPORT"])), file=sys.stderr)
+            print(timer.report(int(os.environ["F2G_GEMM_REPORT"])), file=sys.stderr)
         ops.GEMM_TIMER = None
         achieved = flops / secs / 1e12
-        # HBM bytes per GEMM launch come from the committed PMC passes over this same command
-        # (counters cannot be read live from inside the process); null when the workload differs
+        fam = timer.by_path()
+        hbm = timer.hbm_summary()
+        # HBM bytes per launch of the dominant kernel come from PMC passes over this same command
+        # (profiles/: counters cannot be read from inside the process).  They are only reported when
+        # the profile was taken with THIS library version; otherwise null (stale counters would
+        # describe different kernels / tiles).
         traffic = None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                           "r01_pmc_gemm_traffic.json")
+                           "r02_pmc_gemm_traffic.json")
         if (args.workload == "gan_stage2" and args.gemm == "fp32" and args.model == "mel_24k_base"
                 and B == 64 and nts == 1 and os.path.exists(pmc)):
             with open(pmc) as f:
-                traffic = round(json.load(f)["hbm_bytes_per_launch_fetch_x2"])
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel (fp32 MFMA implicit GEMM, all forms)",
-                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": traffic, "launches_per_step": n,
-                    # the extra step runs with the launch lanes off (ops.Lanes checks GEMM_TIMER):
-                    # every kernel alone on the chip, one stream -- a per-kernel figure; the timed
-                    # region above overlaps up to 7 lanes, so these durations sum to more than a step
-                    "gemm_ms_per_step_serialised": round(1e3 * secs, 2),
-                    "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
+                pj = json.load(f)
+            if pj.get("lib_version") == _lib_version():
+                traffic = round(pj["hbm_bytes_per_launch_fetch_x2"])
+        # dominant kernel = the family with the most time in this pass
+        dom = max(fam.items(), key=lambda kv: kv[1][2])
+        dn, (dl, dfl, dsec) = dom
+        roofline = {"bound": "mfma",
+                    "kernel": {"lean": "gemm_lean_kernel (fp32 MFMA, zero-VALU K loop)",
+                               "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
+                               "direct-conv": "conv32 / conv2ch direct kernels",
+                               "lean-streamk": "gemm_lean_kernel (stream-K)",
+                               "narrow": "narrow VALU kernels"}[dn],
+                    # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
+                    "achieved": round(dfl / dsec / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(dfl / dsec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": traffic, "launches_per_step": dl,
+                    "avg_launch_us": round(1e6 * dsec / dl, 1),
+                    "share_of_mfma_class_time": round(dsec / secs, 3),
+                    # every MFMA-class launch of the step (all GEMM families + direct convs); the
+                    # extra step runs with the launch lanes off (one stream, each kernel alone on the
+                    # chip), so these durations sum to more than a laned step
+                    "mfma_class": {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "launches_per_step": n, "ms_per_step_serialised": round(1e3 * secs, 2),
+                                   "algorithmic_tflop_per_step": round(flops / 1e12, 3),
+                                   "by_family": {k: {"launches": v[0], "tflop": round(v[1] / 1e12, 3),
+                                                     "ms": round(1e3 * v[2], 2),
+                                                     "tflops": round(v[1] / v[2] / 1e12, 1)}
+                                                 for k, v in sorted(fam.items())}},
+                    # HBM-bound kernel class, in-step: algorithmic bytes / HIP-event
+                    # time per kernel, against the 8 TB/s spec peak
+                    "hbm_class": {k: {"launches": v[0], "GB": round(v[1] / 1e9, 3), "ms": round(1e3 * v[2], 3),
+                                      "achieved_GBps": round(v[1] / v[2] / 1e9, 1),
+                                      "frac": round(v[1] / v[2] / 8.0e12, 3)}
+                                  for k, v in sorted(hbm.items())}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: ranks must not wait on it
@@ -256,6 +284,18 @@ def main():
         except Exception as e:  # noqa: BLE001
             cpu = {"value": None, "unit": "audio-s/s", "cores": None, "kind": "port",
                    "sample": f"cpu baseline did not finish: {type(e).__name__}"}
+        # the reference CLIs' own setting is torch.set_num_threads(1) (pretrain.py:894-895,
+        # finetune.py:1027-1028): one bounded step at B=1 on a single thread
+        try:
+            r1 = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only",
+                                 "--workload", args.workload, "--n-timesteps", str(nts),
+                                 "--cpu-threads", "1", "--model", args.model],
+                                capture_output=True, text=True, timeout=120)
+            one = json.loads(r1.stdout.strip().splitlines()[-1])
+            cpu["single_thread"] = {"value": one["value"], "cores": 1, "sample": one["sample"]}
+        except Exception as e:  # noqa: BLE001
+            cpu["single_thread"] = {"value": None, "cores": 1,
+                                    "sample": f"did not finish: {type(e).__name__}"}
 
     if rank == 0:
         line = {
@@ -288,6 +328,11 @@ def main():
         fdist.cleanup_dist()
 
 
+def _lib_version() -> str:
+    from flow2gan_amd import _lib
+    return _lib.version()
+
+
 def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = False,
                  model: str = "mel_24k_base"):
     """The CPU oracle (oracle/flow2gan_oracle.py, a port validated against the reference) on the
@@ -305,7 +350,7 @@ def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = Fa
     gen = O.build_generator(model)
     gc = O.GENERATOR_CONFIGS[model]
     sr, hop = gc["sampling_rate"], gc["mel_hop_length"]
-    B, T = ((64 if sr == 24000 else 32) if eager_gpu else 8), sr
+    B, T = ((64 if sr == 24000 else 32) if eager_gpu else (1 if threads == 1 else 8)), sr
     dev = torch.device("cuda" if eager_gpu else "cpu")
     audio = (0.1 * torch.randn(B, T)).clamp_(-1, 1).to(dev)
     lens = torch.full((B,), T, device=dev)
@@ -338,12 +383,12 @@ def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = Fa
             with torch.no_grad():
                 gen.infer(lm(audio), None, 4)
             return B * (1 + T // hop) * hop / sr
-    for _ in range(3 if eager_gpu else 1):
+    for _ in range(3 if eager_gpu else (0 if threads == 1 else 1)):
         step()
     sync()
     t0 = time.perf_counter()
     done, nstep = 0.0, 0
-    while nstep < 6 and (time.perf_counter() - t0 < 10.0 or nstep == 0):
+    while nstep < (1 if threads == 1 else 6) and (time.perf_counter() - t0 < 10.0 or nstep == 0):
         done += step()
         sync()
         nstep += 1
@@ -353,7 +398,7 @@ def cpu_baseline(workload: str, nts: int, threads: int = 0, eager_gpu: bool = Fa
                 "kind": "PyTorch eager restatement of the reference on this GPU (MIOpen/rocBLAS/hipFFT)",
                 "sample": f"B={B} x 1 s, 3 warm-up + {nstep} timed step(s), fp32"}
     return {"value": round(done / dt, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (PyTorch CPU fp32 restatement), B={B} x 1 s, 1 warm-up + {nstep} timed "
+            "sample": f"oracle (PyTorch CPU fp32 restatement), B={B} x 1 s, {0 if threads == 1 else 1} warm-up + {nstep} timed "
                       f"step(s) of the same workload ({dt:.1f} s)"}
 
 

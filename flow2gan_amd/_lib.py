@@ -162,7 +162,8 @@ _SIGS = {
     "f2g_zero_halo": [_P, _I, _I, _I, _I, _I],
     "f2g_sadam_update": [_P, _P, _I, _P],
 }
-EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_dwnorm_bwd_workspace",
+EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
+                                 "f2g_dwnorm_bwd_workspace",
                                  "f2g_dwconv_bwd_workspace", "f2g_sadam_chunk_elems"])
 
 

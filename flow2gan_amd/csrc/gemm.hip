@@ -26,6 +26,8 @@
 
 namespace {
 
+int g_last_path = 0;   // kernel family of the last dispatch (f2g_gemm_last_path)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
@@ -1171,6 +1173,7 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
+  g_last_path = upb > 0 ? 2 : 1;
   if (upb > 0)
     hipLaunchKernelGGL(gemm_lean_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, kchunk, upb);
   else
@@ -1203,6 +1206,11 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
 
 }  // namespace
 
+// Which kernel family the last f2g_gemm call of this process dispatched to (diagnostics for the
+// benchmark's per-kernel roofline; not thread safe): 0 generic MFMA kernels, 1 lean kernel,
+// 2 lean kernel in stream-K mode, 3 narrow (VALU) kernels.
+extern "C" int f2g_gemm_last_path(void) { return g_last_path; }
+
 extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   if (!dp || !dp->A.base || !dp->B.base || !dp->E.C) return F2G_EINVAL;
   const f2g_gemm_desc& d = *dp;
@@ -1210,6 +1218,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   int split = d.split_k > 0 ? d.split_k : 1;
   {
     const int nr = f2g_gemm_narrow(d, st);  // <= 4 output columns / gradient rows: VALU kernels
+    g_last_path = nr != 0 ? 3 : 0;
     if (nr != 0) return nr < 0 ? nr : F2G_OK;
   }
   if (d.E.prelu_slope && (d.E.atomic || d.E.accumulate || d.E.P0o > 0 || d.form == 2)) return F2G_EINVAL;

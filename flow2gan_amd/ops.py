@@ -336,6 +336,36 @@ class GemmTimer:
     def __init__(self):
         self.records = []
         self.shapes = []
+        self.paths = []       # kernel family per record
+        self.hbm = []         # (start, end, algorithmic bytes, kernel name): HBM-bound kernels
+
+    def time_hbm(self, fn, nbytes: float, name: str):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.hbm.append((s, e, nbytes, name))
+
+    def by_path(self):
+        """{family: (launches, flops, seconds)} -- after a device synchronise."""
+        out = {}
+        for (s, e, f), pth in zip(self.records, self.paths):
+            a = out.setdefault(pth, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += f
+            a[2] += s.elapsed_time(e) * 1e-3
+        return out
+
+    def hbm_summary(self):
+        """{kernel: (launches, algorithmic bytes, seconds)} -- after a device synchronise."""
+        out = {}
+        for s, e, nb, name in self.hbm:
+            a = out.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += nb
+            a[2] += s.elapsed_time(e) * 1e-3
+        return out
 
     def launch(self, d, A, Bm, form):
         if form == 2:
@@ -350,6 +380,7 @@ class GemmTimer:
         call("f2g_gemm", C.byref(d))
         e.record()
         self.records.append((s, e, flops))
+        self.paths.append(("generic", "lean", "lean-streamk", "narrow")[L.lib.f2g_gemm_last_path()])
         nn = Bm.rows if form == 0 else Bm.cols
         mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
         self.shapes.append((form, mm, nn, kk))
@@ -362,6 +393,7 @@ class GemmTimer:
         fn()
         e.record()
         self.records.append((s, e, flops))
+        self.paths.append("direct-conv")
         self.shapes.append(shape)
 
     def report(self, top: int = 25) -> str:
@@ -515,7 +547,12 @@ def dwnorm_fwd(x, z, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=None,
                up=1, cp_off=0, te=None, ldte=0, te_off=0, rstd=None):
     f = _dw_desc(x, x.stride(0), z, z.stride(0), B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale,
                  cproj, ldcp, Fc, up, cp_off, te, ldte, te_off, rstd)
-    call("f2g_dwnorm_fwd", C.byref(f))
+    if GEMM_TIMER is not None:
+        # algorithmic bytes: read x, write z, read the condition row once per `up` frames
+        nb = 4.0 * B * F * Cc * (2.0 + (1.0 / up if cproj is not None else 0.0))
+        GEMM_TIMER.time_hbm(lambda: call("f2g_dwnorm_fwd", C.byref(f)), nb, "dwnorm_fwd")
+    else:
+        call("f2g_dwnorm_fwd", C.byref(f))
     return z
 
 
@@ -533,7 +570,10 @@ def dwnorm_bwd(x, gz, du, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=
     ws = torch.empty(L.lib.f2g_dwnorm_bwd_workspace(B, F, Cc, up if cproj is not None else 1),
                      device=x.device, dtype=torch.float32)
     d.partials = ptr(ws)
-    call("f2g_dwnorm_bwd", C.byref(d))
+    if GEMM_TIMER is not None:   # read x, gz; write du
+        GEMM_TIMER.time_hbm(lambda: call("f2g_dwnorm_bwd", C.byref(d)), 12.0 * B * F * Cc, "dwnorm_bwd")
+    else:
+        call("f2g_dwnorm_bwd", C.byref(d))
     return du
 
 
@@ -553,7 +593,10 @@ def dwconv_bwd(du, x, gx, B, F, Cc, K, lens, w_dw, gres=None, gamma=None, g_w=No
     ws = torch.empty(L.lib.f2g_dwconv_bwd_workspace(B, F, Cc, K), device=x.device,
                      dtype=torch.float32)
     d.partials = ptr(ws)
-    call("f2g_dwconv_bwd", C.byref(d))
+    if GEMM_TIMER is not None:   # read du, x, gres; write gx
+        GEMM_TIMER.time_hbm(lambda: call("f2g_dwconv_bwd", C.byref(d)), 16.0 * B * F * Cc, "dwconv_bwd")
+    else:
+        call("f2g_dwconv_bwd", C.byref(d))
     return gx
 
 
@@ -701,9 +744,14 @@ def lrelu_bwd(g, y_act, f_real, w, slope, rows, cols, ld, wdev=None, g_off=0, y_
 def lrelu_bwd_colsum(g, y_act, f_real, w, slope, rows, Cc, ld, colsum, wdev=None, g_off=0, y_off=0,
                      r_off=0):
     """In-place leaky-ReLU backward of a (rows, Cc) map + column sums of the result (bias grad)."""
-    call("f2g_lrelu_bwd_colsum", ptr(g) + 4 * g_off, ptr(y_act) + 4 * y_off,
-         None if f_real is None else ptr(f_real) + 4 * r_off, float(w), ptr(wdev), float(slope),
-         rows, Cc, ld, ptr(colsum))
+    args = ("f2g_lrelu_bwd_colsum", ptr(g) + 4 * g_off, ptr(y_act) + 4 * y_off,
+            None if f_real is None else ptr(f_real) + 4 * r_off, float(w), ptr(wdev), float(slope),
+            rows, Cc, ld, ptr(colsum))
+    if GEMM_TIMER is not None:   # read g, y (+ f_real); write g
+        GEMM_TIMER.time_hbm(lambda: call(*args), (12.0 + (4.0 if f_real is not None else 0.0)) * rows * Cc,
+                            "lrelu_bwd_colsum")
+    else:
+        call(*args)
 
 
 def zeros_many(shapes, device):

@@ -122,6 +122,9 @@ typedef struct {
 } f2g_gemm_desc;
 
 int f2g_gemm(const f2g_gemm_desc* d, f2g_stream_t stream);
+/* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
+ * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels. */
+int f2g_gemm_last_path(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fused depthwise-conv(k=7) + BiasNorm + cond add + time scale  (modules.py:473-485, A.4):
