@@ -1071,7 +1071,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
     }
 
     const f2g_epilogue& E = d.E;
-    const bool simple = !partial && !E.res && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
+    const bool simple = !partial && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
                         !E.atomic && !E.accumulate && E.scale == 0.f;
     if (simple) {
       // plain store (+ leaky ReLU / PReLU): uniform row bases, per-lane constant offset
@@ -1086,12 +1086,23 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           const int col0 = n0 + (wn * 2 + ni) * 32;
           const int row0 = m0 + (wm * 2 + mi) * 32;
           const float ps = (pre && col0 + li < N) ? E.prelu_slope[col0 + li] : 0.f;
+          const bool hasres = E.res != nullptr;
+          const float gam = (hasres && col0 + li < N) ? (E.gamma ? E.gamma[col0 + li] : 1.f) : 0.f;
           if (row0 + 32 <= M && col0 + 32 <= N) {
             char* cb = reinterpret_cast<char*>(E.C + (long long)row0 * E.ldc + col0);
             char* pb = reinterpret_cast<char*>(E.prelu_out + (long long)row0 * E.ld_prelu_out + col0);
+            const char* rb = reinterpret_cast<const char*>(E.res + (long long)row0 * E.ldres + col0);
+            const unsigned roff = (unsigned)(((long long)(4 * h) * E.ldres + li) * 4);
+            float rv[16];
+            if (hasres) {   // all 16 residual values requested before any is consumed
+#pragma unroll
+              for (int e = 0; e < 16; ++e)
+                rv[e] = *reinterpret_cast<const float*>(rb + (long long)((e & 3) + 8 * (e >> 2)) * E.ldres * 4 + roff);
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               float v = acc[mi][ni][e];
+              if (hasres) v += gam * rv[e];
               if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
               const long long ro = (e & 3) + 8 * (e >> 2);
               if (pre) {
@@ -1101,11 +1112,13 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
               }
               *reinterpret_cast<float*>(cb + ro * E.ldc * 4 + coff) = v;
             }
+            __builtin_amdgcn_sched_barrier(0);   // one sub-tile's loads / stores at a time (registers)
           } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
               float v = acc[mi][ni][e];
+              if (hasres && row < M && col0 + li < N) v += gam * E.res[(long long)row * E.ldres + col0 + li];
               if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
               if (row < M && col0 + li < N) {
                 if (pre) {
@@ -1118,6 +1131,82 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
             }
           }
         }
+    } else if (!partial && E.aux && !E.res && E.P0o == 0 && !E.atomic && !E.accumulate &&
+               E.scale == 0.f && !E.prelu_slope && E.lrelu_slope == 0.f) {
+      // PReLU backward fused into the data gradient (modules.py:444,488 backward):
+      //   v = acc * (a > 0 ? 1 : alpha[n]);  d alpha[n] += sum_r acc * min(a, 0);  d bias[n] += sum_r v
+      // plain store (C may alias aux: each element is read before it is written by the same lane)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + (wn * 2 + ni) * 32 + li;
+        const bool cok = col < N;
+        const float aln = cok ? E.alpha_n[col] : 0.f;
+        float cs = 0.f, csa = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row0 = m0 + (wm * 2 + mi) * 32 + 4 * h;
+          const bool full = cok && row0 - 4 * h + 32 <= M;
+          const float* ab = E.aux + (long long)row0 * E.ldaux + col;
+          float* cb = E.C + (long long)row0 * E.ldc + col;
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {           // four rows (r, r+1, r+2, r+3) at a time
+            float av[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int r = 8 * e4 + k;
+              av[k] = (full || (cok && row0 + r < M)) ? ab[(long long)r * E.ldaux] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int r = 8 * e4 + k;
+              const float a0 = acc[mi][ni][e4 * 4 + k];
+              csa += a0 * fminf(av[k], 0.f);
+              const float v = a0 * (av[k] > 0.f ? 1.f : aln);
+              if (full || (cok && row0 + r < M)) {
+                cs += v;
+                cb[(long long)r * E.ldc] = v;
+              }
+            }
+          }
+        }
+        if (E.colsum || E.colsum_alpha) {
+          cs += __shfl_xor(cs, 32);
+          csa += __shfl_xor(csa, 32);
+          if (cok && h == 0) {
+            if (E.colsum) atomicAdd(E.colsum + col, cs);
+            if (E.colsum_alpha) atomicAdd(E.colsum_alpha + col, csa);
+          }
+        }
+      }
+    } else if (!partial && !E.res && !E.aux && !E.colsum && !E.colsum_alpha && !E.atomic &&
+               !E.accumulate && E.scale == 0.f && !E.prelu_slope && E.P0o >= 32) {
+      // row-mapped store (+ leaky ReLU): the halo layout of the MPD maps and the stride residues of
+      // their data gradients.  One division per 32-row sub-tile instead of one per element: the 32
+      // rows of a sub-tile wrap the sequence length (>= 32) at most once.
+      const float sl = E.lrelu_slope;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row0 = m0 + (wm * 2 + mi) * 32;
+        const int q0 = row0 / E.P0o;                         // uniform
+        const int p0 = row0 - q0 * E.P0o + 4 * h;            // position of this lane's first row
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = n0 + (wn * 2 + ni) * 32 + li;
+          if (col >= N) continue;
+          float* cb = E.C + E.off_o + col;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int re = (e & 3) + 8 * (e >> 2);
+            int p = p0 + re, q = q0;
+            if (p >= E.P0o) { p -= E.P0o; ++q; }
+            if (row0 + re + 4 * h < M) {
+              float v = acc[mi][ni][e];
+              if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
+              cb[(long long)q * E.seq_stride_o + (long long)p * E.row_stride_o] = v;
+            }
+          }
+        }
+      }
     } else {
       f2g_epilogue E2 = E;
       E2.bias = nullptr;   // already in the accumulators
