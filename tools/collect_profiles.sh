@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON the GPU box (through gpurun): every measurement profiles/r01_* is made from.
+# Run ON the GPU box (through gpurun): every measurement profiles/<round>_* is made from.
 # Outputs go to gpurun_out/; tools/make_profiles.py turns them into the committed summaries.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -7,6 +7,7 @@ mkdir -p $O
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 F2G_GEMM_REPORT=80 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fast-mode 2> $O/shapes.txt > /dev/null
+./tools/micro/gemm_lab > $O/gemm_lab.txt 2>&1
 for w in stage1 infer4; do
   python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json
 done

@@ -1,6 +1,9 @@
-"""Turn the raw outputs of tools/collect_profiles.sh (gpurun_out/) into profiles/r01_*."""
-import csv, json, re, os
+"""Turn the raw outputs of tools/collect_profiles.sh (gpurun_out/) into profiles/<round>_*
+(ROUND=r02 by default)."""
+import csv, json, re, os, sys
 G, P = "gpurun_out", "profiles"
+R = os.environ.get("ROUND", "r02")
+sys.path.insert(0, os.getcwd())
 
 
 def stats(path, out, header):
@@ -12,25 +15,26 @@ def stats(path, out, header):
         n = re.sub(r"\(anonymous namespace\)::", "", r["Name"]); n = re.sub(r"\(.*", "", n)[:66]
         L.append(f"{n:66s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:9.1f} "
                  f"{float(r['MinNs'])/1e3:8.1f} {float(r['MaxNs'])/1e3:9.1f} {float(r['Percentage']):6.2f}")
-    g = [r for r in rows if "gemm_kernel" in r["Name"] or "narrow_" in r["Name"] or "conv32_" in r["Name"]]
+    g = [r for r in rows if "gemm_kernel" in r["Name"] or "gemm_lean" in r["Name"] or "narrow_" in r["Name"]
+         or "conv32_" in r["Name"] or "conv2ch_" in r["Name"] or "convpost_" in r["Name"]]
     gc = sum(int(r["Calls"]) for r in g); gt = sum(float(r["TotalDurationNs"]) for r in g)
-    L.append(f"# all gemm_kernel<...> + narrow_* + conv32_* dispatches (= the f2g_gemm-class launches bench.py times): {gc} calls, {gt/1e6:.1f} ms, average {gt/gc/1e3:.1f} us, "
+    L.append(f"# all gemm_lean / gemm_kernel<...> / narrow_* / conv32_* / conv2ch_* / convpost_* dispatches (= the f2g_gemm-class launches bench.py times): {gc} calls, {gt/1e6:.1f} ms, average {gt/gc/1e3:.1f} us, "
              f"{100*gt/tot:.1f} % of kernel time")
     open(out, "w").write("\n".join(L) + "\n")
     print(L[1]); print(L[-1])
 
 
 CMD = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode"
-stats(f"{G}/prof_serial/p_kernel_stats.csv", f"{P}/r01_gan_stage2_kernel_stats.txt",
+stats(f"{G}/prof_serial/p_kernel_stats.csv", f"{P}/{R}_gan_stage2_kernel_stats.txt",
       f"# F2G_STREAMS=0 rocprofv3 --kernel-trace --stats -- {CMD}\n"
       "# (mel_24k_base GAN stage-2 step, B=64 x 1 s per D-step and per G-step, exact-fp32 GEMMs, 1 x MI355X)\n"
       "# launch lanes OFF: every kernel alone on the chip -- the same condition as bench.py's roofline pass, whose per-launch average must agree")
-stats(f"{G}/prof_lanes/p_kernel_stats.csv", f"{P}/r01_gan_stage2_kernel_stats_lanes.txt",
+stats(f"{G}/prof_lanes/p_kernel_stats.csv", f"{P}/{R}_gan_stage2_kernel_stats_lanes.txt",
       f"# rocprofv3 --kernel-trace --stats -- {CMD}\n"
       "# default mode: launch lanes ON (up to 7 HIP streams): kernel durations overlap and stretch, their sum exceeds the wall time of a step")
 txt = open(f"{G}/shapes.txt").read().split("\n")
 i = next(k for k, l in enumerate(txt) if l.startswith("form"))
-open(f"{P}/r01_gemm_shapes_fp32.txt", "w").write(
+open(f"{P}/{R}_gemm_shapes_fp32.txt", "w").write(
     "# per-shape HIP-event timing of every f2g_gemm launch of ONE GAN stage-2 step (B=64), exact fp32, launch lanes off\n"
     "# (F2G_GEMM_REPORT=80 python bench.py ...); form 0 = forward, 1 = data gradient, 2 = weight gradient; TFLOP/s = 2*M*N*K / time (peak 157.3)\n"
     + "\n".join(txt[i:i + 81]) + "\n")
@@ -38,20 +42,21 @@ res = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     tot = 0.0; n = 0
     for row in csv.DictReader(open(f"{G}/pmcb_{name}/p_counter_collection.csv")):
-        if ("gemm_kernel" in row["Kernel_Name"] or "narrow_" in row["Kernel_Name"]
-                or "conv32_" in row["Kernel_Name"]):
+        if "gemm_lean_kernel<false>" in row["Kernel_Name"] or "gemm_lean_kernelILb0" in row["Kernel_Name"]:
             tot += float(row["Counter_Value"]); n += 1
     res[name] = (tot, n)
 f, nf = res["FETCH_SIZE"]; w, nw = res["WRITE_SIZE"]
+from flow2gan_amd import _lib
 json.dump({"source": "F2G_STREAMS=0 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py "
-                     "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode; all gemm_kernel / narrow_* / conv32_* dispatches (2 steps)",
+                     "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode; gemm_lean_kernel<false> dispatches (2 steps)",
+           "lib_version": _lib.version(), "kernel": "gemm_lean_kernel<false>",
            "launches": nf, "fetch_kib_per_launch": f / nf, "write_kib_per_launch": w / nw,
            "hbm_bytes_per_launch_raw": (f / nf + w / nw) * 1024, "hbm_bytes_per_launch_fetch_x2": (2 * f / nf + w / nw) * 1024,
            "note": "gfx950 FETCH_SIZE under-reports wide coalesced reads by up to 2x (MI355X_MICROARCH.md, HBM); both raw and "
-                   "x2-corrected sums given; algorithmic bytes per launch (operands read once + output) average ~75 MB"},
-          open(f"{P}/r01_pmc_gemm_traffic.json", "w"), indent=1)
-open(f"{P}/r01_bench_n1.json", "w").write(open(f"{G}/bench_default.json").read().strip().split("\n")[-1] + "\n")
-with open(f"{P}/r01_other_workloads.jsonl", "w") as fo:
+                   "x2-corrected sums given (rocprofv3 reports these counters in KiB)"},
+          open(f"{P}/{R}_pmc_gemm_traffic.json", "w"), indent=1)
+open(f"{P}/{R}_bench_n1.json", "w").write(open(f"{G}/bench_default.json").read().strip().split("\n")[-1] + "\n")
+with open(f"{P}/{R}_other_workloads.jsonl", "w") as fo:
     for f_, cmd in (("bench_stage1", "python bench.py --workload stage1 --steps 10 --warmup 3 --no-cpu-baseline"),
                     ("bench_infer4", "python bench.py --workload infer4 --steps 10 --warmup 3 --no-cpu-baseline"),
                     ("bench_44k", "python bench.py --model mel_44k_128band_512x_base --steps 6 --warmup 2 --no-cpu-baseline"),
@@ -60,6 +65,6 @@ with open(f"{P}/r01_other_workloads.jsonl", "w") as fo:
         d = json.loads(open(f"{G}/{f_}.json").read().strip().split("\n")[-1])
         fo.write(json.dumps({"command": cmd, **d}) + "\n")
         print(f_, d["ms_per_step"], d["value"], d.get("fast_mode") and d["fast_mode"].get("ms_per_step"))
-d = json.loads(open(f"{P}/r01_bench_n1.json").read())
-print("default", d["ms_per_step"], d["value"], d["roofline"], d["cpu_baseline"]["value"], d["fast_mode"]["ms_per_step"])
+d = json.loads(open(f"{P}/{R}_bench_n1.json").read())
+print("default", d["ms_per_step"], d["value"], {k: v for k, v in d["roofline"].items() if k not in ("mfma_class", "hbm_class")}, d["cpu_baseline"], d["fast_mode"]["ms_per_step"])
 print(open(f"{G}/hbm_kernels.txt").read()); print(open(f"{G}/streaming.txt").read())
