@@ -10,7 +10,8 @@ File layout (identical to the reference, so either side can read the other's fil
    **params (epoch, batch_idx_train, ...)}
 A "module." prefix left by DDP is stripped on load; loading is non-strict by default because real
 torchaudio registers persistent window / filterbank buffers this package does not keep.
-The optimizer entry holds flow2gan_amd.optim.ScaledAdam's own (per-tensor) state layout.
+The optimizer entry is in the reference's layout too (stacked per-shape state, see
+flow2gan_amd.optim.ScaledAdam.state_dict).
 """
 from __future__ import annotations
 

@@ -8,7 +8,8 @@ Differences to the reference that a caller can observe:
     stacked dimension is only a batching device there;
   * the gradient-clipping factor never leaves the device (the reference calls `.item()` every
     step, optim.py:599); the quartile log lines are not printed;
-  * `state_dict()` uses this class's own layout (per-tensor, not per shape batch).
+  * state is KEPT per tensor; `state_dict()` / `load_state_dict()` convert to and from the reference's
+    stacked per-shape layout, so checkpoints are interchangeable.
 """
 from __future__ import annotations
 
@@ -159,6 +160,10 @@ class ScaledAdam(Optimizer):
                  plan["gstate"].data_ptr() + 4 * gi * L.SADAM_GSTATE, plan["coef"].data_ptr())
             self._steps[gi] += 1
         call("f2g_sadam_update", tab, chunks, plan["nchunks"], plan["coef"].data_ptr())
+        # the parameters were written through raw pointers (no autograd version bump): tell the
+        # derived-weight cache (transposes, window-major conv weights) that they changed
+        from . import ops
+        ops.bump_weight_epoch()
         return loss
 
     # ---------------------------------------------------------------- introspection / checkpoints
@@ -171,24 +176,107 @@ class ScaledAdam(Optimizer):
         return {"exp_avg_sq": plan["v"][o:o + n].view_as(p), "delta": plan["m"][o:o + n].view_as(p),
                 "param_rms": ts[0], "scale_exp_avg_sq": ts[1], "scale_grads": ts[2:]}
 
+    # The checkpoint entry has the REFERENCE's layout (torch.optim.Optimizer.state_dict() of the
+    # reference ScaledAdam): same-shaped parameters of a group are stacked along a new first
+    # dimension (optim.py:70-122), the stack's state sits under the index of its FIRST parameter,
+    # batches are ordered by (dtype, *shape), and the clipping statistics live in the first batch's
+    # state (optim.py:509-619).  A reference `epoch-N.pt` optimizer entry loads here and vice versa.
+    def _batches(self, gi: int):
+        """[(key, [tensor index in the plan / position in the group, ...])] in the reference's order."""
+        group = self.param_groups[gi]
+        by_key: Dict[tuple, list] = {}
+        for pos, p in enumerate(group["params"]):
+            by_key.setdefault((str(p.dtype), *p.shape), []).append(pos)
+        return [(k, by_key[k]) for k in sorted(by_key)]
+
     def state_dict(self):
-        sd = {"steps": list(self._steps),
-              "param_groups": [{k: v for k, v in g.items() if k != "params"}
-                               for g in self.param_groups]}
-        if self._plan is not None:
-            for k in ("v", "m", "tstate", "gstate"):
-                sd[k] = self._plan[k].clone()
-        return sd
+        groups, state, base = [], {}, 0
+        for gi, group in enumerate(self.param_groups):
+            n = len(group["params"])
+            packed = {k: v for k, v in group.items() if k != "params" and not k.startswith("_")}
+            packed["params"] = list(range(base, base + n))
+            groups.append(packed)
+            if self._plan is not None and self._steps[gi] > 0:
+                plan = self._plan
+                P = group["size_update_period"]
+                period = group["clipping_update_period"]
+                first = group["_first"]
+                gs = plan["gstate"][gi * L.SADAM_GSTATE:(gi + 1) * L.SADAM_GSTATE]
+                for bi, (key, members) in enumerate(self._batches(gi)):
+                    p0 = group["params"][members[0]]
+                    vs, ms, ts = [], [], []
+                    for pos in members:
+                        ti = first + pos
+                        o, cnt = plan["offs"][ti], p0.numel()
+                        vs.append(plan["v"][o:o + cnt].view_as(p0))
+                        ms.append(plan["m"][o:o + cnt].view_as(p0))
+                        ts.append(plan["tstate"][ti * L.SADAM_TSTATE:(ti + 1) * L.SADAM_TSTATE])
+                    st = {"step": self._steps[gi], "exp_avg_sq": torch.stack(vs), "delta": torch.stack(ms)}
+                    if p0.numel() > 1:
+                        tt = torch.stack(ts)                                  # (nb, TSTATE)
+                        one = (len(members),) + (1,) * p0.dim()
+                        st["param_rms"] = tt[:, 0].reshape(one).clone()
+                        st["scale_exp_avg_sq"] = tt[:, 1].reshape(one).clone()
+                        st["scale_grads"] = tt[:, 2:2 + P].t().reshape((P,) + one).clone()
+                    if bi == 0 and group["clipping_scale"] is not None and self._steps[gi] > 1:
+                        st["model_norms"] = gs[:period].clone()
+                        if float(gs[1025]) != 0.0:
+                            st["model_norm_threshold"] = float(gs[1024])
+                            st["num_clipped"] = 0
+                    state[base + members[0]] = st
+            base += n
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self._steps = list(sd["steps"])
+        if "state" not in sd:            # this class's round-1 layout (flat arenas)
+            self._steps = list(sd["steps"])
+            for g, saved in zip(self.param_groups, sd["param_groups"]):
+                g.update({k: v for k, v in saved.items() if not k.startswith("_")})
+            if "v" in sd:
+                if self._plan is None:
+                    self._build()
+                for k in ("v", "m", "tstate", "gstate"):
+                    self._plan[k].copy_(sd[k])
+            return
+        assert len(sd["param_groups"]) == len(self.param_groups)
         for g, saved in zip(self.param_groups, sd["param_groups"]):
-            g.update({k: v for k, v in saved.items() if not k.startswith("_")})
-        if "v" in sd:
-            if self._plan is None:
-                self._build()
-            for k in ("v", "m", "tstate", "gstate"):
-                self._plan[k].copy_(sd[k])
+            g.update({k: v for k, v in saved.items() if k != "params" and not k.startswith("_")})
+        if not sd["state"]:
+            self._steps = [0] * len(self.param_groups)
+            return
+        if self._plan is None:
+            self._build()
+        plan, base = self._plan, 0
+        dev = plan["dev"]
+        for gi, group in enumerate(self.param_groups):
+            n = len(group["params"])
+            P = group["size_update_period"]
+            period = group["clipping_update_period"]
+            first = group["_first"]
+            gs = plan["gstate"][gi * L.SADAM_GSTATE:(gi + 1) * L.SADAM_GSTATE]
+            gs.zero_()
+            for bi, (key, members) in enumerate(self._batches(gi)):
+                st = sd["state"].get(base + members[0])
+                if st is None:
+                    continue
+                self._steps[gi] = int(st["step"])
+                p0 = group["params"][members[0]]
+                for row, pos in enumerate(members):
+                    ti = first + pos
+                    o, cnt = plan["offs"][ti], p0.numel()
+                    plan["v"][o:o + cnt].copy_(st["exp_avg_sq"][row].reshape(-1).to(dev))
+                    plan["m"][o:o + cnt].copy_(st["delta"][row].reshape(-1).to(dev))
+                    if p0.numel() > 1:
+                        ts = plan["tstate"][ti * L.SADAM_TSTATE:(ti + 1) * L.SADAM_TSTATE]
+                        ts[0] = float(st["param_rms"][row].reshape(-1)[0])
+                        ts[1] = float(st["scale_exp_avg_sq"][row].reshape(-1)[0])
+                        ts[2:2 + P].copy_(st["scale_grads"][:, row].reshape(-1).to(dev))
+                if bi == 0 and "model_norms" in st:
+                    gs[:period].copy_(st["model_norms"].reshape(-1)[:period].to(dev))
+                    if "model_norm_threshold" in st:
+                        gs[1024] = float(st["model_norm_threshold"])
+                        gs[1025] = 1.0
+            base += n
 
 
 class LRScheduler:

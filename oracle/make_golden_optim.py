@@ -73,6 +73,15 @@ def main():
                     out[f"{name}/step{k + 1}/{i}"] = p.detach().numpy().copy()
                     d = float((p.detach() - mine[i]).abs().max()) / (float(p.detach().abs().max()) + 1e-12)
                     worst = max(worst, d)
+        # the reference's own optimizer state dict after the last step (checkpoint-format pin):
+        # state index -> tensors; flow2gan_amd.optim must emit the same keys, shapes and values
+        sd = opt.state_dict()
+        out[f"{name}/sd/indices"] = np.array(sorted(sd["state"].keys()), dtype=np.int64)
+        for idx, st in sd["state"].items():
+            for k, v in st.items():
+                out[f"{name}/sd/{idx}/{k}"] = (v.detach().numpy().copy() if torch.is_tensor(v)
+                                                else np.array(v, dtype=np.float64))
+        out[f"{name}/sd/group_params"] = np.array(sd["param_groups"][0]["params"], dtype=np.int64)
         out[f"{name}/lrs"] = np.array(lrs)
         out[f"{name}/kw"] = np.array([2.0 if kw.get("clipping_scale") else 0.0,
                                       kw.get("clipping_update_period", 100),

@@ -42,6 +42,47 @@ def test_scaled_adam_matches_reference_trajectory(fopt, golden, case):
                 err = float((p.detach().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
                 # fp32, different summation order in the per-tensor reductions
                 assert err < 2e-5, (case, k + 1, i, err)
+    # ---- checkpoint format: the state dict equals the REFERENCE optimizer's own state dict
+    # (stacked per-shape batches under their first parameter's index, optim.py:70-122; clipping
+    # statistics in the first batch's state), key by key
+    sd = opt.state_dict()
+    want_idx = [int(v) for v in g[f"{case}/sd/indices"]]
+    assert sorted(sd["state"].keys()) == want_idx
+    assert sd["param_groups"][0]["params"] == [int(v) for v in g[f"{case}/sd/group_params"]]
+    for idx in want_idx:
+        ref_keys = {k.split("/")[-1] for k in g if k.startswith(f"{case}/sd/{idx}/")}
+        assert set(sd["state"][idx].keys()) == ref_keys, (idx, set(sd["state"][idx].keys()), ref_keys)
+        for k in ref_keys:
+            want = np.asarray(g[f"{case}/sd/{idx}/{k}"], dtype=np.float64)
+            got = sd["state"][idx][k]
+            got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.float64(got)
+            assert got.shape == want.shape, (idx, k, got.shape, want.shape)
+            if k == "num_clipped":        # a logging counter of the reference, not part of the update
+                continue
+            tol = 5e-5 * (np.abs(want).max() + 1e-12) + 1e-12
+            assert np.abs(got - want).max() <= tol, (case, idx, k, float(np.abs(got - want).max()))
+    # ---- and the reference's state dict loads: a fresh optimizer continues identically
+    ref_sd = {"state": {}, "param_groups": sd["param_groups"]}
+    for idx in want_idx:
+        st = {}
+        for k in {k.split("/")[-1] for k in g if k.startswith(f"{case}/sd/{idx}/")}:
+            v = g[f"{case}/sd/{idx}/{k}"]
+            st[k] = T(v).float() if v.ndim > 0 else (int(v) if k in ("step", "num_clipped") else float(v))
+        ref_sd["state"][idx] = st
+    params2 = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    opt2 = fopt.ScaledAdam([(f"t{i}", p) for i, p in enumerate(params2)], lr=0.045,
+                           clipping_scale=(float(clip) if clip > 0 else None),
+                           clipping_update_period=int(period), size_update_period=int(sup))
+    opt2.load_state_dict(ref_sd)
+    gen = torch.Generator().manual_seed(5)
+    extra = [torch.randn(p.shape, generator=gen) for p in params]
+    for o, ps in ((opt, params), (opt2, params2)):
+        for p, g_ in zip(ps, extra):
+            p.grad = g_.to(DEV)
+        o.step()
+    for i, (a, b) in enumerate(zip(params, params2)):
+        err = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-12)
+        assert err < 2e-5, (case, "resume", i, err)
 
 
 def test_scaled_adam_vs_oracle_large_tensors_groups_and_missing_grads(fopt):
@@ -85,7 +126,9 @@ def test_scaled_adam_vs_oracle_large_tensors_groups_and_missing_grads(fopt):
                            lr=0.03, clipping_scale=2.0, clipping_update_period=4)
     opt2.load_state_dict(sd)
     assert opt2._steps == opt._steps
-    assert torch.equal(opt2._plan["v"], opt._plan["v"]) and torch.equal(opt2._plan["tstate"], opt._plan["tstate"])
+    assert torch.equal(opt2._plan["v"], opt._plan["v"]) and torch.equal(opt2._plan["m"], opt._plan["m"])
+    assert torch.allclose(opt2._plan["tstate"], opt._plan["tstate"], rtol=0, atol=0)
+    assert torch.equal(opt2._plan["gstate"][:1026], opt._plan["gstate"][:1026])
 
 
 def test_non_finite_gradient_step_follows_the_reference(fopt):
@@ -124,3 +167,45 @@ def test_scaled_adam_refuses_cpu_parameters(fopt):
     opt = fopt.ScaledAdam([torch.nn.Parameter(torch.zeros(4))])
     with pytest.raises(F2GError):
         opt.step()
+
+
+def test_derived_weight_cache_follows_optimizer_steps(fopt, monkeypatch):
+    """Transposed / re-laid weight copies are cached across steps (flow2gan_amd/ops.py:derived);
+    the HIP optimizer writes parameters through raw pointers, so it must invalidate them: losses
+    after an optimizer step equal those of a run with the cache switched off."""
+    import random
+    import flow2gan_amd
+    from flow2gan_amd.models.gan import GAN
+    cfg = dict(sampling_rate=24000, n_mels=100, mel_n_fft=1024, mel_hop_length=256,
+               n_ffts=(512, 256, 128), hop_lengths=(256, 128, 64), channels=(48, 32, 24),
+               time_embed_channels=32, hidden_factor=3, num_layers=(2, 2, 2),
+               cond_enc_channels=32, cond_enc_num_layers=1, branch_dropout=0.0)
+    monkeypatch.setattr(random, "random", lambda: 1.0)
+    torch.manual_seed(3)
+    gan = GAN(flow2gan_amd.MelAudioGenerator(**cfg)).to(DEV)
+    logmel = flow2gan_amd.LogMelSpectrogram(24000, 1024, 256, 100).to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    audio = (0.1 * torch.randn(2, 6000, generator=gen)).to(DEV)
+    noise = (0.1 * torch.randn(2, 6000, generator=gen)).to(DEV)
+    lens = torch.tensor([6000, 6000])
+    opt_d = fopt.ScaledAdam(gan.discriminator.named_parameters(), lr=0.02)
+    opt_g = fopt.ScaledAdam(gan.generator.named_parameters(), lr=0.02)
+
+    def losses():
+        with torch.no_grad():
+            d = gan(logmel(audio), audio, lens, 1, True, noise=noise)
+        return [float(v) for v in d]
+
+    for _ in range(2):
+        gan.zero_grad()
+        d = gan(logmel(audio), audio, lens, 1, True, noise=noise)
+        (d[0] + 0.1 * d[1]).backward()
+        opt_d.step()
+        gan.zero_grad()
+        ls = gan(logmel(audio), audio, lens, 1, False, noise=noise)
+        sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ls)).backward()
+        opt_g.step()
+    cached = losses()
+    monkeypatch.setenv("F2G_WEIGHT_CACHE", "0")
+    fresh = losses()
+    assert np.allclose(cached, fresh, rtol=1e-6, atol=1e-7), (cached, fresh)
