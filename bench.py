@@ -80,6 +80,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torchrun"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    # F2G_BENCH_ONE_GPU=1 (tests only): every rank drives GPU 0 and the exchange goes through gloo
+    # (RCCL refuses two ranks on one device) -- the torchrun path of this file on a 1-GPU box
+    one_gpu = os.environ.get("F2G_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -92,7 +97,7 @@ def main():
     force_dist = bool(os.environ.get("F2G_FORCE_DIST"))  # exercise RCCL with a single rank
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        fdist.setup_dist(rank, world, backend="nccl")
+        fdist.setup_dist(rank, world, backend="gloo" if one_gpu else "nccl")
 
     gcfg = get_generator_config(args.model)
     sr = gcfg["sampling_rate"]

@@ -93,6 +93,37 @@ def test_two_ranks_average_the_single_rank_gradients(tmp_path):
                 want = 0.5 * (singles[0][name][k] + singles[1][name][k])
                 err = float((v - want).abs().max()) / (float(want.abs().max()) + 1e-9)
                 worst = max(worst, err)
-            # atomics reorder sums between runs, and the hinge / L1 / leaky-ReLU gradients are
-            # discontinuous in the activations: a 1e-7 wobble can flip single sign() terms
-            assert worst < 1e-2, (r, name, worst)
+            # F2G_DETERMINISTIC=1 in the workers (no library-chosen split-K); what remains is the
+            # atomic accumulation order of the weight gradients
+            assert worst < 2e-3, (r, name, worst)
+
+
+def test_bench_step_under_torchrun_with_two_ranks(tmp_path):
+    """bench.py's own step() through `python -m torch.distributed.run --nproc-per-node 2` (both
+    ranks on this box's single GPU, gloo exchange): the exact launch line the driver uses on the
+    8-GPU node must not run for the first time there.  Checks the JSON contract of rank 0's line."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    import subprocess
+    import sys
+    from _mp import ROOT, free_port, gloo_rendezvous_works
+    pre = tmp_path / "preflight"
+    pre.mkdir()
+    if not gloo_rendezvous_works(str(pre)):
+        pytest.skip("two CPU-only processes cannot rendezvous over gloo/127.0.0.1 on this box")
+    env = dict(os.environ, F2G_BENCH_ONE_GPU="1", GLOO_SOCKET_IFNAME="lo", F2G_DIST_TIMEOUT_S="90",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline", "--no-roofline", "--no-fast-mode"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    # whole-job aggregate: both ranks' audio over the max-over-ranks time
+    assert abs(d["value"] - 2 * 2 * 4 * 1.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
