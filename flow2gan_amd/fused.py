@@ -497,7 +497,15 @@ class ModelEvalFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, t, wbranch, metas, lens_cpu, training: bool, nparams, *args):
+        # metas: one (n_fft, hop, up, window) per branch, optionally followed by ("scale", s): the
+        # weight of every branch in the reduction (1/nb = mean, generator.py:165-168; 1 = sum)
+        bscale = None
+        if metas and metas[-1][0] == "scale":
+            bscale = float(metas[-1][1])
+            metas = metas[:-1]
         nb = len(metas)
+        if bscale is None:
+            bscale = 1.0 / nb
         cprojs = list(args[:nb])
         flat = args[nb:]
         dev = x.device
@@ -516,7 +524,7 @@ class ModelEvalFn(torch.autograd.Function):
         for i in range(nb):
             wrow = None if wbranch is None else wbranch[i]
             with lanes.lane(i):
-                sv = _branch_forward(views[i], metas[i], x, t, cprojs[i], wrow, 1.0 / nb, pred,
+                sv = _branch_forward(views[i], metas[i], x, t, cprojs[i], wrow, bscale, pred,
                                      i > 0, lens_list[i], training, keep, lanes)
             saved.append(sv)
         lanes.join()
@@ -528,6 +536,7 @@ class ModelEvalFn(torch.autograd.Function):
             ctx.cprojs = cprojs
             ctx.wbranch = wbranch
             ctx.metas = metas
+            ctx.bscale = bscale
             ctx.nparams = nparams
         return pred
 
@@ -548,7 +557,7 @@ class ModelEvalFn(torch.autograd.Function):
             with lanes.lane(i):
                 g_cp = ops.zeros(cproj.shape[0], cproj.shape[1], device=dev) if need_gc else None
                 g_flat += _branch_backward(ctx.views[i], ctx.metas[i], ctx.saved[i], (B, T), cproj,
-                                           g_pred, wrow, 1.0 / nb, ctx.lens[i], g_x, i > 0, g_cp,
+                                           g_pred, wrow, ctx.bscale, ctx.lens[i], g_x, i > 0, g_cp,
                                            need_gx, lanes)
             g_cprojs.append(g_cp)
         lanes.join()
@@ -649,12 +658,14 @@ class FmLossFn(torch.autograd.Function):
     """Stage-1 spectrally scaled endpoint loss (generator.py:172-200)."""
 
     @staticmethod
-    def forward(ctx, pred, x1, lens_cpu, n_fft, hop, fb, eps, power, lo, hi):
+    def forward(ctx, pred, x1, lens_cpu, n_fft, hop, fb, eps, power, lo, hi, gt=None):
+        """err = pred - x1 (`x1` = the regression target: the audio, or audio - noise for the
+        velocity objective); the spectral weights come from `gt` (the audio; default: x1)."""
         dev = pred.device
         B, T = pred.shape
         err = torch.empty_like(pred)
         ops.axpby_rows(err, pred.contiguous(), x1.contiguous(), sa=1.0, sb=-1.0)
-        S_gt, _, _, F = filterbank_spec(x1.contiguous(), n_fft, hop, fb, 2)
+        S_gt, _, _, F = filterbank_spec((x1 if gt is None else gt).contiguous(), n_fft, hop, fb, 2)
         S_err, packed_err, _, _ = filterbank_spec(err, n_fft, hop, fb, 2)
         nf = fb.shape[1]
         lens_f = frames_lens(lens_cpu, hop, dev)
@@ -682,4 +693,4 @@ class FmLossFn(torch.autograd.Function):
         flat = g_err.view(1, -1)
         ops.axpby_rows(flat, flat, None, ca=g.reshape(1).contiguous())
         ctx.saved = None
-        return g_err, None, None, None, None, None, None, None, None, None
+        return g_err, None, None, None, None, None, None, None, None, None, None

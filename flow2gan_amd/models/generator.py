@@ -76,11 +76,14 @@ class BaseAudioGenerator(nn.Module):
         assert len(channels) == self.num_branches
         assert len(conv_kernel_sizes) == self.num_branches
         assert len(num_layers) == self.num_branches
-        # The HIP path implements the configuration every named config of the reference uses
-        # (config.py:31-95); the other switches are rejected loudly rather than approximated.
-        if not (use_cond_encoder and pred_x1 and spec_scaling_loss and branch_reduction == "mean"):
-            raise ValueError("flow2gan_amd supports use_cond_encoder=True, pred_x1=True, "
-                             "spec_scaling_loss=True, branch_reduction='mean' (all named configs)")
+        # Every named config (config.py:31-95) uses the defaults; the other switches of the
+        # reference's constructor are implemented as well, except spec_scaling_loss=False (the
+        # unweighted spectral loss of generator.py:191-192), which is rejected loudly.
+        if not spec_scaling_loss:
+            raise ValueError("flow2gan_amd implements the scaled spectral loss only "
+                             "(spec_scaling_loss=True, as in every named config)")
+        if branch_reduction not in ("mean", "sum"):
+            raise ValueError(f"Unsupported branch_reduction: {branch_reduction}")
         self.sampling_rate = sampling_rate
         self.init_noise_scale = init_noise_scale
         self.pred_x1 = pred_x1
@@ -96,14 +99,16 @@ class BaseAudioGenerator(nn.Module):
         self.loss_spec = LinearFilterSpectrogram(
             sample_rate=sampling_rate, n_fft=loss_n_fft, hop_length=loss_hop_length,
             n_filter=loss_n_filters, center=True, power=2)
-        self.cond_encoder = CondEncoder(
-            cond_dim=cond_dim, channels=cond_enc_channels, hidden_factor=cond_enc_hidden_factor,
-            conv_kernel_size=cond_enc_conv_kernel_size, num_layers=cond_enc_num_layers,
-            residual_scale=residual_scale)
+        if use_cond_encoder:   # generator.py:86-97: without it the estimators see the raw condition
+            self.cond_encoder = CondEncoder(
+                cond_dim=cond_dim, channels=cond_enc_channels, hidden_factor=cond_enc_hidden_factor,
+                conv_kernel_size=cond_enc_conv_kernel_size, num_layers=cond_enc_num_layers,
+                residual_scale=residual_scale)
+        cond_channels = cond_enc_channels if use_cond_encoder else cond_dim
         self.estimators = nn.ModuleList([
             AudioConvNeXt(
                 n_fft=n_ffts[i], hop_length=hop_lengths[i], cond_hop_length=cond_hop_length,
-                channels=channels[i], cond_channels=cond_enc_channels,
+                channels=channels[i], cond_channels=cond_channels,
                 time_embed_channels=time_embed_channels, hidden_factor=hidden_factor,
                 conv_kernel_size=conv_kernel_sizes[i], num_layers=num_layers[i],
                 residual_scale=residual_scale)
@@ -121,6 +126,8 @@ class BaseAudioGenerator(nn.Module):
     def encode_cond(self, mel: Tensor) -> CondRows:
         """cond_encoder(mel) (generator.py:311-312): (B, n_mels, F) -> CondRows."""
         B, _, Fm = mel.shape
+        if not hasattr(self, "cond_encoder"):      # generator.py:311-314: the mel itself
+            return self._as_cond_rows(mel)
         rows = fused.CondEncoderFn.apply(mel, self.training,
                                          *fused.cond_encoder_params(self.cond_encoder))
         return CondRows(rows, B, Fm)
@@ -146,8 +153,10 @@ class BaseAudioGenerator(nn.Module):
         return outs
 
     def _metas(self):
-        return tuple((e.n_fft, e.hop_length, e.cond_upsample_factor, e.ifft.window)
-                     for e in self.estimators)
+        m = tuple((e.n_fft, e.hop_length, e.cond_upsample_factor, e.ifft.window)
+                  for e in self.estimators)
+        # weight of a branch in the reduction (generator.py:165-168)
+        return m + (("scale", 1.0 / self.num_branches if self.branch_reduction == "mean" else 1.0),)
 
     def _draw_branch_weights(self, B: int, device) -> Optional[Tensor]:
         """Branch dropout (generator.py:145-162).  Returns (num_branches, B) weights or None."""
@@ -192,7 +201,7 @@ class BaseAudioGenerator(nn.Module):
         ls = self.loss_spec
         return fused.FmLossFn.apply(pred, ref, _lens_list(audio_lens), ls.n_fft, ls.hop_length,
                                     ls.fb, self.loss_eps, self.loss_power, self.loss_scale_min,
-                                    self.loss_scale_max)
+                                    self.loss_scale_max, None if gt_audio is ref else gt_audio)
 
     def forward(self, x0: Tensor, x1: Tensor, cond, audio_lens: Optional[Tensor] = None, *,
                 t: Optional[Tensor] = None, branch_weights: Optional[Tensor] = None) -> Tensor:
@@ -205,7 +214,12 @@ class BaseAudioGenerator(nn.Module):
         ops.axpby_rows(x, x0.contiguous(), x1.contiguous(), ca=(1.0 - tf).contiguous(), cb=tf)
         pred = self.process_model(x, cond, t=tf, audio_lens=audio_lens,
                                   branch_weights=branch_weights)
-        return self.compute_loss(pred=pred, ref=x1, audio_lens=audio_lens, gt_audio=x1)
+        if self.pred_x1:
+            ref = x1
+        else:                                    # velocity objective (generator.py:218): x1 - x0
+            ref = torch.empty_like(x1)
+            ops.axpby_rows(ref, x1.contiguous(), x0.contiguous(), sa=1.0, sb=-1.0)
+        return self.compute_loss(pred=pred, ref=ref, audio_lens=audio_lens, gt_audio=x1)
 
     def infer(self, noise: Tensor, cond, audio_lens: Optional[Tensor] = None,
               n_timesteps: int = 1, clamp_pred: bool = False) -> Tensor:
@@ -223,11 +237,12 @@ class BaseAudioGenerator(nn.Module):
             tk = ops.fill_(ops.empty(B, device=noise.device), t) if grad else ops.fill_(tdev, t)
             bw = self._draw_branch_weights(B, noise.device)
             pred = self.model_eval(x, tk, cprojs, lens_cpu, bw)
-            b = dt / (1.0 - t)
+            # generator.py:263-264: x += vt*dt with vt = (pred - x)/(1 - t) (x1 prediction) or pred
+            a, b = (1.0 - dt / (1.0 - t), dt / (1.0 - t)) if self.pred_x1 else (1.0, dt)
             if grad:
-                x = fused.AxpbyFn.apply(x, pred, 1.0 - b, b)
+                x = fused.AxpbyFn.apply(x, pred, a, b)
             else:
-                x = ops.axpby_rows(pred, x, pred, sa=1.0 - b, sb=b)
+                x = ops.axpby_rows(pred, x, pred, sa=a, sb=b)
             t = float(t_span[step])
         if clamp_pred:
             if grad:

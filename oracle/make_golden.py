@@ -350,6 +350,46 @@ def case_tiny_stage2(cfg=None, name="tiny_stage2", T=6000, short=4600, seed=31):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+# ------------------------------------------------------------------ case 4b
+def case_tiny_switches():
+    """The constructor switches no named config uses (generator.py:86-97,165-168,218,263):
+    use_cond_encoder=False, pred_x1=False (velocity objective), branch_reduction="sum" -- stage-1
+    loss + every parameter gradient and a 2-step Euler inference, from the reference alone."""
+    cfg = dict(TINY, use_cond_encoder=False, pred_x1=False, branch_reduction="sum",
+               branch_dropout=0.0)
+    torch.manual_seed(13)
+    ref = rgen.MelAudioGenerator(**cfg)
+    g = torch.Generator().manual_seed(14)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.ndim >= 2:
+                p.mul_(3.0)
+            elif n.endswith(".bias") and "norm" not in n:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    assert not hasattr(ref, "cond_encoder")
+    B, T = 2, 6000
+    audio = 0.1 * torch.randn(B, T, generator=g)
+    lens = torch.tensor([6000, 4600])
+    mel = O.LogMelSpectrogram()(audio)
+    noise = 0.1 * torch.randn(B, T, generator=g)
+    t = torch.tensor([[0.3], [0.85]])
+    out = dict(sd_np(ref.state_dict()))
+    out.update(audio=npy(audio), lens=lens.numpy(), mel=npy(mel), noise=npy(noise), t=npy(t))
+    ref.train()
+    with Patched(torch__rand=queue_fn([t]), random__random=lambda: 0.0):
+        loss = rgen.BaseAudioGenerator.forward(ref, x0=noise, x1=audio, cond=mel, audio_lens=lens)
+    loss.backward()
+    out["loss"] = npy(loss)
+    for n, p in ref.named_parameters():
+        out[f"g/{n}"] = npy(p.grad)
+    ref.eval()
+    with torch.no_grad():
+        y = rgen.BaseAudioGenerator.infer(ref, noise=noise, cond=mel, audio_lens=lens, n_timesteps=2)
+    out["infer_n2"] = npy(y)
+    print(f"[tiny_switches] loss {float(loss):.6f}, infer rms {float(y.pow(2).mean().sqrt()):.4f}")
+    np.savez_compressed(os.path.join(OUT, "tiny_switches.npz"), **out)
+
+
 # ------------------------------------------------------------------ case 5
 def case_full_width():
     """Full-width mel_24k_base, weights from seed (init equivalence proven by digest),
@@ -383,7 +423,7 @@ def case_full_width():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mel", "fwd", "s1", "s2", "s2_44k", "full"]
+    which = sys.argv[1:] or ["mel", "fwd", "s1", "s2", "s2_44k", "sw", "full"]
     if "mel" in which:
         case_mel_frontend()
     if "fwd" in which:
@@ -394,6 +434,8 @@ if __name__ == "__main__":
         case_tiny_stage2()
     if "s2_44k" in which:
         case_tiny_stage2(TINY44, "tiny_stage2_44k", T=11025, short=9000, seed=32)
+    if "sw" in which:
+        case_tiny_switches()
     if "full" in which:
         case_full_width()
     for f in sorted(os.listdir(OUT)):

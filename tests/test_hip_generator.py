@@ -351,3 +351,30 @@ def test_plain_bf16_throughput_mode_stays_close_to_fp32(f2g, golden):
     ref = A.double() @ W.double().t()
     rel = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
     assert 1e-5 < rel < 2e-2, rel
+
+
+def test_non_default_constructor_switches_against_reference_vectors(f2g, golden, monkeypatch):
+    """use_cond_encoder=False, pred_x1=False (velocity objective), branch_reduction="sum"
+    (generator.py:86-97,165-168,218,263; unused by the named configs): stage-1 loss, every
+    parameter gradient and a 2-step Euler inference against the REFERENCE's recorded vectors."""
+    g = golden("tiny_switches")
+    cfg = dict(TINY, use_cond_encoder=False, pred_x1=False, branch_reduction="sum", branch_dropout=0.0)
+    m = f2g.MelAudioGenerator(**cfg)
+    assert not hasattr(m, "cond_encoder")
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("w/")}
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    monkeypatch.setattr(random, "random", lambda: 0.0)
+    mel, audio, noise = T(g["mel"]).to(DEV), T(g["audio"]).to(DEV), T(g["noise"]).to(DEV)
+    lens, t = T(g["lens"]), T(g["t"]).to(DEV)
+    loss = m(mel, audio, lens, noise=noise, t=t)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    loss.backward()
+    worst = max((float((p.grad.cpu() - T(g[f"g/{n}"])).abs().max()) / (float(T(g[f"g/{n}"]).abs().max()) + 1e-12), n)
+                for n, p in m.named_parameters())
+    assert worst[0] < 2e-3, worst
+    m.eval()
+    with torch.no_grad():
+        y = m.infer(mel, lens, 2, noise=noise)
+    assert rms(y, T(g["infer_n2"])) < RMS_TOL
