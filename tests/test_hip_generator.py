@@ -378,3 +378,32 @@ def test_non_default_constructor_switches_against_reference_vectors(f2g, golden,
     with torch.no_grad():
         y = m.infer(mel, lens, 2, noise=noise)
     assert rms(y, T(g["infer_n2"])) < RMS_TOL
+
+
+def test_mel_noise_augmentation_draws_like_the_reference(f2g, golden, monkeypatch):
+    """max_add_noise_scale > 0 (generator.py:306-309,342-345): in training mode the condition gets
+    randn_like(cond) * rand(B,1,1) * scale added, drawn in the reference's order from torch's
+    generator; off in eval mode."""
+    g = golden("tiny_forward")
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("w/")}
+    m = f2g.MelAudioGenerator(max_add_noise_scale=0.3, **TINY)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    plain = f2g.MelAudioGenerator(**TINY)
+    plain.load_state_dict(sd)
+    plain = plain.to(DEV)
+    mel, noise = T(g["mel"]).to(DEV), T(g["noise"]).to(DEV)
+    lens = T(g["lens"])
+    monkeypatch.setattr(random, "random", lambda: 1.0)
+    m.train(), plain.train()
+    m.branch_dropout = plain.branch_dropout = 0.0
+    with torch.no_grad():
+        torch.manual_seed(123)
+        got = m.infer(mel, lens, 1, noise=noise)
+        torch.manual_seed(123)
+        e = torch.randn_like(mel) * torch.rand(mel.shape[0], 1, 1, device=mel.device) * 0.3
+        want = plain.infer(mel + e, lens, 1, noise=noise)
+        assert float((got - want).abs().max()) < 1e-6
+        assert float((got - plain.infer(mel, lens, 1, noise=noise)).abs().max()) > 5e-6
+        m.eval(), plain.eval()
+        assert torch.equal(m.infer(mel, lens, 1, noise=noise), plain.infer(mel, lens, 1, noise=noise))
