@@ -211,12 +211,33 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
   if (myu == 1) return;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] += red[(pg * 16 + q) * 64 + lane];
+  // optional: leaky-ReLU backward of the layer below (+ feature-matching term) fused into the
+  // store, column sums of the result = that layer's bias gradient
+  const bool msk = d.mask_src != nullptr, fm = d.fm_ref != nullptr;
+  const float fmw = fm ? d.fm_w * (d.fm_wdev ? d.fm_wdev[0] : 1.f) : 0.f;
+  float cs = 0.f;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int px = pg * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
     const int oh = h0 + (px >> 4), ox = 2 * (m0 + (px & 15)) + e;
-    if (oh < d.H && ox < d.Win)
-      d.y[(long long)s * d.y_seq + (long long)oh * d.y_line + (long long)ox * C + li] = acc[q];
+    if (oh < d.H && ox < d.Win) {
+      const long long off = (long long)s * d.y_seq + (long long)oh * d.y_line + (long long)ox * C + li;
+      float v = acc[q];
+      if (msk) {
+        const float y = d.mask_src[off];
+        if (fm) {
+          const float dl = y - d.fm_ref[off];
+          v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+        }
+        v *= y > 0.f ? 1.f : d.mask_slope;
+      }
+      cs += v;
+      d.y[off] = v;
+    }
+  }
+  if (d.colsum) {
+    cs += __shfl_xor(cs, 32);
+    if (hh == 0) atomicAdd(d.colsum + li, cs);
   }
 }
 

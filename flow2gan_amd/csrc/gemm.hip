@@ -424,6 +424,7 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
                                               int N, int m0, int n0, int wm, int wn, int li,
                                               int h, bool first) {
   const float scale = E.scale != 0.f ? E.scale : 1.f;
+  const float fmw = E.fm_ref ? E.fm_w * (E.fm_wdev ? E.fm_wdev[0] : 1.f) : 0.f;
   // first: split-K / stream-K -- bias and residual enter once
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
@@ -456,7 +457,6 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
           if (E.prelu_out) E.prelu_out[(long long)row * E.ld_prelu_out + col] = pv;
           else v = pv;
         }
-        cs += v;
         long long off;
         if (E.P0o > 0) {
           int sq = row / E.P0o;
@@ -465,6 +465,15 @@ __device__ __forceinline__ void gemm_epilogue(const f2g_epilogue& E, f32x16 (&ac
         } else {
           off = (long long)row * E.ldc + col;
         }
+        if (E.mask_src) {   // leaky-ReLU backward of the layer below (+ feature-matching term)
+          const float y = E.mask_src[off];
+          if (E.fm_ref) {
+            const float dl = y - E.fm_ref[off];
+            v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+          }
+          v *= y > 0.f ? 1.f : E.mask_slope;
+        }
+        cs += v;
         if (E.atomic) atomicAdd(E.C + off, v);
         else if (E.accumulate) E.C[off] += v;
         else E.C[off] = v;
@@ -906,7 +915,12 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
   return (unsigned)(off * 4);
 }
 
-template <bool SK>
+// EP selects the epilogue compiled into an instance (the host picks it from the descriptor): one
+// kernel holding all of them needs 256 VGPRs + scratch; each on its own stays near 130-160.
+//   0 plain store (+ residual*gamma, leaky ReLU, fused PReLU)   1 PReLU backward (+ column sums)
+//   2 row-mapped store (halo layout; + leaky ReLU, or leaky-ReLU backward of the layer below)
+//   3 everything else (generic epilogue; the only one stream-K instances use)
+template <bool SK, int EP>
 __global__ __launch_bounds__(256, 2)
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
   constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
@@ -1072,8 +1086,9 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
 
     const f2g_epilogue& E = d.E;
     const bool simple = !partial && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
-                        !E.atomic && !E.accumulate && E.scale == 0.f;
-    if (simple) {
+                        !E.atomic && !E.accumulate && E.scale == 0.f && !E.mask_src;
+    (void)simple;
+    if constexpr (EP == 0) {
       // plain store (+ leaky ReLU / PReLU): uniform row bases, per-lane constant offset
       const float sl = E.lrelu_slope;
       const bool pre = E.prelu_slope != nullptr, two = pre && E.prelu_out != nullptr;
@@ -1131,8 +1146,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
             }
           }
         }
-    } else if (!partial && E.aux && !E.res && E.P0o == 0 && !E.atomic && !E.accumulate &&
-               E.scale == 0.f && !E.prelu_slope && E.lrelu_slope == 0.f) {
+    } else if constexpr (EP == 1) {
       // PReLU backward fused into the data gradient (modules.py:444,488 backward):
       //   v = acc * (a > 0 ? 1 : alpha[n]);  d alpha[n] += sum_r acc * min(a, 0);  d bias[n] += sum_r v
       // plain store (C may alias aux: each element is read before it is written by the same lane)
@@ -1178,33 +1192,64 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           }
         }
       }
-    } else if (!partial && !E.res && !E.aux && !E.colsum && !E.colsum_alpha && !E.atomic &&
-               !E.accumulate && E.scale == 0.f && !E.prelu_slope && E.P0o >= 32) {
-      // row-mapped store (+ leaky ReLU): the halo layout of the MPD maps and the stride residues of
-      // their data gradients.  One division per 32-row sub-tile instead of one per element: the 32
-      // rows of a sub-tile wrap the sequence length (>= 32) at most once.
+    } else if constexpr (EP == 2) {
+      // row-mapped store: the halo layout of the MPD maps and the stride residues of their data
+      // gradients.  One division per 32-row sub-tile instead of one per element (the 32 rows of a
+      // sub-tile wrap the sequence length (>= 32) at most once).  Options: leaky ReLU (forward), or
+      // the leaky-ReLU backward of the layer below (+ feature-matching term) with the column sums
+      // of the result = that layer's bias gradient.
       const float sl = E.lrelu_slope;
+      const bool msk = E.mask_src != nullptr, fm = E.fm_ref != nullptr;
+      const float fmw = fm ? E.fm_w * (E.fm_wdev ? E.fm_wdev[0] : 1.f) : 0.f;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int row0 = m0 + (wm * 2 + mi) * 32;
-        const int q0 = row0 / E.P0o;                         // uniform
-        const int p0 = row0 - q0 * E.P0o + 4 * h;            // position of this lane's first row
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + (wn * 2 + ni) * 32 + li;
+        const bool cok = col < N;
+        float cs = 0.f;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int col = n0 + (wn * 2 + ni) * 32 + li;
-          if (col >= N) continue;
-          float* cb = E.C + E.off_o + col;
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row0 = m0 + (wm * 2 + mi) * 32;
+          const int q0 = row0 / E.P0o;                         // uniform
+          const int p0 = row0 - q0 * E.P0o + 4 * h;            // position of this lane's first row
+          const long long cbase = E.off_o + col;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int re = (e & 3) + 8 * (e >> 2);
-            int p = p0 + re, q = q0;
-            if (p >= E.P0o) { p -= E.P0o; ++q; }
-            if (row0 + re + 4 * h < M) {
-              float v = acc[mi][ni][e];
-              if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
-              cb[(long long)q * E.seq_stride_o + (long long)p * E.row_stride_o] = v;
+          for (int e4 = 0; e4 < 4; ++e4) {
+            long long off[4];
+            bool ok[4];
+            float yv[4], rv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int re = 8 * e4 + k;
+              int p = p0 + re, q = q0;
+              if (p >= E.P0o) { p -= E.P0o; ++q; }
+              ok[k] = cok && row0 + re + 4 * h < M;
+              off[k] = cbase + (long long)q * E.seq_stride_o + (long long)p * E.row_stride_o;
+              if (msk) yv[k] = ok[k] ? E.mask_src[off[k]] : 0.f;
+              if (fm) rv[k] = ok[k] ? E.fm_ref[off[k]] : 0.f;
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float v = acc[mi][ni][e4 * 4 + k];
+              if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
+              if (msk) {
+                if (fm) {
+                  const float dl = yv[k] - rv[k];
+                  v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+                }
+                v *= yv[k] > 0.f ? 1.f : E.mask_slope;
+              }
+              if (ok[k]) {
+                cs += v;
+                E.C[off[k]] = v;
+              }
+            }
+            asm volatile("" ::: "memory");   // four rows at a time: keeps the next group's loads
+            __builtin_amdgcn_sched_barrier(0);   // from being hoisted (register pressure)
           }
+        }
+        if (E.colsum) {
+          cs += __shfl_xor(cs, 32);
+          if (cok && h == 0) atomicAdd(E.colsum + col, cs);
         }
       }
     } else {
@@ -1254,19 +1299,36 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
     const long long total = (long long)grid.x * grid.y * (K / BK);
     grid = dim3((unsigned)((total + upb - 1) / upb), 1, 1);
   }
+  // epilogue instance (see gemm_lean_kernel)
+  const f2g_epilogue& E = d.E;
+  int ep = 3;
+  if (upb == 0) {
+    const bool plainish = !E.aux && !E.colsum_alpha && !E.atomic && !E.accumulate && E.scale == 0.f;
+    if (plainish && !E.colsum && E.P0o == 0 && !E.mask_src) ep = 0;
+    else if (E.aux && !E.res && E.P0o == 0 && !E.atomic && !E.accumulate && E.scale == 0.f &&
+             !E.prelu_slope && E.lrelu_slope == 0.f && !E.mask_src) ep = 1;
+    else if (plainish && !E.res && !E.prelu_slope && E.P0o >= 32) ep = 2;
+  }
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lean_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lean_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const void* ks[5] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 1>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 2>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 3>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<true, 3>)};
+    for (const void* k : ks)
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   g_last_path = upb > 0 ? 2 : 1;
-  if (upb > 0)
-    hipLaunchKernelGGL(gemm_lean_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, kchunk, upb);
-  else
-    hipLaunchKernelGGL(gemm_lean_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, kchunk, upb);
+#define F2G_LEAN(SKV, EPV) \
+  hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb)
+  if (upb > 0) F2G_LEAN(true, 3);
+  else if (ep == 0) F2G_LEAN(false, 0);
+  else if (ep == 1) F2G_LEAN(false, 1);
+  else if (ep == 2) F2G_LEAN(false, 2);
+  else F2G_LEAN(false, 3);
+#undef F2G_LEAN
   return f2g_check_launch();
 }
 
@@ -1311,6 +1373,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     if (nr != 0) return nr < 0 ? nr : F2G_OK;
   }
   if (d.E.prelu_slope && (d.E.atomic || d.E.accumulate || d.E.P0o > 0 || d.form == 2)) return F2G_EINVAL;
+  if (d.E.mask_src && (d.E.atomic || d.E.accumulate || d.form == 2)) return F2G_EINVAL;
   if (d.form == 0 || d.form == 1) {
     const bool f1 = d.form == 1;
     if (f1 ? d.A.cols != d.B.rows : d.A.cols != d.B.cols) return F2G_EINVAL;
@@ -1320,7 +1383,8 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     // split_k: 1 = off, > 1 = as asked, 0 = decide here (linear epilogues only)
     // (an epilogue input that aliases the output -- in-place residual or PReLU-derivative mask --
     // would be destroyed by the zero fill)
-    const bool linear = d.E.lrelu_slope == 0.f && d.E.res != d.E.C && d.E.aux != d.E.C && !d.E.prelu_slope;
+    const bool linear = d.E.lrelu_slope == 0.f && d.E.res != d.E.C && d.E.aux != d.E.C && !d.E.prelu_slope &&
+                        !d.E.mask_src;
     int s = d.split_k;
     // (STFT framing GEMMs are never split: atomics would make the spectra -- the input of every
     // discriminator and loss -- differ in the last bit from run to run)

@@ -145,7 +145,8 @@ def _dgrad_weight(w, stride: int, j0: int, nt: int):
     return ops.derived(w, ("dgradT", stride, j0, nt), build)
 
 
-def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=True, out_halo=True):
+def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=True, out_halo=True,
+                  mask=None, fm=None, colsum=None):
     """g_x from g_pre (S sequences of Hout rows x Cout, starting g_off floats in; halo layout when
     g_halo).  Returns g_x in the halo layout (S, Hin + 2*HALO, Cin) when out_halo, else (S*Hin, Cin).
     One forward-form GEMM per stride residue against the cached re-laid weights."""
@@ -165,7 +166,9 @@ def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=Tru
             rm = (Lq, (Hin + 2 * HALO) * Cin, stride * Cin, (HALO + rho) * Cin)
         else:
             rm = (Lq, Hin * Cin, stride * Cin, rho * Cin)
-        gemm(A, mat(wq), gx, rowmap=rm)
+        # mask / fm / colsum: leaky-ReLU backward of the layer whose output gradient this is (every
+        # element of gx is written by exactly one stride residue)
+        gemm(A, mat(wq), gx, rowmap=rm, mask=mask, fm=fm, colsum=colsum)
     return gx
 
 
@@ -251,25 +254,49 @@ class MPDLossFn(torch.autograd.Function):
                 gb = zbuf[1]
                 ops.colsum(gb, gs, S * H5, 1)
                 grads_p[11] = gb
-            g = _conv1d_dgrad(gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5, g_halo=False)
+            # Every data gradient applies the leaky-ReLU backward of the layer it lands on in its own
+            # epilogue (mask by that layer's activation, in the G-step plus the feature-matching
+            # term) and leaves the column sums = the bias gradient of the conv that produced it:
+            # the maps are not re-read by a separate pass.
+            def below(l_out):
+                """(mask, fm, colsum) for a gradient that lands on acts[l_out] (l_out = 1..5)."""
+                y = acts[l_out]
+                Hp_, C_ = hs[l_out] + 2 * HALO, y.shape[1]
+                yo = roff * Hp_ * C_
+                fm_ = None
+                if (not train_disc) and l_out >= 2:     # fmaps: conv layers 1..4 (acts[2..5])
+                    fm_ = (y, 0, 1.0 / (Sx * hs[l_out] * C_), g1)
+                cs_ = zbuf[2 + 2 * (l_out - 1) + 1] if train_disc else None
+                return (y, yo, SLOPE), fm_, cs_
+
+            def land(gmap, l_out, producer):
+                """Run `producer(mask, fm, colsum)` -> gradient map landing on acts[l_out], with its
+                leaky-ReLU backward fused (FUSE_LRELU & 1) or as a separate pass."""
+                mk, fk, ck = below(l_out)
+                if FUSE_LRELU & 1:
+                    return producer(mk, fk, ck)
+                gm = producer(None, None, None)
+                y = acts[l_out]
+                Hp_, C_ = hs[l_out] + 2 * HALO, y.shape[1]
+                n_ = Sx * Hp_ * C_
+                if train_disc:
+                    ops.lrelu_bwd_colsum(gm, y, None, 0.0, SLOPE, Sx * Hp_, C_, C_, ck, y_off=mk[1])
+                elif fk is not None:
+                    ops.lrelu_bwd(gm, y, y, fk[2], SLOPE, 1, n_, n_, wdev=g1, y_off=mk[1], r_off=0)
+                else:
+                    ops.lrelu_bwd(gm, y, None, 0.0, SLOPE, 1, n_, n_, y_off=mk[1])
+                return gm
+
+            g = land(None, 5, lambda mk, fk, ck: _conv1d_dgrad(
+                gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5, g_halo=False, mask=mk, fm=fk, colsum=ck))
             for l in reversed(range(5)):
                 w = prm[2 * l]
                 Cin, Cout, stv = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
                 Hin, Hout = hs[l], hs[l + 1]
                 Hp = Hout + 2 * HALO
-                y = acts[l + 1]
-                yoff = roff * Hp * Cout
-                n = Sx * Hp * Cout                    # flat, halo rows included (they stay 0)
-                nval = Sx * Hout * Cout
-                if train_disc:     # + the bias gradient (column sums) in the same pass
-                    gb = zbuf[2 + 2 * l + 1]
-                    ops.lrelu_bwd_colsum(g, y, None, 0.0, SLOPE, S * Hp, Cout, Cout, gb, y_off=yoff)
-                    grads_p[2 * l + 1] = gb
-                elif l >= 1:
-                    ops.lrelu_bwd(g, y, y, 1.0 / nval, SLOPE, 1, n, n, wdev=g1, y_off=yoff, r_off=0)
-                else:
-                    ops.lrelu_bwd(g, y, None, 0.0, SLOPE, 1, n, n, y_off=yoff)
+                # g: gradient of layer l's PRE-activation (S or Sx sequences, halo layout)
                 if train_disc:
+                    grads_p[2 * l + 1] = zbuf[2 + 2 * l + 1]
                     # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
                     # the windows they pair with -- partly outside the input -- contribute nothing)
                     gwp = zbuf[2 + 2 * l]
@@ -279,8 +306,11 @@ class MPDLossFn(torch.autograd.Function):
                         X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5)
                     ops.wgrad(g, Cout, Cout, X, gwp)
                     grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
-                if l > 0 or not train_disc:
-                    g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=l > 0)
+                if l > 0:
+                    g = land(None, l, lambda mk, fk, ck, g=g, w=w, Hout=Hout, Cout=Cout, stv=stv, Hin=Hin:
+                             _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, mask=mk, fm=fk, colsum=ck))
+                elif not train_disc:
+                    g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=False)
             if not train_disc:
                 # g: (B*p*H0, 1) gradient of the folded image of the generated half
                 lanes.chain_enter()  # g_fake is accumulated period after period
@@ -331,6 +361,12 @@ import os as _os
 
 # F2G_DIRECT_CONV=0 routes the band layers through the implicit GEMM again (A/B switch)
 DIRECT_CONV32 = _os.environ.get("F2G_DIRECT_CONV", "1") != "0"
+# leaky-ReLU backward fused into the data-gradient epilogue that lands on a map (1) or run as its
+# own pass over the map afterwards (0): bit 0 = MPD, bit 1 = MRD.  Measured on the stage-2 step
+# (B = 64, 10 steps each): separate passes 257.5 ms, MPD fused 258.6, MRD fused 260.6, both 261.2 --
+# the HBM-bound passes overlap with other lanes' MFMA work, while masking in the epilogue (two more
+# loads per element, strided by the row map) holds an MFMA wave's registers and LDS idle.  Default 0.
+FUSE_LRELU = int(_os.environ.get("F2G_FUSE_LRELU", "0"))
 
 
 def _band_edges(n_fft: int):
@@ -408,7 +444,7 @@ def _mrd_forward_one(x2, win: int, prm: list):
 
 
 def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq=None, g_off=0,
-                  x_line=None, x_off=0):
+                  x_line=None, x_off=0, mask=None, fm=None, colsum=None):
     """Data gradient of a (3, kw) conv with stride (1, sw), pad (1, kw//2).
     g_pre: image (S, H, Wout, Cout) starting g_off floats in (line / seq strides optional);
     gx: destination image with line stride x_line floats (default Win*Cin) starting x_off."""
@@ -423,7 +459,8 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
             ops.permute4(out, t, (kh * kw, Cin, Cout, 1), (1, kh * kw, Cin * kh * kw, 0))
             return out
         wT = ops.derived(w, "dgrad_taps", build_t)
-        ops.conv32_s2_dgrad(g_pre, S, H, Win, Wout, wT, gx, g_seq=g_seq, g_line=g_line, g_off=g_off)
+        ops.conv32_s2_dgrad(g_pre, S, H, Win, Wout, wT, gx, g_seq=g_seq, g_line=g_line, g_off=g_off,
+                            mask=mask, fm=fm, colsum=colsum)
         return gx
     if x_line is None:
         x_line = Win * Cin
@@ -438,7 +475,8 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
         wq = ops.derived(w, ("dgrad2d", sw, j0, ntw), build)
         A = win2d(g_pre, S, H, Wout, Cout, Lq, kh, ntw, 1, 1, (ntw - 1) - e0, line_stride=g_line,
                   seq_stride=g_seq, offset=g_off)
-        gemm(A, mat(wq), gx, form=1, rowmap=(Lq, x_line, sw * Cin, x_off + rho * Cin))
+        gemm(A, mat(wq), gx, form=1, rowmap=(Lq, x_line, sw * Cin, x_off + rho * Cin), mask=mask,
+             fm=fm, colsum=colsum)
     return gx
 
 
@@ -557,24 +595,16 @@ class MRDLossFn(torch.autograd.Function):
                     ops.lrelu_bwd(gcat, cat, cat, 1.0 / (B * Ft * cols), SLOPE, Sx * Ft, cols, ldc,
                                   wdev=g1, g_off=foff * C, y_off=y_off, r_off=foff * C)
                 g = None
+                # bias-gradient accumulators of the band (layers 0..3 get theirs as column sums from
+                # the data-gradient epilogue that lands on their output)
+                gbs = ops.zeros_many([(C,)] * 4, dev) if train_disc else [None] * 4
                 for l in reversed(range(5)):
                     kw, sw = MRD_LAYERS[l]
                     w = prm[(bi * 5 + l) * 2]
                     Cin = 2 if l == 0 else C
                     Win, Wout = ws[l], ws[l + 1]
-                    if l < 4:
-                        y = st["acts"][bi][l]
-                        n = Sx * Ft * Wout * C
-                        yoff = soff * Ft * Wout * C
-                        if train_disc:   # + bias gradient (column sums) in the same pass
-                            gb_l = ops.zeros(C, device=dev)
-                            ops.lrelu_bwd_colsum(g, y, None, 0.0, SLOPE, S * Ft * Wout, C, C, gb_l,
-                                                 y_off=yoff)
-                        elif l >= 1:
-                            ops.lrelu_bwd(g, y, y, 1.0 / n, SLOPE, 1, n, n, wdev=g1, y_off=yoff,
-                                          r_off=0)
-                        else:
-                            ops.lrelu_bwd(g, y, None, 0.0, SLOPE, 1, n, n, y_off=yoff)
+                    # (for l < 4, g already is the gradient of layer l's PRE-activation: the data
+                    # gradient that produced it applied this layer's leaky-ReLU backward)
                     # operands describing this layer's pre-activation gradient image
                     if l == 4:
                         dy_line, dy_seq, dy_off, dy_t = ldc, Ft * ldc, foff * C, gcat
@@ -605,12 +635,31 @@ class MRDLossFn(torch.autograd.Function):
                             gb = ops.zeros(C, device=dev)
                             _colsum_strided(gb, gcat, S * Ft, W4, C, ldc, foff * C)
                         else:
-                            gb = gb_l
+                            gb = gbs[l]
                         grads_w[(bi * 5 + l) * 2 + 1] = gb
                     if l > 0:
+                        # lands on acts[bi][l-1]: its leaky-ReLU backward (+ feature matching for the
+                        # maps the reference lists, band layers 1..4) rides in this epilogue
+                        yb = st["acts"][bi][l - 1]
+                        nb_ = Sx * Ft * Win * C
+                        mk = (yb, soff * Ft * Win * C, SLOPE)
+                        fmk = (yb, 0, 1.0 / nb_, g1) if ((not train_disc) and l - 1 >= 1) else None
                         gx = ops.empty(Sx * Ft * Win, Cin, device=dev)
-                        _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, gx, g_line=dy_line,
-                                      g_seq=dy_seq, g_off=dy_off)
+                        if FUSE_LRELU & 2:
+                            _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, gx, g_line=dy_line,
+                                          g_seq=dy_seq, g_off=dy_off, mask=mk, fm=fmk,
+                                          colsum=gbs[l - 1])
+                        else:
+                            _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, gx, g_line=dy_line,
+                                          g_seq=dy_seq, g_off=dy_off)
+                            if train_disc:
+                                ops.lrelu_bwd_colsum(gx, yb, None, 0.0, SLOPE, Sx * Ft * Win, C, C,
+                                                     gbs[l - 1], y_off=mk[1])
+                            elif fmk is not None:
+                                ops.lrelu_bwd(gx, yb, yb, fmk[2], SLOPE, 1, nb_, nb_, wdev=g1,
+                                              y_off=mk[1], r_off=0)
+                            else:
+                                ops.lrelu_bwd(gx, yb, None, 0.0, SLOPE, 1, nb_, nb_, y_off=mk[1])
                         g = gx
                     elif not train_disc and DIRECT_CONV32 and ops.GEMM_PRECISION == 0:
                         def build_c2t(t):

@@ -163,7 +163,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
          res=None, ldres: Optional[int] = None, gamma=None, aux=None, ldaux: Optional[int] = None,
          alpha_n=None, colsum_alpha=None, colsum=None, lrelu: float = 0.0, scale: float = 0.0,
          accumulate: bool = False, atomic: bool = False, split_k: int = 0, out_offset: int = 0,
-         rowmap=None, prelu=None, prelu_out=None):
+         rowmap=None, prelu=None, prelu_out=None, mask=None, fm=None):
     """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None.
     split_k: 0 = let the library decide (forms 0/1: split-K onto a zeroed output when the tile
     grid would leave most of the last wave of CUs idle), 1 = off, > 1 = as given."""
@@ -198,6 +198,13 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     e.prelu_slope = ptr(prelu)
     e.prelu_out = ptr(prelu_out)
     e.ld_prelu_out = prelu_out.stride(0) if prelu_out is not None else 0
+    if mask is not None:      # (activation tensor, float offset, slope): leaky-ReLU backward below
+        e.mask_src = ptr(mask[0]) + 4 * mask[1]
+        e.mask_slope = float(mask[2])
+        if fm is not None:    # (reference activation tensor, float offset, weight, device scalar)
+            e.fm_ref = ptr(fm[0]) + 4 * fm[1]
+            e.fm_w = float(fm[2])
+            e.fm_wdev = ptr(fm[3])
     d.E = e
     d.form = form
     d.split_k = split_k
@@ -231,7 +238,7 @@ def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope:
 
 
 def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, g_line=None,
-                    g_off: int = 0):
+                    g_off: int = 0, mask=None, fm=None, colsum=None):
     """Data gradient of Conv2d(32, 32, (3, 9), stride (1, 2), padding (1, 4)): g (S, H, Wout, 32)
     (optionally strided / offset) -> gx (S*H*Win, 32); wT = (27, 32, 32) tiles [tap][ci][co]."""
     d = L.Conv32Desc()
@@ -241,6 +248,12 @@ def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, 
     d.S, d.H, d.Win, d.Wout = S, H, Win, Wout
     d.w, d.bias, d.lrelu_slope = ptr(wT), None, 0.0
     d.y, d.y_seq, d.y_line = ptr(gx), H * Win * 32, Win * 32
+    if mask is not None:      # leaky-ReLU backward of the layer below fused into the store
+        d.mask_src = ptr(mask[0]) + 4 * mask[1]
+        d.mask_slope = float(mask[2])
+        if fm is not None:
+            d.fm_ref, d.fm_w, d.fm_wdev = ptr(fm[0]) + 4 * fm[1], float(fm[2]), ptr(fm[3])
+    d.colsum = ptr(colsum)
     if GEMM_TIMER is not None:
         GEMM_TIMER.time(lambda: call("f2g_conv32_s2_dgrad", C.byref(d)),
                         2.0 * S * H * Wout * 32 * 27 * 32, (1, S * H * Win, 32, 27 * 32 // 2))

@@ -95,6 +95,17 @@ typedef struct {
   const float* prelu_slope;
   float* prelu_out;
   int64_t ld_prelu_out;
+  /* Leaky-ReLU backward of the layer BELOW fused into a data gradient (discriminators.py:94,205
+   * backward; gan.py:76-87 feature matching): with y = mask_src at the output's own address (same
+   * row map; the caller offsets the pointer to the right half of a stacked batch)
+   *   v = (v + fm_w * fm_wdev[0] * sign(y - fm_ref)) * (y > 0 ? 1 : mask_slope)
+   * (the fm term only when fm_ref is set) -- the gradient of the pre-activation, whose column sums
+   * (`colsum`) are that layer's bias gradient.  Plain / row-mapped stores only. */
+  const float* mask_src;
+  const float* fm_ref;
+  const float* fm_wdev;
+  float mask_slope;
+  float fm_w;
 } f2g_epilogue;
 
 /* form: 0 = C[r,n] = sum_k A[r,k] * B[n,k]   (forward; B = weights [n][k])
@@ -350,6 +361,14 @@ typedef struct {
   int32_t _pad;
   float* y;
   int64_t y_seq, y_line;
+  /* dgrad only: leaky-ReLU backward of the layer below fused into the store (see f2g_epilogue):
+   * mask_src / fm_ref have y's layout; colsum[32] += column sums of the stored gradient */
+  const float* mask_src;
+  const float* fm_ref;
+  const float* fm_wdev;
+  float mask_slope;
+  float fm_w;
+  float* colsum;
 } f2g_conv32_desc;
 int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream);
 /* Data gradient of that layer as a direct transposed convolution (discriminators.py:171-181
