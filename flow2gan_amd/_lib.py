@@ -145,6 +145,7 @@ _SIGS = {
     "f2g_peaknorm_fwd": [_P, _P, _P, _I, _I],
     "f2g_peaknorm_bwd": [_P, _P, _P, _P, _I, _I],
     "f2g_lrelu_bwd": [_P, _P, _P, _F, _P, _F, _I, _I, _L],
+    "f2g_reflect_pad": [_P, _P, _I, _I, _I, _I],
     "f2g_period_fold": [_P, _P, _I, _I, _I, _I],
     "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
     "f2g_fill": [_P, _F, _L],

@@ -354,3 +354,32 @@ extern "C" int f2g_wave_gain(float* out, int64_t ldo, const float* x, int64_t it
                      stats, target_peak);
   return f2g_check_launch();
 }
+
+// ---- reflect padding of STFT inputs (torch.stft center=True, modules.py:69-78) as data -------------
+namespace {
+__global__ __launch_bounds__(256) void reflect_pad_kernel(float* out, const float* x, int B, int T,
+                                                          int pad, int Tp) {
+  const long long total = (long long)B * Tp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / Tp), j = (int)(i - (long long)b * Tp);
+    int t = j - pad;
+    float v = 0.f;
+    if (j < T + 2 * pad) {
+      t = t < 0 ? -t : t;
+      t = t >= T ? 2 * (T - 1) - t : t;
+      v = x[(long long)b * T + t];
+    }
+    out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int f2g_reflect_pad(float* out, const float* x, int32_t B, int32_t T, int32_t pad,
+                               int32_t Tp, f2g_stream_t stream) {
+  if (!out || !x || pad < 0 || pad >= T || Tp < T + 2 * pad) return F2G_EINVAL;
+  if (B <= 0) return F2G_OK;
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(f2g_grid_for((int64_t)B * Tp, 256)), dim3(256), 0,
+                     (hipStream_t)stream, out, x, B, T, pad, Tp);
+  return f2g_check_launch();
+}

@@ -359,7 +359,7 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     Wd, Wi = dft_matrices(N, dev)
     ldp = ops.pad4(Cin)
     packed = ops.empty(rows, ldp, device=dev)
-    gemm(win1d(x, B, T, 1, F, hop, N // 2, N, reflect=True), mat(Wd), packed)
+    gemm(ops.stft_frames(x, N, hop, F), mat(Wd), packed, split_k=1)   # spectra stay bit-reproducible
     h0 = ops.empty(rows, Cc, device=dev)
     gemm(mat(packed, rows, Cin), mat(bv.w_in.reshape(Cc, Cin)), h0, bias=bv.b_in)
     flags = [_limit_draw(training)]
@@ -600,7 +600,7 @@ def stft_packed(x, n_fft: int, hop: int):
     F = 1 + T // hop
     Wd, _ = dft_matrices(n_fft, dev)
     packed = ops.empty(B * F, ops.pad4(n_fft + 2), device=dev)
-    gemm(win1d(x, B, T, 1, F, hop, n_fft // 2, n_fft, reflect=True), mat(Wd), packed)
+    gemm(ops.stft_frames(x, n_fft, hop, F), mat(Wd), packed, split_k=1)   # never split: bit-reproducible
     return packed, F
 
 

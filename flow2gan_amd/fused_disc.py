@@ -385,8 +385,8 @@ def _mrd_forward_one(x2, win: int, prm: list):
     ops.peaknorm_fwd(xn, stats, x2, S, T)
     ldp = ops.pad4(2 * nb)
     packed = ops.empty(S * Ft, ldp, device=dev)
-    gemm(win1d(xn, S, T, 1, Ft, hop, win // 2, win, reflect=True), mat(dft_interleaved(win, dev)),
-         packed)
+    gemm(ops.stft_frames(xn, win, hop, Ft), mat(dft_interleaved(win, dev)),
+         packed, split_k=1)
     bands = _band_edges(win)
     # widths per band per layer
     widths = []

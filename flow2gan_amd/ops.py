@@ -784,6 +784,21 @@ def zeros_many(shapes, device):
     return [flat[o:o + n].view(*sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
+def stft_frames(x, n_fft: int, hop: int, F: int) -> Operand:
+    """Framing operand of an STFT (center=True, reflect): rows = (item, frame m), cols = the n_fft
+    samples [m*hop, m*hop + n_fft) of the reflect-padded signal.  The padding is materialised once
+    (B x (T + n_fft) floats) so that the frames are plain overlapping rows -- no bounds tests or
+    mirroring in the GEMM's K loop (the lean kernel applies)."""
+    B, T = x.shape
+    pad = n_fft // 2
+    Tp = pad4(T + 2 * pad)
+    if hop % 4 or n_fft % 32:
+        return win1d(x, B, T, 1, F, hop, pad, n_fft, reflect=True)
+    xp = torch.empty(B, Tp, device=x.device, dtype=torch.float32)
+    call("f2g_reflect_pad", ptr(xp), ptr(x), B, T, pad, Tp)
+    return win1d(xp, B, Tp, 1, F, hop, 0, n_fft)
+
+
 def period_fold(out, x, B, T, p, H):
     call("f2g_period_fold", ptr(out), ptr(x), B, T, p, H)
 

@@ -332,6 +332,11 @@ int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w, co
 int f2g_lrelu_bwd_colsum(float* g, const float* y_act, const float* f_real, float w,
                          const float* wdev, float slope, int32_t rows, int32_t C, int64_t ld,
                          float* colsum, f2g_stream_t stream);
+/* out (B, Tp) = reflect padding of x (B, T) by `pad` samples on both sides (torch.stft center=True,
+ * modules.py:69-78), zeros from T + 2*pad to Tp (row length, a multiple of 4): the STFT framing
+ * GEMM then reads plain overlapping rows (frame m = samples [m*hop, m*hop + n_fft) of a row). */
+int f2g_reflect_pad(float* out, const float* x, int32_t B, int32_t T, int32_t pad, int32_t Tp,
+                    f2g_stream_t stream);
 int f2g_period_fold(float* out, const float* x, int32_t B, int32_t T, int32_t p, int32_t H,
                     f2g_stream_t stream);
 int f2g_period_fold_bwd(float* gx, const float* gout, int32_t B, int32_t T, int32_t p, int32_t H,

@@ -68,6 +68,15 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
+def _single(rank, world, port, outdir):
+    """What rank `rank` computes on its own (no exchange), in a fresh process with the workers'
+    environment (F2G_DETERMINISTIC=1: no library-chosen split-K / stream-K)."""
+    torch.cuda.set_device(0)
+    from flow2gan_amd import dist as fdist
+    gan, logmel = _build()
+    torch.save(_steps(gan, logmel, rank, fdist.GradReducer()), os.path.join(outdir, f"single{rank}.pt"))
+
+
 def test_two_ranks_average_the_single_rank_gradients(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
@@ -80,11 +89,10 @@ def test_two_ranks_average_the_single_rank_gradients(tmp_path):
     # fresh worker processes, free port, killed (and the test failed) after 150 s
     run_workers("test_zz_hip_dist", "_worker", 2, str(tmp_path), timeout=150.0,
                 env={"F2G_DETERMINISTIC": "1"})
-    # what each rank computes on its own (no exchange), in this process
-    singles = []
-    for r in range(2):
-        gan, logmel = _build()
-        singles.append(_steps(gan, logmel, r, fdist.GradReducer()))
+    # what each rank computes on its own (no exchange): fresh processes, same environment
+    run_workers("test_zz_hip_dist", "_single", 2, str(tmp_path), timeout=150.0,
+                env={"F2G_DETERMINISTIC": "1"})
+    singles = [torch.load(tmp_path / f"single{r}.pt") for r in range(2)]
     for r in range(2):
         got = torch.load(tmp_path / f"rank{r}.pt")
         for name in ("D", "G"):
