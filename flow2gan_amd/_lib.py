@@ -96,6 +96,13 @@ class Conv2chDesc(C.Structure):  # == f2g_conv2ch_desc
                 ("gx", C.c_void_p), ("gx_seq", C.c_int64), ("gx_line", C.c_int64)]
 
 
+class FftDesc(C.Structure):  # == f2g_fft_desc
+    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("hop", C.c_int32), ("n_fft", C.c_int32),
+                ("F", C.c_int32), ("rows", C.c_int32), ("window", C.c_void_p), ("twiddle", C.c_void_p),
+                ("spec", C.c_void_p), ("ld_spec", C.c_int64), ("interleaved", C.c_int32),
+                ("_pad", C.c_int32), ("frames", C.c_void_p), ("ld_frames", C.c_int64)]
+
+
 class SadamGroup(C.Structure):  # == f2g_sadam_group
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("scalar_lr_scale", C.c_float), ("eps", C.c_float), ("param_min_rms", C.c_float),
@@ -146,6 +153,7 @@ _SIGS = {
     "f2g_peaknorm_bwd": [_P, _P, _P, _P, _I, _I],
     "f2g_lrelu_bwd": [_P, _P, _P, _F, _P, _F, _I, _I, _L],
     "f2g_reflect_pad": [_P, _P, _I, _I, _I, _I],
+    "f2g_fft_frames": [C.POINTER(FftDesc), _I],
     "f2g_period_fold": [_P, _P, _I, _I, _I, _I],
     "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
     "f2g_fill": [_P, _F, _L],

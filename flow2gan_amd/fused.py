@@ -359,7 +359,10 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     Wd, Wi = dft_matrices(N, dev)
     ldp = ops.pad4(Cin)
     packed = ops.empty(rows, ldp, device=dev)
-    gemm(ops.stft_frames(x, N, hop, F), mat(Wd), packed, split_k=1)   # spectra stay bit-reproducible
+    if ops.fft_applies(N):
+        ops.stft_fft(x, N, hop, F, packed)
+    else:
+        gemm(ops.stft_frames(x, N, hop, F), mat(Wd), packed, split_k=1)   # spectra stay bit-reproducible
     h0 = ops.empty(rows, Cc, device=dev)
     gemm(mat(packed, rows, Cin), mat(bv.w_in.reshape(Cc, Cin)), h0, bias=bv.b_in)
     flags = [_limit_draw(training)]
@@ -457,7 +460,10 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
         gpacked = ops.empty(rows, ldp, device=dev)
         gemm(mat(gh0, rows, Cc), mat(bv.w_in.reshape(Cc, Cin)), gpacked, form=1)
         gxf = ops.empty(rows, N, device=dev)
-        gemm(mat(gpacked, rows, Cin), mat(Wd), gxf, form=1)
+        if ops.fft_applies(N):
+            ops.stft_fft_adjoint(gpacked, N, F, gxf)
+        else:
+            gemm(mat(gpacked, rows, Cin), mat(Wd), gxf, form=1)
         if lanes is not None:
             lanes.chain_enter()  # g_x is accumulated branch after branch
         ops.frames_fold(gxf, g_x, B, F, N, hop, T, accumulate_gx)
@@ -600,7 +606,10 @@ def stft_packed(x, n_fft: int, hop: int):
     F = 1 + T // hop
     Wd, _ = dft_matrices(n_fft, dev)
     packed = ops.empty(B * F, ops.pad4(n_fft + 2), device=dev)
-    gemm(ops.stft_frames(x, n_fft, hop, F), mat(Wd), packed, split_k=1)   # never split: bit-reproducible
+    if ops.fft_applies(n_fft):
+        ops.stft_fft(x, n_fft, hop, F, packed)   # LDS-butterfly FFT (fft.hip): n_fft >= 1024
+    else:
+        gemm(ops.stft_frames(x, n_fft, hop, F), mat(Wd), packed, split_k=1)   # never split: bit-reproducible
     return packed, F
 
 
@@ -629,7 +638,10 @@ def filterbank_spec_bwd(gS, packed, n_fft: int, hop: int, fb, power: int, B: int
     ops.spec_power_bwd(gpacked, gspec, packed, rows, nb, power)
     Wd, _ = dft_matrices(n_fft, dev)
     gfr = ops.empty(rows, n_fft, device=dev)
-    gemm(mat(gpacked, rows, n_fft + 2), mat(Wd), gfr, form=1)
+    if ops.fft_applies(n_fft):
+        ops.stft_fft_adjoint(gpacked, n_fft, F, gfr)
+    else:
+        gemm(mat(gpacked, rows, n_fft + 2), mat(Wd), gfr, form=1)
     if lanes is not None:
         lanes.chain_enter()  # g_x is accumulated scale after scale
     ops.frames_fold(gfr, g_x, B, F, n_fft, hop, T, accumulate)

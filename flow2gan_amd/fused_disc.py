@@ -385,8 +385,11 @@ def _mrd_forward_one(x2, win: int, prm: list):
     ops.peaknorm_fwd(xn, stats, x2, S, T)
     ldp = ops.pad4(2 * nb)
     packed = ops.empty(S * Ft, ldp, device=dev)
-    gemm(ops.stft_frames(xn, win, hop, Ft), mat(dft_interleaved(win, dev)),
-         packed, split_k=1)
+    if ops.fft_applies(win):
+        ops.stft_fft(xn, win, hop, Ft, packed, interleaved=True)
+    else:
+        gemm(ops.stft_frames(xn, win, hop, Ft), mat(dft_interleaved(win, dev)),
+             packed, split_k=1)
     bands = _band_edges(win)
     # widths per band per layer
     widths = []
@@ -674,7 +677,10 @@ class MRDLossFn(torch.autograd.Function):
                 foff += W4
             if not train_disc:
                 gfr = ops.empty(B * Ft, win, device=dev)
-                gemm(mat(g_packed, B * Ft, 2 * nb), mat(dft_interleaved(win, dev)), gfr, form=1)
+                if ops.fft_applies(win):
+                    ops.stft_fft_adjoint(g_packed, win, Ft, gfr, interleaved=True)
+                else:
+                    gemm(mat(g_packed, B * Ft, 2 * nb), mat(dft_interleaved(win, dev)), gfr, form=1)
                 gxn = ops.empty(B, T, device=dev)
                 ops.frames_fold(gfr, gxn, B, Ft, win, hop, T, False)
                 gx2 = ops.empty(B, T, device=dev)

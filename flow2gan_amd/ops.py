@@ -784,6 +784,60 @@ def zeros_many(shapes, device):
     return [flat[o:o + n].view(*sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
+# ------------------------------------------------------------------ LDS-butterfly FFT (n_fft >= 1024)
+USE_FFT = _os.environ.get("F2G_FFT", "1") != "0"
+FFT_MIN = 1024          # smaller transforms stay on the DFT GEMM (K <= 512: a short, full-rate GEMM)
+_FFT_TABLES = {}
+
+
+def fft_applies(n_fft: int) -> bool:
+    return USE_FFT and FFT_MIN <= n_fft <= 4096 and (n_fft & (n_fft - 1)) == 0
+
+
+def _fft_tables(n_fft: int, device):
+    """(hann window, twiddles (cos, -sin)(2 pi j / N)), computed in float64, cached per device."""
+    import math
+    key = (n_fft, str(device))
+    if key not in _FFT_TABLES:
+        j = torch.arange(n_fft // 2, dtype=torch.float64)
+        ang = 2.0 * math.pi * j / n_fft
+        tw = torch.stack([torch.cos(ang), -torch.sin(ang)], dim=1).float().contiguous().to(device)
+        win = torch.hann_window(n_fft, dtype=torch.float32).to(device)
+        _FFT_TABLES[key] = (win, tw)
+    return _FFT_TABLES[key]
+
+
+def stft_fft(x, n_fft: int, hop: int, F: int, spec, interleaved: bool = False):
+    """spec (B*F, ld) = STFT of x (B, T) (center, reflect, periodic hann) through the LDS FFT."""
+    B, T = x.shape
+    pad = n_fft // 2
+    Tp = pad4(T + 2 * pad)
+    xp = torch.empty(B, Tp, device=x.device, dtype=torch.float32)
+    call("f2g_reflect_pad", ptr(xp), ptr(x), B, T, pad, Tp)
+    win, tw = _fft_tables(n_fft, x.device)
+    d = L.FftDesc()
+    d.x, d.x_stride, d.hop, d.n_fft, d.F, d.rows = ptr(xp), Tp, hop, n_fft, F, B * F
+    d.window, d.twiddle = ptr(win), ptr(tw)
+    d.spec, d.ld_spec, d.interleaved = ptr(spec), spec.stride(0), 1 if interleaved else 0
+    call("f2g_fft_frames", C.byref(d), 0)
+    d._keep = (xp, win, tw)
+    return spec
+
+
+def stft_fft_adjoint(gspec, n_fft: int, F: int, gframes, interleaved: bool = False):
+    """gframes (rows, n_fft) = gradient of the (windowed) frames given the gradient of the stored
+    bins gspec (rows, ld): the adjoint of stft_fft; frames_fold scatters it back onto the signal."""
+    rows = gframes.shape[0]
+    win, tw = _fft_tables(n_fft, gspec.device)
+    d = L.FftDesc()
+    d.hop, d.n_fft, d.F, d.rows = 0, n_fft, F, rows
+    d.window, d.twiddle = ptr(win), ptr(tw)
+    d.spec, d.ld_spec, d.interleaved = ptr(gspec), gspec.stride(0), 1 if interleaved else 0
+    d.frames, d.ld_frames = ptr(gframes), gframes.stride(0)
+    call("f2g_fft_frames", C.byref(d), 1)
+    return gframes
+
+
 def stft_frames(x, n_fft: int, hop: int, F: int) -> Operand:
     """Framing operand of an STFT (center=True, reflect): rows = (item, frame m), cols = the n_fft
     samples [m*hop, m*hop + n_fft) of the reflect-padded signal.  The padding is materialised once

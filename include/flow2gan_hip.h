@@ -332,6 +332,28 @@ int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w, co
 int f2g_lrelu_bwd_colsum(float* g, const float* y_act, const float* f_real, float w,
                          const float* wdev, float slope, int32_t rows, int32_t C, int64_t ld,
                          float* colsum, f2g_stream_t stream);
+/* Batched real FFT of STFT frames through LDS butterflies (fft.hip; modules.py:69-78)
+ * for n_fft = 256..4096 (power of two).  rows = items * F frames; frame m of an item is the n_fft
+ * samples x[item*x_stride + m*hop + n] of the REFLECT-PADDED signal (f2g_reflect_pad), multiplied by
+ * `window`.  spec rows are planar [Re(0..N/2) | Im(0..N/2)] or interleaved [Re0, Im0, ...].
+ *   adjoint = 0: spec = FFT(window * frame)                     (replaces the windowed-DFT GEMM)
+ *   adjoint = 1: frames[row, n] = window[n] * Re sum_{k<=N/2} (spec_r[k] + i spec_i[k]) e^{+i theta}
+ *                (the gradient of the frames given the gradient of the stored bins)
+ * twiddle: n_fft/2 pairs (cos, -sin)(2 pi j / n_fft). */
+typedef struct {
+  const float* x;
+  int64_t x_stride;
+  int32_t hop, n_fft, F, rows;
+  const float* window;
+  const float* twiddle;
+  float* spec;
+  int64_t ld_spec;
+  int32_t interleaved, _pad;
+  float* frames;
+  int64_t ld_frames;
+} f2g_fft_desc;
+int f2g_fft_frames(const f2g_fft_desc* d, int32_t adjoint, f2g_stream_t stream);
+
 /* out (B, Tp) = reflect padding of x (B, T) by `pad` samples on both sides (torch.stft center=True,
  * modules.py:69-78), zeros from T + 2*pad to Tp (row length, a multiple of 4): the STFT framing
  * GEMM then reads plain overlapping rows (frame m = samples [m*hop, m*hop + n_fft) of a row). */

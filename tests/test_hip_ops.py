@@ -114,6 +114,53 @@ def test_stft_as_windowed_gemm(ops, n_fft, hop, T):
     close(packed[:, :2 * nb], want, rtol=3e-5, name="stft")
 
 
+@pytest.mark.parametrize("n_fft,hop,T,inter", [(1024, 256, 6000, False), (2048, 512, 24000, True),
+                                               (4096, 1024, 9000, False), (1024, 256, 5003, True)])
+def test_stft_lds_fft_forward_and_adjoint(ops, n_fft, hop, T, inter):
+    """LDS-butterfly FFT (fft.hip) against torch.stft in float64 (modules.py:69-78): spectrum in the
+    planar and the interleaved row layout, and its adjoint against autograd."""
+    B = 3
+    assert ops.fft_applies(n_fft)
+    x = rnd(B, T, seed=11, scale=0.1)
+    Fr = 1 + T // hop
+    nb = n_fft // 2 + 1
+    ld = ops.pad4(2 * nb)
+    spec = torch.full((B * Fr, ld), 7.0, device=DEV)
+    ops.stft_fft(g(x), n_fft, hop, Fr, spec, interleaved=inter)
+    xd = x.double().requires_grad_(True)
+    ref = torch.stft(xd, n_fft, hop, n_fft, torch.hann_window(n_fft).double(), center=True,
+                     return_complex=True)
+    assert ref.shape[2] == Fr
+    if inter:
+        want = torch.stack([ref.real, ref.imag], -1).permute(0, 2, 1, 3).reshape(B * Fr, 2 * nb)
+    else:
+        want = torch.cat([ref.real, ref.imag], 1).permute(0, 2, 1).reshape(B * Fr, 2 * nb)
+    close(spec[:, :2 * nb], want.detach(), rtol=5e-6, name="fft-stft")
+    # adjoint: d<gs, stft(x)>/dx through frames_fold
+    gs = rnd(B * Fr, ld, seed=12)
+    gfr = torch.empty(B * Fr, n_fft, device=DEV)
+    ops.stft_fft_adjoint(g(gs), n_fft, Fr, gfr, interleaved=inter)
+    gx = torch.empty(B, T, device=DEV)
+    ops.frames_fold(gfr, gx, B, Fr, n_fft, hop, T, False)
+    (want * gs[:, :2 * nb].double()).sum().backward()
+    close(gx, xd.grad, rtol=5e-6, name="fft-stft-adjoint")
+
+
+def test_stft_fft_agrees_with_dft_gemm(ops):
+    """Both STFT paths of stft_packed give the same spectra (frame indexing identical)."""
+    from flow2gan_amd.fused import stft_packed
+    x = g(rnd(2, 7000, seed=3, scale=0.1))
+    a, Fa = stft_packed(x, 1024, 256)
+    old = ops.USE_FFT
+    ops.USE_FFT = False
+    try:
+        b, Fb = stft_packed(x, 1024, 256)
+    finally:
+        ops.USE_FFT = old
+    assert Fa == Fb and a.shape == b.shape
+    close(a[:, :1026], b[:, :1026].double(), rtol=3e-5, name="fft-vs-gemm")
+
+
 def test_conv1d_k3_windowed(ops):
     B, Cin, Fm, Cout = 3, 100, 37, 64
     x, w, b = rnd(B, Cin, Fm, seed=1), rnd(Cout, Cin, 3, seed=2), rnd(Cout, seed=3)
