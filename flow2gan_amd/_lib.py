@@ -23,7 +23,7 @@ class Operand(C.Structure):
         ("step1", C.c_int32), ("pad1", C.c_int32), ("L1", C.c_int32),
         ("step0", C.c_int32), ("pad0", C.c_int32), ("unit", C.c_int32), ("L0u", C.c_int32),
         ("seq_stride", C.c_int64), ("line_stride", C.c_int64),
-        ("reflect", C.c_int32), ("_pad", C.c_int32),
+        ("reflect", C.c_int32), ("split", C.c_int32),
         ("alpha", C.c_void_p), ("lrelu_src", C.c_void_p),
         ("lrelu_slope", C.c_float), ("_pad2", C.c_int32),
     ]
@@ -123,6 +123,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # name -> argtypes (stream appended automatically)
 _SIGS = {
     "f2g_gemm": [C.POINTER(GemmDesc)],
+    "f2g_split_bf16": [_P, _P, _L],
     "f2g_dwnorm_fwd": [C.POINTER(DwnormFwd)],
     "f2g_dwnorm_bwd": [C.POINTER(DwnormBwd)],
     "f2g_dwconv_bwd": [C.POINTER(DwconvBwd)],
@@ -176,6 +177,7 @@ _SIGS = {
     "f2g_sadam_update": [_P, _P, _I, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
+                                 "f2g_gemm_lean_ok",
                                  "f2g_dwnorm_bwd_workspace",
                                  "f2g_dwconv_bwd_workspace", "f2g_sadam_chunk_elems"])
 
@@ -198,6 +200,8 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = [C.c_int32] * 4
         fn.restype = C.c_int64
+    lib.f2g_gemm_lean_ok.argtypes = [C.POINTER(GemmDesc)]
+    lib.f2g_gemm_lean_ok.restype = C.c_int
     lib.f2g_sadam_chunk_elems.argtypes = []
     lib.f2g_sadam_chunk_elems.restype = C.c_int32
     lib.f2g_version.restype = C.c_char_p

@@ -900,6 +900,7 @@ inline int op_mode(const f2g_operand& S, bool red_is_cols) {
 // their source (plain matrices, and conv windows over buffers that carry their zero padding as
 // halo rows): every 1x1 conv, the MPD convs and their data gradients (transposed weights).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r) {
   if (r >= S.rows) return 0x80000000u;
@@ -920,7 +921,13 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
 //   0 plain store (+ residual*gamma, leaky ReLU, fused PReLU)   1 PReLU backward (+ column sums)
 //   2 row-mapped store (halo layout; + leaky ReLU, or leaky-ReLU backward of the layer below)
 //   3 everything else (generic epilogue; the only one stream-K instances use)
-template <bool SK, int EP>
+// P3 (split-bf16, precision 1): both operands arrive PRE-SPLIT (f2g_split_bf16: every aligned group
+// of four floats replaced by its four bf16 high parts and four bf16 remainders, same 16 bytes, same
+// addressing), so the K loop stays free of VALU work: a staged 16-byte chunk goes to LDS as two
+// 8-byte halves (row = [hi k0..31 | lo k0..31 | pad], the fp32 tile's 144-byte pitch), fragments are
+// ds_read_b128 of eight consecutive k, and every product is lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_32x32x16_bf16 (24 MFMAs of 32 cycles per wave and slab instead of 64 of 64).
+template <bool SK, int EP, bool P3>
 __global__ __launch_bounds__(256, 2)
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
   constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
@@ -940,10 +947,10 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   const int seglen = d.A.seglen < d.A.cols ? d.A.seglen : d.A.cols;
   const int spseg = seglen / BK;                                  // slabs per segment
   const int segjump = (int)((d.A.line_stride - seglen) * 4);      // bytes skipped at a segment end
-  float* wA = smem + rr * LDR + ch * 4;
-  float* wB = smem + 2 * TSZ + rr * LDR + ch * 4;
-  const float* rA = smem + (wm * 64 + li) * LDR + h * 16;
-  const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * 16;
+  float* wA = smem + rr * LDR + ch * (P3 ? 2 : 4);
+  float* wB = smem + 2 * TSZ + rr * LDR + ch * (P3 ? 2 : 4);
+  const float* rA = smem + (wm * 64 + li) * LDR + h * (P3 ? 4 : 16);
+  const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * (P3 ? 4 : 16);
 
   // ---- work of this block.  Classic: one tile (blockIdx.x/y), K chunk blockIdx.z.  Stream-K
   // (upb > 0): the (tile, slab) units of the whole problem are numbered tile-major and every
@@ -1021,11 +1028,45 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
     auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<u32x4*>(wA + bufoff + q * 32 * LDR) = la[q];
-        *reinterpret_cast<u32x4*>(wB + bufoff + q * 32 * LDR) = lb[q];
+        if constexpr (P3) {
+          *reinterpret_cast<u32x2*>(wA + bufoff + q * 32 * LDR) = u32x2{la[q].x, la[q].y};
+          *reinterpret_cast<u32x2*>(wA + bufoff + q * 32 * LDR + 16) = u32x2{la[q].z, la[q].w};
+          *reinterpret_cast<u32x2*>(wB + bufoff + q * 32 * LDR) = u32x2{lb[q].x, lb[q].y};
+          *reinterpret_cast<u32x2*>(wB + bufoff + q * 32 * LDR + 16) = u32x2{lb[q].z, lb[q].w};
+        } else {
+          *reinterpret_cast<u32x4*>(wA + bufoff + q * 32 * LDR) = la[q];
+          *reinterpret_cast<u32x4*>(wB + bufoff + q * 32 * LDR) = lb[q];
+        }
       }
     };
     auto mfma_slab = [&](int bufoff) {
+      if constexpr (P3) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            ah[mi] = *reinterpret_cast<const bf16x8*>(rA + bufoff + mi * 32 * LDR + ks * 8);
+            al[mi] = *reinterpret_cast<const bf16x8*>(rA + bufoff + mi * 32 * LDR + ks * 8 + 16);
+          }
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            bh[ni] = *reinterpret_cast<const bf16x8*>(rB + bufoff + ni * 32 * LDR + ks * 8);
+            bl[ni] = *reinterpret_cast<const bf16x8*>(rB + bufoff + ni * 32 * LDR + ks * 8 + 16);
+          }
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni) {
+                const bf16x8 av = term == 0 ? al[mi] : ah[mi];
+                const bf16x8 bv = term == 1 ? bl[ni] : bh[ni];
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
+              }
+        }
+        return;
+      }
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         float4 a[2], b[2];
@@ -1290,6 +1331,7 @@ inline bool lean_b_ok(const f2g_operand& S) {
 }
 
 int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st) {
+  const bool p3 = d.precision == 1;
   constexpr size_t smem = (size_t)4 * 128 * LDR * sizeof(float);
   int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
   int zs = (K + kchunk - 1) / kchunk;
@@ -1311,18 +1353,30 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   }
   static bool attr_done = false;
   if (!attr_done) {
-    const void* ks[5] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0>),
-                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 1>),
-                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 2>),
-                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 3>),
-                         reinterpret_cast<const void*>(gemm_lean_kernel<true, 3>)};
+    const void* ks[10] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, false>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, false>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, false>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, false>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, false>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, true>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, true>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, true>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, true>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, true>)};
     for (const void* k : ks)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   g_last_path = upb > 0 ? 2 : 1;
-#define F2G_LEAN(SKV, EPV) \
-  hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb)
+#define F2G_LEAN(SKV, EPV)                                                                        \
+  do {                                                                                            \
+    if (p3)                                                                                       \
+      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, true>), grid, dim3(256), smem, st, d, M, N,  \
+                         K, kchunk, upb);                                                         \
+    else                                                                                          \
+      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, false>), grid, dim3(256), smem, st, d, M, N, \
+                         K, kchunk, upb);                                                         \
+  } while (0)
   if (upb > 0) F2G_LEAN(true, 3);
   else if (ep == 0) F2G_LEAN(false, 0);
   else if (ep == 1) F2G_LEAN(false, 1);
@@ -1362,6 +1416,46 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
 // 2 lean kernel in stream-K mode, 3 narrow (VALU) kernels.
 extern "C" int f2g_gemm_last_path(void) { return g_last_path; }
 
+// Would f2g_gemm run this form-0 descriptor on the lean kernel (whatever its precision)?  The host
+// asks before it pre-splits the operands of a split-bf16 GEMM.
+extern "C" int f2g_gemm_lean_ok(const f2g_gemm_desc* dp) {
+  if (!dp || !dp->A.base || !dp->B.base || dp->form != 0) return 0;
+  static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
+  const f2g_gemm_desc& d = *dp;
+  if (d.A.cols != d.B.cols || !host_plain(d.B)) return 0;
+  return lean_on && d.B.rows > 64 && lean_a_ok(d.A) && lean_b_ok(d.B) ? 1 : 0;
+}
+
+// dst = split-bf16 image of src (n4 groups of four floats, both 16-byte aligned): group g becomes
+// [hi(x0) hi(x1) hi(x2) hi(x3) | lo(x0) lo(x1) lo(x2) lo(x3)], hi = bf16(x) (round to nearest even),
+// lo = bf16(x - hi): the same 16 bytes at the same address, so every operand descriptor (windows,
+// halo rows, strides -- all multiples of four floats on the lean path) addresses it unchanged.
+__global__ __launch_bounds__(256) void split_bf16_kernel(uint4* __restrict__ dst,
+                                                         const float4* __restrict__ src, long long n4) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = src[i];
+    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+    split_bf16(v.x, h0, l0);
+    split_bf16(v.y, h1, l1);
+    split_bf16(v.z, h2, l2);
+    split_bf16(v.w, h3, l3);
+    dst[i] = make_uint4(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16), l0 | ((unsigned)l1 << 16),
+                        l2 | ((unsigned)l3 << 16));
+  }
+}
+
+extern "C" int f2g_split_bf16(float* dst, const float* src, int64_t n, f2g_stream_t stream) {
+  if (!dst || !src || (n & 3) || !al16(dst) || !al16(src)) return F2G_EINVAL;
+  if (n == 0) return F2G_OK;
+  const long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<uint4*>(dst), reinterpret_cast<const float4*>(src), n4);
+  return f2g_check_launch();
+}
+
 extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   if (!dp || !dp->A.base || !dp->B.base || !dp->E.C) return F2G_EINVAL;
   const f2g_gemm_desc& d = *dp;
@@ -1391,7 +1485,11 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     // F2G_DETERMINISTIC=1: never split on the library's own initiative (bit-reproducible forward)
     static const bool no_auto = getenv("F2G_DETERMINISTIC") && atoi(getenv("F2G_DETERMINISTIC")) != 0;
     static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
-    const bool lean = !f1 && lean_on && d.precision == 0 && N > 64 && lean_a_ok(d.A) && lean_b_ok(d.B);
+    // pre-split operands (f2g_split_bf16) are understood by the lean kernel's split-bf16 instances only
+    const bool presplit = d.A.split != 0 && d.B.split != 0;
+    const bool lean = !f1 && lean_on && N > 64 && lean_a_ok(d.A) && lean_b_ok(d.B) &&
+                      (d.precision == 0 || (d.precision == 1 && presplit));
+    if ((d.A.split || d.B.split) && !(lean && d.precision == 1)) return F2G_EINVAL;
     if (lean && d.split_k == 0) {
       // library-chosen work split on the lean kernel: stream-K (same linear-epilogue condition as
       // split-K; F2G_DETERMINISTIC=1 keeps the plain tile grid)

@@ -72,6 +72,8 @@ def derived(t, tag, build):
     if hit is not None and hit[0] == stamp:
         return hit[1]
     out = build(t)
+    if isinstance(out, torch.Tensor):
+        out._f2g_const = True     # a cached re-layout of a parameter (see _split_operand)
     slot[key] = (stamp, out)
     return out
 
@@ -167,7 +169,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None.
     split_k: 0 = let the library decide (forms 0/1: split-K onto a zeroed output when the tile
     grid would leave most of the last wave of CUs idle), 1 = off, > 1 = as given."""
-    if form == 1 and LEAN_DGRAD and GEMM_PRECISION == 0:
+    if form == 1 and LEAN_DGRAD and GEMM_PRECISION in (0, 1):
         # data gradient C[r,n] = sum_k A[r,k] W[k,n] as a forward GEMM against the cached transpose
         # W^T [n][k]: same products in the same order, and the lean forward kernel applies
         src = getattr(Bm, "_src", None)
@@ -209,6 +211,10 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.form = form
     d.split_k = split_k
     d.precision = GEMM_PRECISION
+    if GEMM_PRECISION == 1 and form == 0 and LEAN_SPLIT and L.lib.f2g_gemm_lean_ok(C.byref(d)):
+        # split-bf16 on the lean kernel: both operands as pre-split images (no conversion in the K
+        # loop); weights come from the derived-weight cache, activations are split here
+        d.A, d.B = _split_operand(A), _split_operand(Bm)
     if GEMM_TIMER is not None:
         GEMM_TIMER.launch(d, A, Bm, form)
     else:
@@ -219,6 +225,51 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
 import os as _os
 
 LEAN_DGRAD = _os.environ.get("F2G_LEAN_DGRAD", "1") != "0"
+LEAN_SPLIT = _os.environ.get("F2G_LEAN_SPLIT", "1") != "0"
+
+
+def split_bf16(t):
+    """Split-bf16 image of a contiguous fp32 tensor (f2g_split_bf16): same shape, same bytes per
+    element, every aligned group of four floats = four bf16 high parts + four bf16 remainders."""
+    out = torch.empty_like(t)
+    call("f2g_split_bf16", ptr(out), ptr(t), t.numel())
+    out._f2g_const = getattr(t, "_f2g_const", False)
+    return out
+
+
+def _is_const(t) -> bool:
+    """Parameters, views of parameters and cached re-layouts of them: safe to cache images of."""
+    owner = t._base if t._base is not None else t
+    return isinstance(owner, torch.nn.Parameter) or getattr(owner, "_f2g_const", False)
+
+
+def _split_operand(o: Operand) -> Operand:
+    """Copy of a lean-eligible operand over the split-bf16 image of what it reads: the whole tensor
+    (cached until it changes) for weights, the touched range (split here, once) for activations."""
+    if o.split:
+        return o
+    t = o._keep[0]
+    n = Operand()
+    C.memmove(C.byref(n), C.byref(o), C.sizeof(Operand))
+    if _is_const(t) and t.is_contiguous() and t.numel() % 4 == 0 and (o.base - ptr(t)) % 16 == 0:
+        img = derived(t, "split", split_bf16)
+        n.base = ptr(img) + (o.base - ptr(t))
+    else:
+        nseq = o.rows // (o.P0 * o.P1)
+        nseg = o.cols // min(o.seglen, o.cols)
+        if o.P0 == 1 and o.P1 == 1:
+            extent = (o.rows - 1) * o.seq_stride + o.cols
+        else:
+            extent = (nseq - 1) * o.seq_stride + \
+                ((o.P1 - 1) * o.step1 - o.pad1 + nseg - 1) * o.line_stride + \
+                ((o.P0 - 1) * o.step0 - o.pad0) * o.unit + min(o.seglen, o.cols)
+        extent = (extent + 3) // 4 * 4
+        img = torch.empty(extent, device=t.device, dtype=torch.float32)
+        call("f2g_split_bf16", ptr(img), o.base, extent)
+        n.base = ptr(img)
+    n.split = 1
+    n._keep = (img,) + tuple(o._keep)
+    return n
 
 
 def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope: float, y):

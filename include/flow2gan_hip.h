@@ -59,7 +59,7 @@ typedef struct {
   int32_t step0, pad0, unit, L0u;
   int64_t seq_stride, line_stride;
   int32_t reflect;
-  int32_t _pad;
+  int32_t split; /* 1: `base` holds the split-bf16 image written by f2g_split_bf16 (same addressing) */
   const float* alpha;
   const float* lrelu_src;
   float lrelu_slope;
@@ -133,6 +133,16 @@ typedef struct {
 } f2g_gemm_desc;
 
 int f2g_gemm(const f2g_gemm_desc* d, f2g_stream_t stream);
+/* 1 if f2g_gemm would run this form-0 descriptor on the lean kernel (buffer loads, no VALU in the K
+ * loop), whatever its precision: the host asks before pre-splitting the operands of a precision-1
+ * GEMM.  No launch. */
+int f2g_gemm_lean_ok(const f2g_gemm_desc* d);
+/* dst = split-bf16 image of src (n floats, n % 4 == 0, both 16-byte aligned): every aligned group
+ * of four floats becomes its four bf16 high parts followed by the four bf16 remainders (x = hi + lo
+ * to ~2^-17 |x|), the same 16 bytes at the same offset.  An operand with `split = 1` over such an
+ * image is read by the lean kernel's split-bf16 instances without any conversion in the K loop
+ * (precision 1 only; both operands must be split; anything else is F2G_EINVAL). */
+int f2g_split_bf16(float* dst, const float* src, int64_t n, f2g_stream_t stream);
 /* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
  * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels. */
 int f2g_gemm_last_path(void);

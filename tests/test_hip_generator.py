@@ -267,7 +267,10 @@ def test_full_size_batch_64_reproduces_reference_waveform(f2g, golden):
     assert y.shape == (64, want.shape[1])
     worst = max(rms(y[b:b + 1], want) for b in (0, 17, 63))
     assert worst < RMS_TOL, worst
-    assert float((y - y[:1]).abs().max()) < 1e-5   # rows agree with each other
+    from flow2gan_amd import ops as _ops
+    # rows agree with each other (up to the summation order of split tiles; the opt-in split-bf16
+    # GEMM mode amplifies those last-bit differences through its 2^-16 products)
+    assert float((y - y[:1]).abs().max()) < (5e-5 if _ops.GEMM_PRECISION == 1 else 1e-5)
 
 
 def test_full_width_stage1_loss_and_grads_vs_oracle_then_batch_64(f2g, monkeypatch):

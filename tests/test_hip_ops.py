@@ -69,6 +69,75 @@ def test_gemm_forward_epilogues(ops):
     assert float(out3[:, N:].min()) == 7.0
 
 
+def test_split_bf16_image_roundtrip(ops):
+    """f2g_split_bf16: hi + lo reproduces x to ~2^-17 |x|, group layout [hi x4 | lo x4]."""
+    x = rnd(37, 64, seed=9)
+    img = ops.split_bf16(g(x)).cpu()
+    u = img.view(torch.int16).reshape(-1, 8).to(torch.int32) & 0xFFFF
+    hi = (u[:, :4] << 16).to(torch.int32).view(torch.float32).reshape(x.shape)
+    lo = (u[:, 4:] << 16).to(torch.int32).view(torch.float32).reshape(x.shape)
+    assert torch.equal(hi, x.bfloat16().float())
+    assert float(((hi.double() + lo.double()) - x.double()).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+
+
+@pytest.mark.parametrize("R,K,N", [(300, 512, 96), (1000, 64, 1536), (129, 1536, 512), (4100, 160, 130)])
+def test_gemm_split_bf16_on_the_lean_kernel(ops, R, K, N):
+    """precision 1 with pre-split operands (lean kernel, no conversion in the K loop): products
+    hi*hi + hi*lo + lo*hi, fp32 accumulation -- error ~2^-16 per product; epilogues as in fp32."""
+    A, W, b = rnd(R, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    res, gam, ps = rnd(R, N, seed=4), rnd(N, seed=5), rnd(N, seed=6) * 0.3
+    was = ops.GEMM_PRECISION
+    ops.set_gemm_precision("bf16x3")
+    try:
+        lib = ops.L.lib
+        out = torch.empty(R, N, device=DEV)
+        ops.gemm(ops.mat(g(A)), ops.mat(g(W)), out, bias=g(b))
+        assert lib.f2g_gemm_last_path() in (1, 2), "split-bf16 GEMM did not take the lean kernel"
+        ref = A.double() @ W.double().t() + b.double()
+        close(out, ref, rtol=3e-5, name="lean3")
+        out2 = torch.empty(R, N, device=DEV)
+        ops.gemm(ops.mat(g(A)), ops.mat(g(W)), out2, bias=g(b), res=g(res), gamma=g(gam), split_k=1)
+        assert lib.f2g_gemm_last_path() == 1
+        close(out2, ref + gam.double() * res.double(), rtol=3e-5, name="lean3-res")
+        pre, act = torch.empty(R, N, device=DEV), torch.empty(R, N, device=DEV)
+        ops.gemm(ops.mat(g(A)), ops.mat(g(W)), pre, bias=g(b), prelu=g(ps), prelu_out=act, split_k=1)
+        close(pre, ref, rtol=3e-5, name="lean3-pre")
+        close(act, torch.where(ref > 0, ref, ref * ps.double()[None]), rtol=3e-5, name="lean3-prelu")
+        # data gradient against the cached transposed (and split) weight
+        Wk = rnd(K, N, seed=7)
+        Wk_d = torch.nn.Parameter(g(Wk))
+        out3 = torch.empty(R, N, device=DEV)
+        ops.gemm(ops.mat(g(A)), ops.mat(Wk_d), out3, form=1)
+        if K % 32 == 0 and N > 64:
+            assert lib.f2g_gemm_last_path() in (1, 2)
+        close(out3, A.double() @ Wk.double(), rtol=3e-5, name="lean3-dgrad")
+        # ... which follows an in-place update of the weight
+        with torch.no_grad():
+            Wk_d.mul_(2.0)
+        ops.gemm(ops.mat(g(A)), ops.mat(Wk_d), out3, form=1)
+        close(out3, 2.0 * (A.double() @ Wk.double()), rtol=3e-5, name="lean3-dgrad-updated")
+    finally:
+        ops.GEMM_PRECISION = was
+
+
+def test_gemm_split_bf16_windowed_operand(ops):
+    """MPD-style (5,1) conv over a halo layout in split-bf16: the window addressing of the lean
+    kernel is unchanged by the split image."""
+    S, H, Cin, Cout = 6, 96, 32, 128          # stride 1, taps 5: rows = S * (H - 4)
+    x, w = rnd(S, H, Cin, seed=1), rnd(Cout, 5 * Cin, seed=2)
+    Hout = H - 4
+    was = ops.GEMM_PRECISION
+    ops.set_gemm_precision("bf16x3")
+    try:
+        out = torch.empty(S * Hout, Cout, device=DEV)
+        ops.gemm(ops.win1d(g(x), S, H, Cin, Hout, 1, 0, 5), ops.mat(g(w)), out, split_k=1)
+        assert ops.L.lib.f2g_gemm_last_path() == 1
+    finally:
+        ops.GEMM_PRECISION = was
+    cols = torch.stack([x[:, i:i + Hout] for i in range(5)], 2).reshape(S * Hout, 5 * Cin)
+    close(out, cols.double() @ w.double().t(), rtol=3e-5, name="lean3-window")
+
+
 @pytest.mark.parametrize("R,K,N", [(300, 96, 514), (64, 1536, 512), (1000, 24, 72)])
 def test_gemm_dgrad_with_prelu_grad(ops, R, K, N):
     G, W = rnd(R, K, seed=1), rnd(K, N, seed=2)
