@@ -83,7 +83,7 @@ class Conv32Desc(C.Structure):  # == f2g_conv32_desc
     _fields_ = [("x", C.c_void_p), ("x_seq", C.c_int64), ("x_line", C.c_int64),
                 ("S", C.c_int32), ("H", C.c_int32), ("Win", C.c_int32), ("Wout", C.c_int32),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("lrelu_slope", C.c_float),
-                ("_pad", C.c_int32), ("y", C.c_void_p), ("y_seq", C.c_int64), ("y_line", C.c_int64),
+                ("precision", C.c_int32), ("y", C.c_void_p), ("y_seq", C.c_int64), ("y_line", C.c_int64),
                 ("mask_src", C.c_void_p), ("fm_ref", C.c_void_p), ("fm_wdev", C.c_void_p),
                 ("mask_slope", C.c_float), ("fm_w", C.c_float), ("colsum", C.c_void_p)]
 

@@ -27,6 +27,58 @@ constexpr int TG = 2;                   // taps per barrier (weights double-buff
 
 __device__ __attribute__((aligned(16))) float c32_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
+// ---- split-bf16 variants (P3; f2g_conv32_desc.precision = 1) -----------------------------------
+// Same tiling; every product is lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 (6 MFMAs of 32
+// cycles per tap and wave instead of 16 of 64).  A staged pixel keeps its 144-byte pitch as
+// [32 hi | 32 lo | pad]: the patch is split ONCE per block while it is staged (each element then
+// feeds 27 taps x 32 outputs), the weight tiles arrive pre-split (f2g_split_bf16 image of the same
+// packed matrix, same addressing) and go to LDS as two 8-byte halves.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b, float& ra, float& rb) {
+  const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+  ra = a - (float)ha;
+  rb = b - (float)hb;
+  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+
+// write the split image of four floats: hi half at p, lo half 16 floats (64 bytes) further
+__device__ __forceinline__ void store_split4(float* p, const float4 v) {
+  float r0, r1, r2, r3, z0, z1;
+  u32x2 hi, lo;
+  hi.x = pack_bf16(v.x, v.y, r0, r1);
+  hi.y = pack_bf16(v.z, v.w, r2, r3);
+  lo.x = pack_bf16(r0, r1, z0, z1);
+  lo.y = pack_bf16(r2, r3, z0, z1);
+  *reinterpret_cast<u32x2*>(p) = hi;
+  *reinterpret_cast<u32x2*>(p + 16) = lo;
+}
+
+__device__ __forceinline__ void store_presplit4(float* p, const float4 v) {
+  *reinterpret_cast<u32x2*>(p) = u32x2{__float_as_uint(v.x), __float_as_uint(v.y)};
+  *reinterpret_cast<u32x2*>(p + 16) = u32x2{__float_as_uint(v.z), __float_as_uint(v.w)};
+}
+
+// one tap: A = pixel row (pitch 144 B, this lane's pixel), B = weight row (this lane's channel)
+__device__ __forceinline__ void tap_mfma3(const float* Ab, const float* Bb, int hh, f32x16& acc, f32x16& acc2) {
+  bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    ah[ks] = *reinterpret_cast<const bf16x8*>(Ab + (2 * ks + hh) * 4);
+    al[ks] = *reinterpret_cast<const bf16x8*>(Ab + (2 * ks + hh) * 4 + 16);
+    bh[ks] = *reinterpret_cast<const bf16x8*>(Bb + (2 * ks + hh) * 4);
+    bl[ks] = *reinterpret_cast<const bf16x8*>(Bb + (2 * ks + hh) * 4 + 16);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh[0], acc, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh[1], acc2, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl[0], acc, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl[1], acc2, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh[0], acc, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh[1], acc2, 0, 0, 0);
+}
+
+template <bool P3>
 __global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_desc d) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* At = sm;                 // [2 parities][IH][IW][PITCH]
@@ -49,12 +101,15 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_
     const bool ok = h >= 0 && h < d.H && x >= 0 && x < d.Win;
     const float* p = ok ? xs + (long long)h * d.x_line + (long long)x * C + c4 * 4 : c32_zero;
     const float4 v = *reinterpret_cast<const float4*>(p);
-    *reinterpret_cast<float4*>(At + (xr & 1) * SUB + (r * IW + (xr >> 1)) * PITCH + c4 * 4) = v;
+    if constexpr (P3) store_split4(At + (xr & 1) * SUB + (r * IW + (xr >> 1)) * PITCH + c4 * 2, v);
+    else *reinterpret_cast<float4*>(At + (xr & 1) * SUB + (r * IW + (xr >> 1)) * PITCH + c4 * 4) = v;
   }
   // weights: thread = (tap of the group, co, 4 input channels); group 0 -> buffer 0
   const int wu = tid >> 8, wco = (tid & 255) >> 3, wc4 = tid & 7;
   const float* wrow = d.w + (long long)wco * (KH * KW * C) + wc4 * 4;
-  *reinterpret_cast<float4*>(Bt + wu * WB + wco * PITCH + wc4 * 4) =
+  if constexpr (P3) store_presplit4(Bt + wu * WB + wco * PITCH + wc4 * 2,
+                                    *reinterpret_cast<const float4*>(wrow + wu * C));
+  else *reinterpret_cast<float4*>(Bt + wu * WB + wco * PITCH + wc4 * 4) =
       *reinterpret_cast<const float4*>(wrow + wu * C);
   __syncthreads();
 
@@ -80,8 +135,10 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_
       const int t = gidx * TG + u;
       if (t < KH * KW) {
         const int dh = t / KW, j = t - dh * KW;
-        const float* Ab = At + (j & 1) * SUB + ((ph + dh) * IW + pw + (j >> 1)) * PITCH + kk0;
-        const float* Bb = Bt + (cur * TG + u) * WB + li * PITCH + kk0;
+        const float* Ab = At + (j & 1) * SUB + ((ph + dh) * IW + pw + (j >> 1)) * PITCH + (P3 ? 0 : kk0);
+        const float* Bb = Bt + (cur * TG + u) * WB + li * PITCH + (P3 ? 0 : kk0);
+        if constexpr (P3) tap_mfma3(Ab, Bb, hh, acc, acc2);
+        else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const float4 a = *reinterpret_cast<const float4*>(Ab + s4 * 4);
@@ -93,7 +150,8 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_
         }
       }
     }
-    *reinterpret_cast<float4*>(Bt + ((cur ^ 1) * TG + wu) * WB + wco * PITCH + wc4 * 4) = wn;
+    if constexpr (P3) store_presplit4(Bt + ((cur ^ 1) * TG + wu) * WB + wco * PITCH + wc4 * 2, wn);
+    else *reinterpret_cast<float4*>(Bt + ((cur ^ 1) * TG + wu) * WB + wco * PITCH + wc4 * 4) = wn;
     __syncthreads();
   }
 #pragma unroll
@@ -134,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_
 constexpr int GW = TW + 4;               // staged gradient columns
 constexpr int GSUB = IH * GW * PITCH;
 
+template <bool P3>
 __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv32_desc d) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* At = sm;                 // [IH][GW][PITCH]
@@ -155,7 +214,8 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
     const int h = h0 - 1 + r, c = m0 - 2 + xc;
     const bool ok = h >= 0 && h < d.H && c >= 0 && c < d.Wout;
     const float* p = ok ? gs + (long long)h * d.x_line + (long long)c * C + c4 * 4 : c32_zero;
-    *reinterpret_cast<float4*>(At + (r * GW + xc) * PITCH + c4 * 4) = *reinterpret_cast<const float4*>(p);
+    if constexpr (P3) store_split4(At + (r * GW + xc) * PITCH + c4 * 2, *reinterpret_cast<const float4*>(p));
+    else *reinterpret_cast<float4*>(At + (r * GW + xc) * PITCH + c4 * 4) = *reinterpret_cast<const float4*>(p);
   }
   const int nu = e ? 4 : 5, NT = KH * nu;
   // weights: thread = (tap of the group, ci, 4 output channels of the forward conv)
@@ -165,7 +225,9 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
     const int dh = ti / nu, u = ti - dh * nu;
     return d.w + (long long)(dh * KW + e + 2 * u) * (C * C) + wci * C + wc4 * 4;
   };
-  *reinterpret_cast<float4*>(Bt + wu * WB + wci * PITCH + wc4 * 4) =
+  if constexpr (P3) store_presplit4(Bt + wu * WB + wci * PITCH + wc4 * 2,
+                                    *reinterpret_cast<const float4*>(wsrc(wu)));
+  else *reinterpret_cast<float4*>(Bt + wu * WB + wci * PITCH + wc4 * 4) =
       *reinterpret_cast<const float4*>(wsrc(wu));
   __syncthreads();
 
@@ -184,8 +246,10 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
       const int ti = gidx * TG + myu;
       if (ti < NT) {
         const int dh = ti / nu, u = ti - dh * nu;
-        const float* Ab = At + ((ph + 2 - dh) * GW + pw + 4 - u) * PITCH + kk0;
-        const float* Bb = Bt + (cur * TG + myu) * WB + li * PITCH + kk0;
+        const float* Ab = At + ((ph + 2 - dh) * GW + pw + 4 - u) * PITCH + (P3 ? 0 : kk0);
+        const float* Bb = Bt + (cur * TG + myu) * WB + li * PITCH + (P3 ? 0 : kk0);
+        if constexpr (P3) tap_mfma3(Ab, Bb, hh, acc, acc2);
+        else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const float4 a = *reinterpret_cast<const float4*>(Ab + s4 * 4);
@@ -197,7 +261,8 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
         }
       }
     }
-    *reinterpret_cast<float4*>(Bt + ((cur ^ 1) * TG + wu) * WB + wci * PITCH + wc4 * 4) = wn;
+    if constexpr (P3) store_presplit4(Bt + ((cur ^ 1) * TG + wu) * WB + wci * PITCH + wc4 * 2, wn);
+    else *reinterpret_cast<float4*>(Bt + ((cur ^ 1) * TG + wu) * WB + wci * PITCH + wc4 * 4) = wn;
     __syncthreads();
   }
 #pragma unroll
@@ -372,18 +437,25 @@ extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) 
   if (!d || !d->x || !d->w || !d->y) return F2G_EINVAL;
   if (d->S <= 0 || d->H <= 0 || d->Wout <= 0) return F2G_OK;
   if (d->Wout != (d->Win + 8 - 9) / 2 + 1) return F2G_EINVAL;
+  if (d->precision != 0 && d->precision != 1) return F2G_EINVAL;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
   const size_t smem = (size_t)(2 * SUB + 2 * TG * WB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_fwd_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_fwd_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_fwd_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   const int tiles = ((d->H + TH - 1) / TH) * ((d->Wout + TW - 1) / TW);
-  hipLaunchKernelGGL(conv32_s2_fwd_kernel, dim3(tiles, d->S), dim3(512), smem, (hipStream_t)stream,
-                     *d);
+  if (d->precision == 1)   // w = the f2g_split_bf16 image of the packed weights
+    hipLaunchKernelGGL(conv32_s2_fwd_kernel<true>, dim3(tiles, d->S), dim3(512), smem,
+                       (hipStream_t)stream, *d);
+  else
+    hipLaunchKernelGGL(conv32_s2_fwd_kernel<false>, dim3(tiles, d->S), dim3(512), smem,
+                       (hipStream_t)stream, *d);
   return f2g_check_launch();
 }
 
@@ -393,16 +465,23 @@ extern "C" int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream
   if (d->Wout != (d->Win + 8 - 9) / 2 + 1) return F2G_EINVAL;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
+  if (d->precision != 0 && d->precision != 1) return F2G_EINVAL;
   const size_t smem = (size_t)(GSUB + 2 * TG * WB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
   const int tiles = ((d->H + TH - 1) / TH) * (((d->Win + 1) / 2 + TW - 1) / TW);
-  hipLaunchKernelGGL(conv32_s2_dgrad_kernel, dim3(tiles, d->S, 2), dim3(512), smem,
-                     (hipStream_t)stream, *d);
+  if (d->precision == 1)   // w = the f2g_split_bf16 image of the transposed tiles
+    hipLaunchKernelGGL(conv32_s2_dgrad_kernel<true>, dim3(tiles, d->S, 2), dim3(512), smem,
+                       (hipStream_t)stream, *d);
+  else
+    hipLaunchKernelGGL(conv32_s2_dgrad_kernel<false>, dim3(tiles, d->S, 2), dim3(512), smem,
+                       (hipStream_t)stream, *d);
   return f2g_check_launch();
 }
 

@@ -934,7 +934,11 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
-  const int ch = tid & 7, rr = tid >> 3;
+  // staged row of this thread (of 32, repeated four times 32 rows apart).  The split-bf16 tile is
+  // filled with 8-byte stores, served 16 lanes = two rows at a time over 32 banks: rows r and r + 4
+  // (4 x 36 dwords = 16 mod 32) share no bank, rows r and r + 1 would share 12 of 16.
+  const int ch = tid & 7;
+  const int rr = P3 ? (((tid >> 4) & 3) + 8 * (tid >> 6) + 4 * ((tid >> 3) & 1)) : (tid >> 3);
   __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, 0x80000000u, 0x00020000);
   // B is a plain [n][k] matrix: the resource ends with its last row, so the rows of a partial
@@ -1097,6 +1101,79 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         ka += segjump;
       }
     };
+    if constexpr (P3) {
+      // The bf16 MFMA phase of a slab is 5x shorter than the fp32 one (24 x 32 cycles), too short to
+      // hide a load, an LDS fill and a barrier behind it one after the other.  So the phases overlap
+      // inside a wave: slab t's MFMAs are interleaved with the LDS stores of slab t+1 (in registers
+      // since the previous iteration) while the loads of slab t+2 fly -- two register stages.
+      u32x4 xa[4], xb[4], ya[4], yb[4];
+      if (nt > 0) {
+        gload(ka, kb, xa, xb);
+        lstore(0, xa, xb);
+      }
+      advance();
+      gload(nt > 1 ? ka : ka0, nt > 1 ? kb : kb0, xa, xb);
+      __syncthreads();
+      // fragments: f0 = first k step (8 consecutive k per lane half), f1 = second; [0..1] = hi of
+      // the two sub-tiles, [2..3] = lo.  f0 of the NEXT slab is read right after the barrier, under
+      // the MFMAs of f1; f1 is read at the top of an iteration, under the MFMAs of f0.
+      bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+      auto frags = [&](int off, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8);
+          fa[2 + i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8 + 16);
+          fb[i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + ks * 8);
+          fb[2 + i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + ks * 8 + 16);
+        }
+      };
+      auto mfma12 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const bf16x8 av = term == 0 ? fa[2 + mi] : fa[mi];
+              const bf16x8 bv = term == 1 ? fb[2 + ni] : fb[ni];
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
+            }
+      };
+      frags(0, 0, fa0, fb0);
+      auto step3 = [&](int t, int curoff, int nxtoff, const u32x4 (&wa)[4], const u32x4 (&wb)[4],
+                       u32x4 (&la)[4], u32x4 (&lb)[4]) {
+        frags(curoff, 1, fa1, fb1);
+        advance();
+        const bool again = t + 2 < nt;   // past the end: re-read the first slab (never used)
+        gload(again ? ka : ka0, again ? kb : kb0, la, lb);
+        mfma12(fa0, fb0);
+        lstore(nxtoff, wa, wb);
+        // issue order: fragments, the loads of the slab after next, one LDS store behind each of
+        // the first MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        frags(nxtoff, 0, fa0, fb0);
+        mfma12(fa1, fb1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      int t = 0;
+      for (; t + 1 < nt; t += 2) {
+        step3(t, 0, TSZ, xa, xb, ya, yb);
+        step3(t + 1, TSZ, 0, ya, yb, xa, xb);
+      }
+      if (t < nt) step3(t, 0, TSZ, xa, xb, ya, yb);
+    } else {
     if (nt > 0) {
       u32x4 la[4], lb[4];
       gload(ka, kb, la, lb);
@@ -1123,6 +1200,8 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       step(t, 0, TSZ);
       // an odd slab count leaves the (unused) restaged slab in buffer 1; the next segment starts in
       // buffer 0, which every wave has finished reading (barrier above)
+    }
+
     }
 
     const f2g_epilogue& E = d.E;

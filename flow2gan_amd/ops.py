@@ -226,6 +226,7 @@ import os as _os
 
 LEAN_DGRAD = _os.environ.get("F2G_LEAN_DGRAD", "1") != "0"
 LEAN_SPLIT = _os.environ.get("F2G_LEAN_SPLIT", "1") != "0"
+CONV32_SPLIT = _os.environ.get("F2G_CONV32_SPLIT", "1") != "0"   # split-bf16 direct MRD convs
 
 
 def split_bf16(t):
@@ -278,6 +279,10 @@ def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope:
     d = L.Conv32Desc()
     d.x, d.x_seq, d.x_line = ptr(x), H * Win * 32, Win * 32
     d.S, d.H, d.Win, d.Wout = S, H, Win, Wout
+    if GEMM_PRECISION == 1 and CONV32_SPLIT:
+        w_packed = derived(w_packed, "split", split_bf16)
+        d.precision = 1
+        d._keep = w_packed
     d.w, d.bias, d.lrelu_slope = ptr(w_packed), ptr(bias), slope
     d.y, d.y_seq, d.y_line = ptr(y), H * Wout * 32, Wout * 32
     if GEMM_TIMER is not None:
@@ -297,6 +302,10 @@ def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, 
     d.x_line = g_line if g_line is not None else Wout * 32
     d.x_seq = g_seq if g_seq is not None else H * d.x_line
     d.S, d.H, d.Win, d.Wout = S, H, Win, Wout
+    if GEMM_PRECISION == 1 and CONV32_SPLIT:
+        wT = derived(wT, "split", split_bf16)
+        d.precision = 1
+        d._keep = wT
     d.w, d.bias, d.lrelu_slope = ptr(wT), None, 0.0
     d.y, d.y_seq, d.y_line = ptr(gx), H * Win * 32, Win * 32
     if mask is not None:      # leaky-ReLU backward of the layer below fused into the store

@@ -395,7 +395,10 @@ typedef struct {
   const float* w;
   const float* bias;  /* may be NULL */
   float lrelu_slope;  /* 0 = none */
-  int32_t _pad;
+  /* fwd / dgrad: 0 = exact fp32 MFMA; 1 = split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulation):
+   * `w` is then the f2g_split_bf16 image of the same weight matrix, the patch is split while it
+   * is staged in LDS.  wgrad ignores it (always exact fp32). */
+  int32_t precision;
   float* y;
   int64_t y_seq, y_line;
   /* dgrad only: leaky-ReLU backward of the layer below fused into the store (see f2g_epilogue):

@@ -594,6 +594,34 @@ def test_direct_conv32_dgrad_matches_autograd(ops, S, H, Win):
     close(gx, ref, name="conv32 dgrad")
 
 
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 21, 51), (1, 5, 2), (2, 8, 64)])
+def test_direct_conv32_split_bf16(ops, S, H, Win):
+    """Split-bf16 instances of the direct MRD conv (forward and data gradient): patch split while it
+    is staged, pre-split weight tiles, 3 bf16 MFMAs per product -- ~2^-16 per product."""
+    Wout = (Win - 1) // 2 + 1
+    x = rnd(S * H * Win, 32, seed=1)
+    w = rnd(32, 32, 3, 9, seed=2, scale=0.05)
+    b = rnd(32, seed=3)
+    gy = rnd(S * H * Wout, 32, seed=4)
+    wp = w.permute(0, 2, 3, 1).reshape(32, 27 * 32).contiguous()
+    wT = w.permute(2, 3, 1, 0).reshape(27, 32, 32).contiguous()
+    xd = x.reshape(S, H, Win, 32).permute(0, 3, 1, 2).double().requires_grad_(True)
+    pre = torch.nn.functional.conv2d(xd, w.double(), b.double(), stride=(1, 2), padding=(1, 4))
+    ref = torch.nn.functional.leaky_relu(pre, 0.1).permute(0, 2, 3, 1).reshape(S * H * Wout, 32)
+    (pre - b.double()[None, :, None, None]).backward(gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
+    was = ops.GEMM_PRECISION
+    ops.set_gemm_precision("bf16x3")
+    try:
+        y = torch.full((S * H * Wout, 32), 7.0, device=DEV)
+        ops.conv32_s2_fwd(g(x), S, H, Win, Wout, g(wp), g(b), 0.1, y)
+        gx = torch.full((S * H * Win, 32), 7.0, device=DEV)
+        ops.conv32_s2_dgrad(g(gy), S, H, Win, Wout, g(wT), gx)
+    finally:
+        ops.GEMM_PRECISION = was
+    close(y, ref.detach(), rtol=3e-5, name="conv32 split-bf16")
+    close(gx, xd.grad.permute(0, 2, 3, 1).reshape(S * H * Win, 32), rtol=3e-5, name="conv32 dgrad split-bf16")
+
+
 @pytest.mark.parametrize("S,H,W,lo,Wtot", [(2, 11, 34, 7, 50), (3, 8, 32, 0, 32), (1, 5, 3, 2, 9), (2, 21, 77, 10, 100)])
 def test_conv2ch_direct_kernels_match_autograd(ops, S, H, W, lo, Wtot):
     """conv2ch.hip (first MRD layer, 2 -> 32 channels on a band of the interleaved spectrogram):
