@@ -25,7 +25,7 @@ class Operand(C.Structure):
         ("seq_stride", C.c_int64), ("line_stride", C.c_int64),
         ("reflect", C.c_int32), ("split", C.c_int32),
         ("alpha", C.c_void_p), ("lrelu_src", C.c_void_p),
-        ("lrelu_slope", C.c_float), ("_pad2", C.c_int32),
+        ("lrelu_slope", C.c_float), ("unbounded", C.c_int32),
     ]
 
 

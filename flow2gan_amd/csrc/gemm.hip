@@ -1465,6 +1465,215 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   return f2g_check_launch();
 }
 
+// ---- lean weight-gradient kernel, split-bf16 --------------------------------------------------
+// C[m,n] (+)= sum_r A[r,m] * B[r,n]: both operands are K-MAJOR (the reduction walks rows, memory is
+// contiguous along m / n), while a bf16 MFMA wants 8 consecutive k per lane.  The transposition is
+// done by the LDS itself: slabs of 32 rows are staged exactly as they lie in memory (pre-split
+// images: a 16-byte chunk = four m as hi | lo, stored as two 8-byte halves into a hi and a lo plane
+// of 32 x 128 bf16) and read back with ds_read_b64_tr_b16, which hands lane c of a 16-lane group
+// column c of a 4 (k) x 16 (m) block whose 8-byte pieces the group's lanes point at -- two such reads
+// = the 8 k of one operand.  Rows are 256 bytes; the 64-byte column blocks are XOR-swizzled with
+// (row & 3) so that the four rows of a transposed block fall on different banks (a padded pitch
+// would push the tile past two blocks per CU).  Everything else is the lean kernel's recipe:
+// buffer loads with the K advance in a scalar register, rows past the end out of range = zeros, two
+// register stages, LDS stores behind the MFMAs, fragments prefetched across the barrier.
+// A: plain (R x M).  B: plain, or a 1-D window operand (rows = (sequence, position), P1 = 1, one
+// segment) flagged `unbounded`: windows may reach past the ends of their sequence because the caller
+// guarantees that those rows of A are zero (halo layout of the MPD maps) -- the per-row offsets are
+// recomputed every slab (one magic-number division per staged row).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * 256));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool BWIN>
+__global__ __launch_bounds__(256, 2)
+void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
+  constexpr int PL = 32 * 256;            // bytes of one plane (32 rows x 128 bf16)
+  constexpr int BUF = 4 * PL;             // [A hi | A lo | B hi | B lo]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(128, 128, m0, n0);
+  const int kbeg = blockIdx.z * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+  if (nt <= 0) return;
+
+  // staging: thread = (row rid + 8q of the slab, 16-byte chunk c of the 128-wide tile row)
+  const int rid = tid >> 5, c = tid & 31;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.A.base, 0, (unsigned)((long long)K * d.A.seq_stride * 4), 0x00020000);
+  const long long b_bytes = BWIN ? (long long)(d.B.rows / d.B.P0) * d.B.seq_stride * 4
+                                 : (long long)K * d.B.seq_stride * 4;
+  __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)b_bytes, 0x00020000);
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    offA[q] = (unsigned)(((long long)(rid + 8 * q) * d.A.seq_stride + m0 + 4 * c) * 4);
+    offB[q] = (unsigned)(((long long)(rid + 8 * q) * d.B.seq_stride + n0 + 4 * c) * 4);
+  }
+  const int stepA = (int)(BK * d.A.seq_stride * 4), stepB = (int)(BK * d.B.seq_stride * 4);
+  const unsigned mgP0 = BWIN ? magic_of(d.B.P0) : 0u;
+  const int colB = (n0 + 4 * c) * 4;
+  // LDS store offsets (row r, chunk c): r*256 + (((c >> 3) ^ (r & 3)) << 6) + (c & 7)*8
+  int wofs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rid + 8 * q;
+    wofs[q] = r * 256 + ((((c >> 3) ^ (r & 3))) << 6) + (c & 7) * 8;
+  }
+  // transposed-fragment addresses: 16-lane group g = (m half, k half), lane i = (row i>>2, quad i&3)
+  const int g = lane >> 4, i16 = lane & 15;
+  const int rrow = (g >> 1) * 8 + (i16 >> 2), sw = i16 >> 2, within = (g & 1) * 32 + (i16 & 3) * 8;
+  int rofA[2], rofB[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    rofA[t] = rrow * 256 + ((((wm * 2 + t) ^ sw)) << 6) + within;
+    rofB[t] = rrow * 256 + ((((wn * 2 + t) ^ sw)) << 6) + within;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  int ka = (int)((long long)kbeg * d.A.seq_stride * 4), kb = (int)((long long)kbeg * d.B.seq_stride * 4);
+  const int ka0 = ka, kb0 = kb;
+  int srow = kbeg;   // first row of the slab being loaded (window operands)
+  auto gload = [&](bool valid, u32x4 (&la)[4], u32x4 (&lb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      la[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q], valid ? ka : ka0, 0);
+      if constexpr (BWIN) {
+        const int r = (valid ? srow : kbeg) + rid + 8 * q;
+        const int sq = fast_div(r, d.B.P0, mgP0), p = r - sq * d.B.P0;
+        const long long off = ((long long)sq * d.B.seq_stride + (long long)(p * d.B.step0 - d.B.pad0) * d.B.unit) * 4 + colB;
+        const unsigned vo = (r < K && off >= 0 && off < b_bytes) ? (unsigned)off : 0x80000000u;
+        lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, vo, 0, 0);
+      } else {
+        lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB[q], valid ? kb : kb0, 0);
+      }
+    }
+  };
+  auto advance = [&]() {
+    ka += stepA;
+    kb += stepB;
+    srow += BK;
+  };
+  auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned char* pa = sm + bufoff + wofs[q];
+      *reinterpret_cast<u32x2*>(pa) = u32x2{la[q].x, la[q].y};
+      *reinterpret_cast<u32x2*>(pa + PL) = u32x2{la[q].z, la[q].w};
+      *reinterpret_cast<u32x2*>(pa + 2 * PL) = u32x2{lb[q].x, lb[q].y};
+      *reinterpret_cast<u32x2*>(pa + 3 * PL) = u32x2{lb[q].z, lb[q].w};
+    }
+  };
+  bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];   // [0..1] hi of the two sub-tiles, [2..3] lo
+  auto frags = [&](int bufoff, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+    const unsigned char* base = sm + bufoff + ks * 16 * 256;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      fa[t] = tr_frag(base + rofA[t]);
+      fa[2 + t] = tr_frag(base + PL + rofA[t]);
+      fb[t] = tr_frag(base + 2 * PL + rofB[t]);
+      fb[2 + t] = tr_frag(base + 3 * PL + rofB[t]);
+    }
+  };
+  auto mfma12 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const bf16x8 av = term == 0 ? fa[2 + mi] : fa[mi];
+          const bf16x8 bv = term == 1 ? fb[2 + ni] : fb[ni];
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
+        }
+  };
+  u32x4 xa[4], xb[4], ya[4], yb[4];
+  gload(true, xa, xb);
+  lstore(0, xa, xb);
+  advance();
+  gload(nt > 1, xa, xb);
+  __syncthreads();
+  frags(0, 0, fa0, fb0);
+  auto step3 = [&](int t, int curoff, int nxtoff, const u32x4 (&wa)[4], const u32x4 (&wb)[4],
+                   u32x4 (&la)[4], u32x4 (&lb)[4]) {
+    frags(curoff, 1, fa1, fb1);
+    advance();
+    gload(t + 2 < nt, la, lb);    // past the end: re-read the first slab (never used)
+    mfma12(fa0, fb0);
+    lstore(nxtoff, wa, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    frags(nxtoff, 0, fa0, fb0);
+    mfma12(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    step3(t, 0, BUF, xa, xb, ya, yb);
+    step3(t + 1, BUF, 0, ya, yb, xa, xb);
+  }
+  if (t < nt) step3(t, 0, BUF, xa, xb, ya, yb);
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
+}
+
+// form 2 on the kernel above: split-bf16 with both operands pre-split, whole 128 x 128 tiles,
+// A a plain matrix, B plain or an `unbounded` single-segment 1-D window
+inline bool leanw_ok(const f2g_gemm_desc& d) {
+  const f2g_operand& A = d.A;
+  const f2g_operand& B = d.B;
+  if (d.form != 2 || A.rows != B.rows || A.rows <= 0) return false;
+  if (!host_plain(A) || A.alpha || B.alpha || B.reflect || B.lrelu_src) return false;
+  if (A.cols % 128 || B.cols % 128 || !al16(A.base) || !al16(B.base)) return false;
+  if ((A.seq_stride & 3) || (B.seq_stride & 3)) return false;
+  if ((long long)A.rows * A.seq_stride * 4 >= 0x7ff00000ll) return false;
+  if (host_plain(B)) return (long long)B.rows * B.seq_stride * 4 < 0x7ff00000ll;
+  if (!B.unbounded || B.P1 != 1 || B.P0 < 1 || B.rows % B.P0 || B.seglen < B.cols) return false;
+  if ((((long long)B.step0 * B.unit) & 3) || (((long long)B.pad0 * B.unit) & 3)) return false;
+  return (long long)(B.rows / B.P0) * B.seq_stride * 4 < 0x7ff00000ll;
+}
+
+int launch_leanw3(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+  constexpr size_t smem = 2 * 4 * 32 * 256;
+  int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
+  const int zs = (K + kchunk - 1) / kchunk;
+  dim3 grid(M / 128, N / 128, zs);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw3_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw3_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  g_last_path = 1;
+  if (host_plain(d.B))
+    hipLaunchKernelGGL(gemm_leanw3_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  else
+    hipLaunchKernelGGL(gemm_leanw3_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  return f2g_check_launch();
+}
+
 // Stream-K decision for the lean kernel: units per block, or 0 to keep the classic tile grid.
 // Measured on the stage-2 step (B = 64): evening out the rounds lifts the kernels alone on the chip
 // (GEMM class 283.8 -> 275.4 ms serialised) but not the step itself, whose launch lanes already
@@ -1498,9 +1707,11 @@ extern "C" int f2g_gemm_last_path(void) { return g_last_path; }
 // Would f2g_gemm run this form-0 descriptor on the lean kernel (whatever its precision)?  The host
 // asks before it pre-splits the operands of a split-bf16 GEMM.
 extern "C" int f2g_gemm_lean_ok(const f2g_gemm_desc* dp) {
-  if (!dp || !dp->A.base || !dp->B.base || dp->form != 0) return 0;
+  if (!dp || !dp->A.base || !dp->B.base) return 0;
   static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
   const f2g_gemm_desc& d = *dp;
+  if (d.form == 2) return lean_on && leanw_ok(d) ? 1 : 0;   // split-bf16 weight-gradient kernel
+  if (d.form != 0) return 0;
   if (d.A.cols != d.B.cols || !host_plain(d.B)) return 0;
   return lean_on && d.B.rows > 64 && lean_a_ok(d.A) && lean_b_ok(d.B) ? 1 : 0;
 }
@@ -1607,6 +1818,11 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     if (d.A.rows != d.B.rows) return F2G_EINVAL;
     if (split > 1 && !d.E.atomic) return F2G_EINVAL;
     const int M = d.A.cols, N = d.B.cols, K = d.A.rows;
+    if (d.A.split || d.B.split) {   // pre-split images: the lean weight-gradient kernel only
+      static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
+      if (!(d.precision == 1 && d.A.split && d.B.split && lean_on && leanw_ok(d))) return F2G_EINVAL;
+      return launch_leanw3(d, M, N, K, split, st);
+    }
     int am = op_mode(d.A, false), bm = op_mode(d.B, false);
     // split-K chunks are multiples of BK, so PF only needs the total extent % BK == 0
     if (am == PF && bm == PF) return dispatch_tile<true, true, PF, PF>(d, M, N, K, split, st);

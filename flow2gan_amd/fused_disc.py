@@ -303,7 +303,8 @@ class MPDLossFn(torch.autograd.Function):
                     if l == 0:
                         X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
                     else:
-                        X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5)
+                        X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
+                                  unbounded=True)   # g's halo rows are zero
                     ops.wgrad(g, Cout, Cout, X, gwp)
                     grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
                 if l > 0:

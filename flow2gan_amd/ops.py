@@ -118,7 +118,7 @@ def mat(t, rows: Optional[int] = None, cols: Optional[int] = None, ld: Optional[
 
 def win1d(t, nseq: int, L_in: int, unit: int, L_out: int, step: int, pad: int, taps: int,
           reflect: bool = False, seq_stride: Optional[int] = None, lrelu_src=None,
-          slope: float = 0.0, offset: int = 0) -> Operand:
+          slope: float = 0.0, offset: int = 0, unbounded: bool = False) -> Operand:
     """rows = (seq, out position); cols = taps*unit contiguous floats starting at
     (pos*step - pad)*unit inside a sequence of L_in*unit floats (zero / reflect outside)."""
     o = Operand()
@@ -134,6 +134,11 @@ def win1d(t, nseq: int, L_in: int, unit: int, L_out: int, step: int, pad: int, t
     o.alpha = None
     o.lrelu_src = None if lrelu_src is None else ptr(lrelu_src) + 4 * offset
     o.lrelu_slope = slope
+    # unbounded: the caller guarantees that rows whose window leaves its sequence pair with zeros
+    # (weight gradients against a gradient map with zero halo rows), so a kernel may read past the
+    # sequence ends inside `t` instead of testing bounds (f2g_operand.unbounded); t = whole buffer
+    o.unbounded = 1 if (unbounded and offset == 0 and t.is_contiguous()
+                        and t.numel() == nseq * o.seq_stride) else 0
     o._keep = (t, lrelu_src)
     return o
 
@@ -211,7 +216,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.form = form
     d.split_k = split_k
     d.precision = GEMM_PRECISION
-    if GEMM_PRECISION == 1 and form == 0 and LEAN_SPLIT and L.lib.f2g_gemm_lean_ok(C.byref(d)):
+    if GEMM_PRECISION == 1 and form in (0, 2) and LEAN_SPLIT and L.lib.f2g_gemm_lean_ok(C.byref(d)):
         # split-bf16 on the lean kernel: both operands as pre-split images (no conversion in the K
         # loop); weights come from the derived-weight cache, activations are split here
         d.A, d.B = _split_operand(A), _split_operand(Bm)
@@ -254,6 +259,9 @@ def _split_operand(o: Operand) -> Operand:
     C.memmove(C.byref(n), C.byref(o), C.sizeof(Operand))
     if _is_const(t) and t.is_contiguous() and t.numel() % 4 == 0 and (o.base - ptr(t)) % 16 == 0:
         img = derived(t, "split", split_bf16)
+        n.base = ptr(img) + (o.base - ptr(t))
+    elif o.unbounded:       # read anywhere inside the buffer: the whole tensor
+        img = split_bf16(t)
         n.base = ptr(img) + (o.base - ptr(t))
     else:
         nseq = o.rows // (o.P0 * o.P1)

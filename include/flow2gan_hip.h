@@ -63,7 +63,11 @@ typedef struct {
   const float* alpha;
   const float* lrelu_src;
   float lrelu_slope;
-  int32_t _pad2;
+  /* 1: the windows of this operand may be read past the ends of their sequence (inside the
+   * underlying buffer, zeros outside it) because the caller guarantees that whatever they pair
+   * with is zero there -- the weight gradient of a conv whose gradient map carries zero halo rows.
+   * Only the split-bf16 weight-gradient kernel looks at it. */
+  int32_t unbounded;
 } f2g_operand;
 
 /* Epilogue of f2g_gemm: v = acc (+bias[n]) (+gamma[n]*res[r,n]); optional PReLU-derivative
@@ -135,7 +139,8 @@ typedef struct {
 int f2g_gemm(const f2g_gemm_desc* d, f2g_stream_t stream);
 /* 1 if f2g_gemm would run this form-0 descriptor on the lean kernel (buffer loads, no VALU in the K
  * loop), whatever its precision: the host asks before pre-splitting the operands of a precision-1
- * GEMM.  No launch. */
+ * GEMM.  Form 2: 1 if the split-bf16 weight-gradient kernel (K-major operands transposed by
+ * ds_read_b64_tr_b16) applies.  No launch. */
 int f2g_gemm_lean_ok(const f2g_gemm_desc* d);
 /* dst = split-bf16 image of src (n floats, n % 4 == 0, both 16-byte aligned): every aligned group
  * of four floats becomes its four bf16 high parts followed by the four bf16 remainders (x = hi + lo

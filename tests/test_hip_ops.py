@@ -120,6 +120,50 @@ def test_gemm_split_bf16_on_the_lean_kernel(ops, R, K, N):
         ops.GEMM_PRECISION = was
 
 
+@pytest.mark.parametrize("R,M,N", [(3000, 128, 256), (777, 384, 128), (64, 256, 1152), (24064, 128, 128)])
+def test_wgrad_split_bf16_transposing_kernel(ops, R, M, N):
+    """Weight gradient in split-bf16 on the K-major kernel (operands transposed by the LDS
+    transpose read): g[m, n] += sum_r dY[r, m] X[r, n], atomic split-K onto an initialised output."""
+    dY, X, g0 = rnd(R, M, seed=1), rnd(R, N, seed=2), rnd(M, N, seed=3)
+    was = ops.GEMM_PRECISION
+    ops.set_gemm_precision("bf16x3")
+    try:
+        out = g(g0)
+        ops.wgrad(g(dY), M, M, ops.mat(g(X)), out)
+        assert ops.L.lib.f2g_gemm_last_path() == 1, "split-bf16 wgrad did not take the lean kernel"
+    finally:
+        ops.GEMM_PRECISION = was
+    close(out, g0.double() + dY.double().t() @ X.double(), rtol=5e-5, name="leanw3")
+
+
+def test_wgrad_split_bf16_unbounded_windows(ops):
+    """MPD-style weight gradient: X = (5,1)-tap windows over a halo layout, read past the sequence
+    ends where the gradient map's halo rows are zero (f2g_operand.unbounded)."""
+    S, Hin, Cin, Cout, stv, HALO = 5, 50, 128, 256, 3, 2
+    Hout = (Hin + 4 - 5) // stv + 1
+    Hp = Hout + 2 * HALO
+    x = torch.zeros(S, Hin + 2 * HALO, Cin)
+    x[:, HALO:HALO + Hin] = rnd(S, Hin, Cin, seed=1)
+    gy = torch.zeros(S, Hp, Cout)
+    gy[:, HALO:HALO + Hout] = rnd(S, Hout, Cout, seed=2)
+    was = ops.GEMM_PRECISION
+    ops.set_gemm_precision("bf16x3")
+    try:
+        out = torch.zeros(Cout, 5 * Cin, device=DEV)
+        X = ops.win1d(g(x), S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5, unbounded=True)
+        assert X.unbounded == 1
+        ops.wgrad(g(gy).reshape(S * Hp, Cout), Cout, Cout, X, out)
+        assert ops.L.lib.f2g_gemm_last_path() == 1
+    finally:
+        ops.GEMM_PRECISION = was
+    # conv1d(k=5, stride, pad=2) over the un-haloed input: output row o reads input rows o*stv-2 .. +2
+    xin = x[:, HALO:HALO + Hin].permute(0, 2, 1).double().requires_grad_(False)
+    w = torch.zeros(Cout, Cin, 5, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(xin, w, None, stride=stv, padding=2)
+    y.backward(gy[:, HALO:HALO + Hout].permute(0, 2, 1).double())
+    close(out, w.grad.permute(0, 2, 1).reshape(Cout, 5 * Cin), rtol=5e-5, name="leanw3-window")
+
+
 def test_gemm_split_bf16_windowed_operand(ops):
     """MPD-style (5,1) conv over a halo layout in split-bf16: the window addressing of the lean
     kernel is unchanged by the split image."""
