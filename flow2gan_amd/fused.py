@@ -76,14 +76,22 @@ def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0,
     a = ops.empty(rows, Hh, device=dev)
     if keep:
         p = ops.empty(rows, Hh, device=dev)
-        gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha, prelu_out=p)
-    else:
-        p = a
-        gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha)
+        # (split-bf16 mode) the images of z and p made for these GEMMs serve the weight gradients
+        # of the backward pass as well
+        share = ops.split_sharing(z, p)
+        with share:
+            gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha,
+                 prelu_out=p)
+            out = ops.empty(rows, Cc, device=dev)
+            gemm(mat(p, rows, Hh), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
+                 gamma=bp.gamma.reshape(Cc))
+        return out, z, (a, p, share)
+    p = a
+    gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha)
     out = ops.empty(rows, Cc, device=dev)
     gemm(mat(p, rows, Hh), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
          gamma=bp.gamma.reshape(Cc))
-    return out, z, (a, p)
+    return out, z, (a, p, None)
 
 
 def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale: bool,
@@ -91,20 +99,25 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
               g_te=None):
     """Backward of block_fwd.  Destroys z and a (reused as gradient buffers).
     Returns (gx, grads) with grads ordered like BLOCK_KEYS."""
-    a, p_act = a
+    a, p_act, share = a
+    if share is None:
+        share = ops.split_sharing()
     dev = x.device
     rows, Cc, Hh = B * F, bp.C, bp.H
     (g_w2, g_b2, g_alpha, g_w1, g_b1, g_beta, g_ls, g_wdw, g_bdw, g_gamma) = ops.zeros_many(
         [(Cc, Hh), (Cc,), (Hh,), (Hh, Cc), (Hh,), (Cc,), (1,), (Cc, 1, bp.K), (Cc,), (Cc, 1)], dev)
     # pwconv2: out = W2 prelu(a) + b2 + gamma*x
     ops.colsum(g_b2, gout, rows, Cc)
-    ops.wgrad(gout, Cc, gout.stride(0), mat(p_act, rows, Hh), g_w2)
-    # da = (gout W2) * prelu'(a)   (in place over a), d alpha, d b1
-    gemm(mat(gout, rows, Cc), mat(bp.w2.reshape(Cc, Hh)), a, form=1, aux=a, alpha_n=bp.alpha,
-         colsum_alpha=g_alpha, colsum=g_b1)
-    ops.wgrad(a, Hh, a.stride(0), mat(z, rows, Cc), g_w1)
-    # dz = da W1  (z is dead after the weight gradient above: reuse it)
-    gemm(mat(a, rows, Hh), mat(bp.w1.reshape(Hh, Cc)), z, form=1)
+    with share, ops.split_sharing(gout):   # one split-bf16 image of gout for both GEMMs
+        ops.wgrad(gout, Cc, gout.stride(0), mat(p_act, rows, Hh), g_w2)
+        # da = (gout W2) * prelu'(a)   (in place over a), d alpha, d b1
+        gemm(mat(gout, rows, Cc), mat(bp.w2.reshape(Cc, Hh)), a, form=1, aux=a, alpha_n=bp.alpha,
+             colsum_alpha=g_alpha, colsum=g_b1)
+    with share, ops.split_sharing(a):      # a now holds da
+        ops.wgrad(a, Hh, a.stride(0), mat(z, rows, Cc), g_w1)
+        # dz = da W1  (z is dead after the weight gradient above: reuse it)
+        gemm(mat(a, rows, Hh), mat(bp.w1.reshape(Hh, Cc)), z, form=1)
+    share.drop()
     du = ops.empty(rows, Cc, device=dev)
     ops.dwnorm_bwd(x, z, du, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta,
                    bp.log_scale.reshape(1), cproj, ldcp, Fc, up, cp_off, te, ldte, te_off,

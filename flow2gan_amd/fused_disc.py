@@ -101,7 +101,7 @@ def unhalo(y, S: int, H: int):
     return y.view(S, H + 2 * HALO, y.shape[1])[:, HALO:HALO + H]
 
 
-def _mpd_forward_one(x2, p: int, prm: list):
+def _mpd_forward_one(x2, p: int, prm: list, keep_images: bool = False):
     """x2 (2B, T) -> dict with per-layer activations (channels-last; layers 1..5 in the halo
     layout, see _halo_rows), heights, scores."""
     dev = x2.device
@@ -111,6 +111,7 @@ def _mpd_forward_one(x2, p: int, prm: list):
     img = ops.empty(S * H, 1, device=dev)
     ops.period_fold(img, x2, S2, T, p, H)
     acts, hs = [img], [H]
+    shares = [None] * 6   # (split-bf16 mode) images of the maps, kept for the weight gradients
     x = img
     for l in range(5):
         w, b = prm[2 * l], prm[2 * l + 1]
@@ -122,7 +123,12 @@ def _mpd_forward_one(x2, p: int, prm: list):
             A = win1d(x, S, H, Cin, Hout, st, 2, 5)
         else:        # window of output row h starts at padded row h*st
             A = win1d(x, S, H + 2 * HALO, Cin, Hout, st, 0, 5)
-        gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout))
+        if keep_images and l > 0:
+            shares[l] = ops.split_sharing(x)
+            with shares[l]:
+                gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout))
+        else:
+            gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout))
         acts.append(y)
         hs.append(Hout)
         x, H = y, Hout
@@ -130,7 +136,7 @@ def _mpd_forward_one(x2, p: int, prm: list):
     wpp = ops.derived(wpost, "pack", pack_conv_weight)
     scores = ops.empty(S * H, 1, device=dev)
     gemm(win1d(x, S, H + 2 * HALO, 1024, H, 1, -(HALO - 1), 3), mat(wpp), scores, bias=bpost)
-    return dict(acts=acts, hs=hs, scores=scores, S=S, p=p)
+    return dict(acts=acts, hs=hs, scores=scores, S=S, p=p, shares=shares)
 
 
 def _dgrad_weight(w, stride: int, j0: int, nt: int):
@@ -186,7 +192,7 @@ class MPDLossFn(torch.autograd.Function):
         for i, p in enumerate(periods):
           with lanes.lane(i):
             prm = list(params[12 * i: 12 * i + 12])
-            st = _mpd_forward_one(x2, p, prm)
+            st = _mpd_forward_one(x2, p, prm, keep_images=train_disc)
             S, H5 = st["S"], st["hs"][5]
             nh = (S // 2) * H5  # elements of one half's score map
             sc = st["scores"]
@@ -294,24 +300,27 @@ class MPDLossFn(torch.autograd.Function):
                 Cin, Cout, stv = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
                 Hin, Hout = hs[l], hs[l + 1]
                 Hp = Hout + 2 * HALO
-                # g: gradient of layer l's PRE-activation (S or Sx sequences, halo layout)
-                if train_disc:
-                    grads_p[2 * l + 1] = zbuf[2 + 2 * l + 1]
-                    # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
-                    # the windows they pair with -- partly outside the input -- contribute nothing)
-                    gwp = zbuf[2 + 2 * l]
-                    if l == 0:
-                        X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
-                    else:
-                        X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
-                                  unbounded=True)   # g's halo rows are zero
-                    ops.wgrad(g, Cout, Cout, X, gwp)
-                    grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
-                if l > 0:
-                    g = land(None, l, lambda mk, fk, ck, g=g, w=w, Hout=Hout, Cout=Cout, stv=stv, Hin=Hin:
-                             _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, mask=mk, fm=fk, colsum=ck))
-                elif not train_disc:
-                    g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=False)
+                # g: gradient of layer l's PRE-activation (S or Sx sequences, halo layout);
+                # (split-bf16 mode) one image of it serves the weight gradient and every stride
+                # residue of the data gradient, the forward image of acts[l] the weight gradient
+                with ops.split_sharing(g), (st["shares"][l] or ops.split_sharing()):
+                  if train_disc:
+                      grads_p[2 * l + 1] = zbuf[2 + 2 * l + 1]
+                      # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
+                      # the windows they pair with -- partly outside the input -- contribute nothing)
+                      gwp = zbuf[2 + 2 * l]
+                      if l == 0:
+                          X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
+                      else:
+                          X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
+                                    unbounded=True)   # g's halo rows are zero
+                      ops.wgrad(g, Cout, Cout, X, gwp)
+                      grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
+                  if l > 0:
+                      g = land(None, l, lambda mk, fk, ck, g=g, w=w, Hout=Hout, Cout=Cout, stv=stv, Hin=Hin:
+                               _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, mask=mk, fm=fk, colsum=ck))
+                  elif not train_disc:
+                      g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=False)
             if not train_disc:
                 # g: (B*p*H0, 1) gradient of the folded image of the generated half
                 lanes.chain_enter()  # g_fake is accumulated period after period

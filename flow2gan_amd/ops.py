@@ -243,6 +243,48 @@ def split_bf16(t):
     return out
 
 
+_SHARES: dict = {}
+
+
+class split_sharing:
+    """`with split_sharing(t, ...)`: inside the block every split-bf16 operand over one of these
+    tensors reuses ONE image per (tensor, operand base) instead of splitting again -- the caller
+    asserts that the tensors do not change while the block is active.  The object keeps its images,
+    so the same scope can be re-entered later (an activation split for the forward GEMM serves the
+    weight gradient of the backward pass).  A no-op outside the split-bf16 mode."""
+
+    def __init__(self, *tensors):
+        self.ts = [t for t in tensors if t is not None]
+        self.imgs = {}
+
+    def __enter__(self):
+        for t in self.ts:
+            _SHARES.setdefault(id(t), []).append(self)
+        return self
+
+    def __exit__(self, *exc):
+        for t in self.ts:
+            st = _SHARES.get(id(t))
+            if st:
+                st.pop()
+                if not st:
+                    del _SHARES[id(t)]
+        return False
+
+    def drop(self):
+        self.imgs = {}
+
+    def image(self, t, base: int):
+        key = (id(t), base)
+        img = self.imgs.get(key)
+        if img is None:
+            n = t.numel() - (base - ptr(t)) // 4
+            img = torch.empty(n, device=t.device, dtype=torch.float32)
+            call("f2g_split_bf16", ptr(img), base, n)
+            self.imgs[key] = img
+        return img
+
+
 def _is_const(t) -> bool:
     """Parameters, views of parameters and cached re-layouts of them: safe to cache images of."""
     owner = t._base if t._base is not None else t
@@ -260,6 +302,10 @@ def _split_operand(o: Operand) -> Operand:
     if _is_const(t) and t.is_contiguous() and t.numel() % 4 == 0 and (o.base - ptr(t)) % 16 == 0:
         img = derived(t, "split", split_bf16)
         n.base = ptr(img) + (o.base - ptr(t))
+    elif id(t) in _SHARES and t.is_contiguous() and (o.base - ptr(t)) % 16 == 0 and \
+            (t.numel() - (o.base - ptr(t)) // 4) % 4 == 0 and (not o.unbounded or o.base == ptr(t)):
+        img = _SHARES[id(t)][-1].image(t, o.base)
+        n.base = ptr(img)
     elif o.unbounded:       # read anywhere inside the buffer: the whole tensor
         img = split_bf16(t)
         n.base = ptr(img) + (o.base - ptr(t))
