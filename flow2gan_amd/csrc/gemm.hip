@@ -927,9 +927,12 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
 // 8-byte halves (row = [hi k0..31 | lo k0..31 | pad], the fp32 tile's 144-byte pitch), fragments are
 // ds_read_b128 of eight consecutive k, and every product is lo*hi + hi*lo + hi*hi on
 // v_mfma_f32_32x32x16_bf16 (24 MFMAs of 32 cycles per wave and slab instead of 64 of 64).
-template <bool SK, int EP, bool P3>
+// PM: 0 exact fp32, 1 split-bf16 (three MFMAs per product), 2 plain bf16 = the high parts of the
+// same images only (precision 2: one MFMA per product, the lo halves are neither staged nor read).
+template <bool SK, int EP, int PM>
 __global__ __launch_bounds__(256, 2)
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
+  constexpr bool P3 = PM != 0, HI = PM == 2;
   constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1034,9 +1037,11 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       for (int q = 0; q < 4; ++q) {
         if constexpr (P3) {
           *reinterpret_cast<u32x2*>(wA + bufoff + q * 32 * LDR) = u32x2{la[q].x, la[q].y};
-          *reinterpret_cast<u32x2*>(wA + bufoff + q * 32 * LDR + 16) = u32x2{la[q].z, la[q].w};
+          if constexpr (!HI)
+            *reinterpret_cast<u32x2*>(wA + bufoff + q * 32 * LDR + 16) = u32x2{la[q].z, la[q].w};
           *reinterpret_cast<u32x2*>(wB + bufoff + q * 32 * LDR) = u32x2{lb[q].x, lb[q].y};
-          *reinterpret_cast<u32x2*>(wB + bufoff + q * 32 * LDR + 16) = u32x2{lb[q].z, lb[q].w};
+          if constexpr (!HI)
+            *reinterpret_cast<u32x2*>(wB + bufoff + q * 32 * LDR + 16) = u32x2{lb[q].z, lb[q].w};
         } else {
           *reinterpret_cast<u32x4*>(wA + bufoff + q * 32 * LDR) = la[q];
           *reinterpret_cast<u32x4*>(wB + bufoff + q * 32 * LDR) = lb[q];
@@ -1044,33 +1049,6 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       }
     };
     auto mfma_slab = [&](int bufoff) {
-      if constexpr (P3) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            ah[mi] = *reinterpret_cast<const bf16x8*>(rA + bufoff + mi * 32 * LDR + ks * 8);
-            al[mi] = *reinterpret_cast<const bf16x8*>(rA + bufoff + mi * 32 * LDR + ks * 8 + 16);
-          }
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            bh[ni] = *reinterpret_cast<const bf16x8*>(rB + bufoff + ni * 32 * LDR + ks * 8);
-            bl[ni] = *reinterpret_cast<const bf16x8*>(rB + bufoff + ni * 32 * LDR + ks * 8 + 16);
-          }
-#pragma unroll
-          for (int term = 0; term < 3; ++term)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni) {
-                const bf16x8 av = term == 0 ? al[mi] : ah[mi];
-                const bf16x8 bv = term == 1 ? bl[ni] : bh[ni];
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
-              }
-        }
-        return;
-      }
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         float4 a[2], b[2];
@@ -1122,14 +1100,16 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           fa[i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8);
-          fa[2 + i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8 + 16);
           fb[i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + ks * 8);
-          fb[2 + i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + ks * 8 + 16);
+          if constexpr (!HI) {
+            fa[2 + i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8 + 16);
+            fb[2 + i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + ks * 8 + 16);
+          }
         }
       };
       auto mfma12 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = HI ? 2 : 0; term < 3; ++term)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -1150,21 +1130,21 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         lstore(nxtoff, wa, wb);
         // issue order: fragments, the loads of the slab after next, one LDS store behind each of
         // the first MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, HI ? 4 : 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < (HI ? 4 : 8); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, HI ? 2 : 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if constexpr (!HI) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         frags(nxtoff, 0, fa0, fb0);
         mfma12(fa1, fb1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, HI ? 4 : 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, HI ? 4 : 12, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
       int t = 0;
@@ -1410,7 +1390,7 @@ inline bool lean_b_ok(const f2g_operand& S) {
 }
 
 int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st) {
-  const bool p3 = d.precision == 1;
+  const int pm = d.precision == 1 ? 1 : (d.precision == 2 ? 2 : 0);
   constexpr size_t smem = (size_t)4 * 128 * LDR * sizeof(float);
   int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
   int zs = (K + kchunk - 1) / kchunk;
@@ -1432,16 +1412,21 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   }
   static bool attr_done = false;
   if (!attr_done) {
-    const void* ks[10] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, false>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, false>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, false>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, false>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, false>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, true>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, true>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, true>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, true>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, true>)};
+    const void* ks[15] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 1>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 1>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 1>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 1>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, 1>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 2>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 2>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 2>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 2>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, 2>)};
     for (const void* k : ks)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
@@ -1449,12 +1434,15 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   g_last_path = upb > 0 ? 2 : 1;
 #define F2G_LEAN(SKV, EPV)                                                                        \
   do {                                                                                            \
-    if (p3)                                                                                       \
-      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, true>), grid, dim3(256), smem, st, d, M, N,  \
-                         K, kchunk, upb);                                                         \
+    if (pm == 1)                                                                                  \
+      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 1>), grid, dim3(256), smem, st, d, M, N, K,  \
+                         kchunk, upb);                                                            \
+    else if (pm == 2)                                                                             \
+      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 2>), grid, dim3(256), smem, st, d, M, N, K,  \
+                         kchunk, upb);                                                            \
     else                                                                                          \
-      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, false>), grid, dim3(256), smem, st, d, M, N, \
-                         K, kchunk, upb);                                                         \
+      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 0>), grid, dim3(256), smem, st, d, M, N, K,  \
+                         kchunk, upb);                                                            \
   } while (0)
   if (upb > 0) F2G_LEAN(true, 3);
   else if (ep == 0) F2G_LEAN(false, 0);
@@ -1778,8 +1766,8 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     // pre-split operands (f2g_split_bf16) are understood by the lean kernel's split-bf16 instances only
     const bool presplit = d.A.split != 0 && d.B.split != 0;
     const bool lean = !f1 && lean_on && N > 64 && lean_a_ok(d.A) && lean_b_ok(d.B) &&
-                      (d.precision == 0 || (d.precision == 1 && presplit));
-    if ((d.A.split || d.B.split) && !(lean && d.precision == 1)) return F2G_EINVAL;
+                      (d.precision == 0 || ((d.precision == 1 || d.precision == 2) && presplit));
+    if ((d.A.split || d.B.split) && !(lean && d.precision != 0)) return F2G_EINVAL;
     if (lean && d.split_k == 0) {
       // library-chosen work split on the lean kernel: stream-K (same linear-epilogue condition as
       // split-K; F2G_DETERMINISTIC=1 keeps the plain tile grid)

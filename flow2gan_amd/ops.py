@@ -174,7 +174,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None.
     split_k: 0 = let the library decide (forms 0/1: split-K onto a zeroed output when the tile
     grid would leave most of the last wave of CUs idle), 1 = off, > 1 = as given."""
-    if form == 1 and LEAN_DGRAD and GEMM_PRECISION in (0, 1):
+    if form == 1 and LEAN_DGRAD:
         # data gradient C[r,n] = sum_k A[r,k] W[k,n] as a forward GEMM against the cached transpose
         # W^T [n][k]: same products in the same order, and the lean forward kernel applies
         src = getattr(Bm, "_src", None)
@@ -216,7 +216,8 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.form = form
     d.split_k = split_k
     d.precision = GEMM_PRECISION
-    if GEMM_PRECISION == 1 and form in (0, 2) and LEAN_SPLIT and L.lib.f2g_gemm_lean_ok(C.byref(d)):
+    if ((GEMM_PRECISION == 1 and form in (0, 2)) or (GEMM_PRECISION == 2 and form == 0)) \
+            and LEAN_SPLIT and L.lib.f2g_gemm_lean_ok(C.byref(d)):
         # split-bf16 on the lean kernel: both operands as pre-split images (no conversion in the K
         # loop); weights come from the derived-weight cache, activations are split here
         d.A, d.B = _split_operand(A), _split_operand(Bm)

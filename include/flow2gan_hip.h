@@ -146,7 +146,8 @@ int f2g_gemm_lean_ok(const f2g_gemm_desc* d);
  * of four floats becomes its four bf16 high parts followed by the four bf16 remainders (x = hi + lo
  * to ~2^-17 |x|), the same 16 bytes at the same offset.  An operand with `split = 1` over such an
  * image is read by the lean kernel's split-bf16 instances without any conversion in the K loop
- * (precision 1 only; both operands must be split; anything else is F2G_EINVAL). */
+ * (precision 1: three MFMAs per product; precision 2: the high parts only = plain bf16 operands;
+ * both operands must be split; anything else is F2G_EINVAL). */
 int f2g_split_bf16(float* dst, const float* src, int64_t n, f2g_stream_t stream);
 /* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
  * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels. */
