@@ -31,7 +31,7 @@ class Operand(C.Structure):
 
 class Epilogue(C.Structure):
     _fields_ = [
-        ("C", C.c_void_p), ("ldc", C.c_int64), ("P0o", C.c_int32), ("_pad", C.c_int32),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("P0o", C.c_int32), ("c_bf16", C.c_int32),
         ("seq_stride_o", C.c_int64), ("row_stride_o", C.c_int64), ("off_o", C.c_int64),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int64), ("gamma", C.c_void_p),
         ("aux", C.c_void_p), ("ldaux", C.c_int64), ("alpha_n", C.c_void_p),
@@ -56,7 +56,7 @@ class DwnormFwd(C.Structure):
         ("lens", C.c_void_p), ("w_dw", C.c_void_p), ("b_dw", C.c_void_p), ("beta", C.c_void_p),
         ("log_scale", C.c_void_p), ("cproj", C.c_void_p), ("ldcp", C.c_int64),
         ("Fc", C.c_int32), ("up", C.c_int32), ("te", C.c_void_p), ("ldte", C.c_int64),
-        ("rstd", C.c_void_p),
+        ("rstd", C.c_void_p), ("z_format", C.c_int32), ("_pad", C.c_int32),
     ]
 
 
@@ -124,6 +124,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGS = {
     "f2g_gemm": [C.POINTER(GemmDesc)],
     "f2g_split_bf16": [_P, _P, _L],
+    "f2g_to_bf16": [_P, _P, _L],
     "f2g_dwnorm_fwd": [C.POINTER(DwnormFwd)],
     "f2g_dwnorm_bwd": [C.POINTER(DwnormBwd)],
     "f2g_dwconv_bwd": [C.POINTER(DwconvBwd)],
@@ -226,7 +227,7 @@ def ptr(t) -> int | None:
         return None
     if not t.is_cuda:
         raise F2GError("flow2gan_amd ops need tensors on an MI355X (got a CPU tensor)")
-    if t.dtype not in (torch.float32, torch.int32):
+    if t.dtype not in (torch.float32, torch.int32, torch.bfloat16):   # bf16: GEMM operand images
         raise F2GError(f"unsupported dtype {t.dtype}")
     return t.data_ptr()
 

@@ -345,7 +345,25 @@ __global__ __launch_bounds__(256, (BWD || (FW == 4 && NCH == 3)) ? 2 : 3) void d
           float z4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) z4[e] = (u[i][k][e] * s + cp[i][k][e]) * te1[k][e];
-          st4(P.z + row * P.ldz + c4[k], z4);
+          if (P.z_format == 0) {
+            st4(P.z + row * P.ldz + c4[k], z4);
+          } else {   // the GEMM operand as it is consumed: split-bf16 image (1) or bf16 tensor (2)
+            unsigned short hb[4], lb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const __bf16 hh = (__bf16)z4[e];
+              const __bf16 ll = (__bf16)(z4[e] - (float)hh);
+              hb[e] = __builtin_bit_cast(unsigned short, hh);
+              lb[e] = __builtin_bit_cast(unsigned short, ll);
+            }
+            const unsigned h01 = hb[0] | ((unsigned)hb[1] << 16), h23 = hb[2] | ((unsigned)hb[3] << 16);
+            if (P.z_format == 1)
+              *reinterpret_cast<uint4*>(P.z + row * P.ldz + c4[k]) =
+                  make_uint4(h01, h23, lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+            else
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(P.z) + row * P.ldz + c4[k]) =
+                  make_uint2(h01, h23);
+          }
         }
       }
       if (P.rstd && lane == 0) P.rstd[row] = s;
@@ -774,6 +792,14 @@ template <bool BWD>
 int launch_dwnorm(const f2g_dwnorm_bwd_desc& d, hipStream_t st) {
   const f2g_dwnorm_fwd_desc& f = d.f;
   if (f.B <= 0 || f.F <= 0) return F2G_OK;
+  if (!BWD && f.z_format != 0) {   // operand-format outputs: vector kernel only
+    const bool okf = (f.z_format == 1 || f.z_format == 2) && (f.C % 4) == 0 && (f.ldx % 4) == 0 &&
+                     (((uintptr_t)f.x) & 15) == 0 && (((uintptr_t)f.z) & 15) == 0 &&
+                     (f.ldz % (f.z_format == 1 ? 4 : 8)) == 0 &&
+                     (!f.cproj || ((f.ldcp % 4) == 0 && (((uintptr_t)f.cproj) & 15) == 0)) &&
+                     (!f.te || ((f.ldte % 4) == 0 && (((uintptr_t)f.te) & 15) == 0));
+    if (!okf) return F2G_EINVAL;
+  }
   // frames per wave: a multiple of the condition upsampling factor (4 | up)
   // backward: 4 frames per wave wherever the registers allow it (<= 512 channels: 2 chunks per
   // lane); 768 channels would spill, so they keep 2 (the workspace query sizes for 2, the larger)

@@ -902,7 +902,7 @@ inline int op_mode(const f2g_operand& S, bool red_is_cols) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r) {
+__device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r, int es = 4) {
   if (r >= S.rows) return 0x80000000u;
   long long off;
   if (S.P0 == 1 && S.P1 == 1) {
@@ -913,7 +913,7 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
     off = (long long)sq * S.seq_stride + (long long)(p1 * S.step1 - S.pad1) * S.line_stride +
           (long long)(p0 * S.step0 - S.pad0) * S.unit;
   }
-  return (unsigned)(off * 4);
+  return (unsigned)(off * es);
 }
 
 // EP selects the epilogue compiled into an instance (the host picks it from the descriptor): one
@@ -928,11 +928,16 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r)
 // ds_read_b128 of eight consecutive k, and every product is lo*hi + hi*lo + hi*hi on
 // v_mfma_f32_32x32x16_bf16 (24 MFMAs of 32 cycles per wave and slab instead of 64 of 64).
 // PM: 0 exact fp32, 1 split-bf16 (three MFMAs per product), 2 plain bf16 = the high parts of the
-// same images only (precision 2: one MFMA per product, the lo halves are neither staged nor read).
+// same images only (precision 2: one MFMA per product, the lo halves are neither staged nor read),
+// 3 plain bf16 over TRUE bf16 tensors (f2g_to_bf16 images / bf16 producers: 2 bytes per element,
+// operand strides in elements): the same 128-byte staged row now holds 64 k, so a slab carries
+// twice the reduction for the same load, LDS and barrier work (16 MFMAs per wave and slab).
 template <bool SK, int EP, int PM>
 __global__ __launch_bounds__(256, 2)
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
-  constexpr bool P3 = PM != 0, HI = PM == 2;
+  constexpr bool P3 = PM == 1 || PM == 2, HI = PM == 2, BF = PM == 3;
+  constexpr int BKE = BF ? 64 : BK;   // elements per slab
+  constexpr int ES = BF ? 2 : 4;      // bytes per element
   constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -948,23 +953,23 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   // last tile (n >= N) are out of range = zeros, and ONE per-thread offset serves all four staged
   // rows (their distance, 32 rows, is uniform and rides in the scalar offset)
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * 4), 0x00020000);
-  const int qstepB = (int)(32 * d.B.seq_stride * 4);
+      (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * ES), 0x00020000);
+  const int qstepB = (int)(32 * d.B.seq_stride * ES);
   // scalar K walk of A: segments of `seglen` columns, `line_stride` floats apart
   const int seglen = d.A.seglen < d.A.cols ? d.A.seglen : d.A.cols;
-  const int spseg = seglen / BK;                                  // slabs per segment
-  const int segjump = (int)((d.A.line_stride - seglen) * 4);      // bytes skipped at a segment end
+  const int spseg = seglen / BKE;                                 // slabs per segment
+  const int segjump = (int)((d.A.line_stride - seglen) * ES);     // bytes skipped at a segment end
   float* wA = smem + rr * LDR + ch * (P3 ? 2 : 4);
   float* wB = smem + 2 * TSZ + rr * LDR + ch * (P3 ? 2 : 4);
-  const float* rA = smem + (wm * 64 + li) * LDR + h * (P3 ? 4 : 16);
-  const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * (P3 ? 4 : 16);
+  const float* rA = smem + (wm * 64 + li) * LDR + h * ((P3 || BF) ? 4 : 16);
+  const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * ((P3 || BF) ? 4 : 16);
 
   // ---- work of this block.  Classic: one tile (blockIdx.x/y), K chunk blockIdx.z.  Stream-K
   // (upb > 0): the (tile, slab) units of the whole problem are numbered tile-major and every
   // block takes `upb` consecutive ones -- a tile count just above a multiple of the 512 resident
   // blocks no longer costs a nearly empty extra round; tiles cut between blocks are accumulated
   // atomically onto a zeroed output, bias / residual entering with the part that holds slab 0.
-  const int nt_all = K / BK;
+  const int nt_all = K / BKE;
   const int tiles_n = (N + BN - 1) / BN;
   int u = 0, u_end = 0;
   if (SK) {
@@ -985,8 +990,8 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       const int kbeg = blockIdx.z * kchunk;
       int kend = kbeg + kchunk;
       if (kend > K) kend = K;
-      s0 = kbeg / BK;
-      nt = (kend - kbeg) / BK;
+      s0 = kbeg / BKE;
+      nt = (kend - kbeg) / BKE;
       first = blockIdx.z == 0;
       partial = false;
       more = false;
@@ -1016,13 +1021,13 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
     unsigned offA[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      offA[q] = lean_row_offset(d.A, m0 + rr + 32 * q);
+      offA[q] = lean_row_offset(d.A, m0 + rr + 32 * q, ES);
       if (offA[q] != 0x80000000u) offA[q] += ch * 16;
     }
-    const unsigned offB = (unsigned)((long long)(n0 + rr) * d.B.seq_stride * 4) + ch * 16;
+    const unsigned offB = (unsigned)((long long)(n0 + rr) * d.B.seq_stride * ES) + ch * 16;
     int left = spseg - (s0 % spseg);
-    const int ka0 = (int)(((long long)(s0 / spseg) * d.A.line_stride + (long long)(s0 % spseg) * BK) * 4);
-    const int kb0 = s0 * BK * 4;
+    const int ka0 = (int)(((long long)(s0 / spseg) * d.A.line_stride + (long long)(s0 % spseg) * BKE) * ES);
+    const int kb0 = s0 * BKE * ES;
     int ka = ka0, kb = kb0;
 
     auto gload = [&](int soa, int sob, u32x4 (&la)[4], u32x4 (&lb)[4]) {
@@ -1079,7 +1084,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         ka += segjump;
       }
     };
-    if constexpr (P3) {
+    if constexpr (P3 || BF) {
       // The bf16 MFMA phase of a slab is 5x shorter than the fp32 one (24 x 32 cycles), too short to
       // hide a load, an LDS fill and a barrier behind it one after the other.  So the phases overlap
       // inside a wave: slab t's MFMAs are interleaved with the LDS stores of slab t+1 (in registers
@@ -1097,6 +1102,16 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       // the MFMAs of f1; f1 is read at the top of an iteration, under the MFMAs of f0.
       bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
       auto frags = [&](int off, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+        if constexpr (BF) {   // half `ks` of the slab = k steps 2ks, 2ks+1: [0..1] and [2..3]
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              fa[2 * j + i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + (2 * ks + j) * 8);
+              fb[2 * j + i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + (2 * ks + j) * 8);
+            }
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           fa[i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8);
@@ -1108,6 +1123,17 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         }
       };
       auto mfma12 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+        if constexpr (BF) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * j + mi], fb[2 * j + ni],
+                                                                     acc[mi][ni], 0, 0, 0);
+          return;
+        }
 #pragma unroll
         for (int term = HI ? 2 : 0; term < 3; ++term)
 #pragma unroll
@@ -1137,14 +1163,14 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x200, HI ? 2 : 1, 0);
         }
-        if constexpr (!HI) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if constexpr (PM == 1) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         frags(nxtoff, 0, fa0, fb0);
         mfma12(fa1, fb1);
         __builtin_amdgcn_sched_group_barrier(0x100, HI ? 4 : 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, HI ? 4 : 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, HI ? 4 : (BF ? 8 : 12), 0);
         __builtin_amdgcn_sched_barrier(0);
       };
       int t = 0;
@@ -1192,6 +1218,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       // plain store (+ leaky ReLU / PReLU): uniform row bases, per-lane constant offset
       const float sl = E.lrelu_slope;
       const bool pre = E.prelu_slope != nullptr, two = pre && E.prelu_out != nullptr;
+      const bool cbf = E.c_bf16 != 0;
       const unsigned coff = (unsigned)(((long long)(4 * h) * E.ldc + li) * 4);
       const unsigned poff = (unsigned)(((long long)(4 * h) * E.ld_prelu_out + li) * 4);
 #pragma unroll
@@ -1205,6 +1232,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           const float gam = (hasres && col0 + li < N) ? (E.gamma ? E.gamma[col0 + li] : 1.f) : 0.f;
           if (row0 + 32 <= M && col0 + 32 <= N) {
             char* cb = reinterpret_cast<char*>(E.C + (long long)row0 * E.ldc + col0);
+            __bf16* cb16 = reinterpret_cast<__bf16*>(E.C) + (long long)row0 * E.ldc + col0;
             char* pb = reinterpret_cast<char*>(E.prelu_out + (long long)row0 * E.ld_prelu_out + col0);
             const char* rb = reinterpret_cast<const char*>(E.res + (long long)row0 * E.ldres + col0);
             const unsigned roff = (unsigned)(((long long)(4 * h) * E.ldres + li) * 4);
@@ -1225,7 +1253,10 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
                 if (two) *reinterpret_cast<float*>(pb + ro * E.ld_prelu_out * 4 + poff) = pv;
                 else v = pv;
               }
-              *reinterpret_cast<float*>(cb + ro * E.ldc * 4 + coff) = v;
+              if (cbf)   // C is a bf16 tensor (ldc in elements): the next GEMM's operand as it is
+                cb16[(ro + 4 * h) * E.ldc + li] = (__bf16)v;
+              else
+                *reinterpret_cast<float*>(cb + ro * E.ldc * 4 + coff) = v;
             }
             __builtin_amdgcn_sched_barrier(0);   // one sub-tile's loads / stores at a time (registers)
           } else {
@@ -1241,7 +1272,8 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
                   if (two) E.prelu_out[(long long)row * E.ld_prelu_out + col0 + li] = pv;
                   else v = pv;
                 }
-                E.C[(long long)row * E.ldc + col0 + li] = v;
+                if (cbf) reinterpret_cast<__bf16*>(E.C)[(long long)row * E.ldc + col0 + li] = (__bf16)v;
+                else E.C[(long long)row * E.ldc + col0 + li] = v;
               }
             }
           }
@@ -1384,20 +1416,31 @@ inline bool lean_a_ok(const f2g_operand& S) {
   return last * 4 < 0x7ff00000ll;
 }
 
+// the same operand as a TRUE bf16 tensor (split = 2): 16-byte chunks hold 8 elements, slabs 64
+inline bool lean_bf16_ok(const f2g_operand& A, const f2g_operand& B) {
+  const long long eu0 = (long long)A.step0 * A.unit, ep0 = (long long)A.pad0 * A.unit;
+  if ((A.seq_stride & 7) || (A.line_stride & 7) || (eu0 & 7) || (ep0 & 7) || (B.seq_stride & 7)) return false;
+  const int seglen = A.seglen < A.cols ? A.seglen : A.cols;
+  return seglen % 64 == 0 && B.cols % 64 == 0;
+}
+
 inline bool lean_b_ok(const f2g_operand& S) {
   return host_plain(S) && !S.alpha && al16(S.base) && (S.seq_stride & 3) == 0 && S.cols % BK == 0 &&
          (long long)S.rows * S.seq_stride * 4 < 0x7ff00000ll;
 }
 
 int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st) {
-  const int pm = d.precision == 1 ? 1 : (d.precision == 2 ? 2 : 0);
+  // operand images: split = 1 -> split-bf16 pairs (precision 1: all three products, 2: high parts),
+  // split = 2 -> true bf16 tensors (precision 2 only)
+  const int pm = d.A.split == 2 ? 3 : (d.precision == 1 ? 1 : (d.precision == 2 ? 2 : 0));
+  const int bk = pm == 3 ? 64 : BK;
   constexpr size_t smem = (size_t)4 * 128 * LDR * sizeof(float);
-  int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
+  int kchunk = ((K + split - 1) / split + bk - 1) / bk * bk;
   int zs = (K + kchunk - 1) / kchunk;
   dim3 grid((M + 127) / 128, (N + 127) / 128, zs);
   if (grid.x == 0 || grid.y == 0) return F2G_OK;
   if (upb > 0) {
-    const long long total = (long long)grid.x * grid.y * (K / BK);
+    const long long total = (long long)grid.x * grid.y * (K / bk);
     grid = dim3((unsigned)((total + upb - 1) / upb), 1, 1);
   }
   // epilogue instance (see gemm_lean_kernel)
@@ -1410,9 +1453,13 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
              !E.prelu_slope && E.lrelu_slope == 0.f && !E.mask_src) ep = 1;
     else if (plainish && !E.res && !E.prelu_slope && E.P0o >= 32) ep = 2;
   }
+  if (E.c_bf16 && ep != 0) {
+    f2g_set_error("f2g_gemm: a bf16 output needs the plain-store epilogue of the lean kernel");
+    return F2G_EINVAL;
+  }
   static bool attr_done = false;
   if (!attr_done) {
-    const void* ks[15] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 0>),
+    const void* ks[20] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 0>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 0>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 0>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 0>),
@@ -1426,7 +1473,12 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 2>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 2>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 2>),
-                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, 2>)};
+                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, 2>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 3>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 3>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 3>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 3>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, 3>)};
     for (const void* k : ks)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
@@ -1439,6 +1491,9 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
                          kchunk, upb);                                                            \
     else if (pm == 2)                                                                             \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 2>), grid, dim3(256), smem, st, d, M, N, K,  \
+                         kchunk, upb);                                                            \
+    else if (pm == 3)                                                                             \
+      hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 3>), grid, dim3(256), smem, st, d, M, N, K,  \
                          kchunk, upb);                                                            \
     else                                                                                          \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 0>), grid, dim3(256), smem, st, d, M, N, K,  \
@@ -1701,7 +1756,8 @@ extern "C" int f2g_gemm_lean_ok(const f2g_gemm_desc* dp) {
   if (d.form == 2) return lean_on && leanw_ok(d) ? 1 : 0;   // split-bf16 weight-gradient kernel
   if (d.form != 0) return 0;
   if (d.A.cols != d.B.cols || !host_plain(d.B)) return 0;
-  return lean_on && d.B.rows > 64 && lean_a_ok(d.A) && lean_b_ok(d.B) ? 1 : 0;
+  if (!(lean_on && d.B.rows > 64 && lean_a_ok(d.A) && lean_b_ok(d.B))) return 0;
+  return lean_bf16_ok(d.A, d.B) ? 3 : 1;   // bit 1: also as true bf16 tensors (split = 2)
 }
 
 // dst = split-bf16 image of src (n4 groups of four floats, both 16-byte aligned): group g becomes
@@ -1721,6 +1777,33 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(uint4* __restrict__ dst
     dst[i] = make_uint4(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16), l0 | ((unsigned)l1 << 16),
                         l2 | ((unsigned)l3 << 16));
   }
+}
+
+// dst (bf16, n elements) = round-to-nearest-even of src: the TRUE bf16 image of a tensor (same shape,
+// strides in elements) for the plain-bf16 lean instances
+__global__ __launch_bounds__(256) void to_bf16_kernel(uint2* __restrict__ dst, const float4* __restrict__ src,
+                                                      long long n4) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = src[i];
+    unsigned short h0, h1, h2, h3, l;
+    split_bf16(v.x, h0, l);
+    split_bf16(v.y, h1, l);
+    split_bf16(v.z, h2, l);
+    split_bf16(v.w, h3, l);
+    dst[i] = make_uint2(h0 | ((unsigned)h1 << 16), h2 | ((unsigned)h3 << 16));
+  }
+}
+
+extern "C" int f2g_to_bf16(void* dst, const float* src, int64_t n, f2g_stream_t stream) {
+  if (!dst || !src || (n & 3) || (((uintptr_t)dst) & 7) || !al16(src)) return F2G_EINVAL;
+  if (n == 0) return F2G_OK;
+  const long long n4 = n / 4;
+  long long blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<uint2*>(dst), reinterpret_cast<const float4*>(src), n4);
+  return f2g_check_launch();
 }
 
 extern "C" int f2g_split_bf16(float* dst, const float* src, int64_t n, f2g_stream_t stream) {
@@ -1764,16 +1847,20 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     static const bool no_auto = getenv("F2G_DETERMINISTIC") && atoi(getenv("F2G_DETERMINISTIC")) != 0;
     static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
     // pre-split operands (f2g_split_bf16) are understood by the lean kernel's split-bf16 instances only
-    const bool presplit = d.A.split != 0 && d.B.split != 0;
+    const bool presplit = d.A.split != 0 && d.B.split == d.A.split;
+    const bool bf16img = d.A.split == 2;
     const bool lean = !f1 && lean_on && N > 64 && lean_a_ok(d.A) && lean_b_ok(d.B) &&
-                      (d.precision == 0 || ((d.precision == 1 || d.precision == 2) && presplit));
+                      (d.precision == 0 || ((d.precision == 1 || d.precision == 2) && presplit)) &&
+                      (!bf16img || (d.precision == 2 && lean_bf16_ok(d.A, d.B)));
     if ((d.A.split || d.B.split) && !(lean && d.precision != 0)) return F2G_EINVAL;
+    if (d.E.c_bf16 && !lean) return F2G_EINVAL;
     if (lean && d.split_k == 0) {
       // library-chosen work split on the lean kernel: stream-K (same linear-epilogue condition as
       // split-K; F2G_DETERMINISTIC=1 keeps the plain tile grid)
       static const int sk_mode = getenv("F2G_STREAMK") ? atoi(getenv("F2G_STREAMK")) : 1;
       int upb = 0;
-      if (sk_mode > 0 && linear && !no_auto && !d.E.atomic) upb = lean_stream_k(M, N, K, sk_mode > 1);
+      if (sk_mode > 0 && linear && !no_auto && !d.E.atomic && !d.E.c_bf16)
+        upb = lean_stream_k(M, N, bf16img ? K / 2 : K, sk_mode > 1);   // (64-element slabs)
       if (upb > 0 && !d.E.accumulate)
         hipLaunchKernelGGL(zero_out_kernel, dim3(f2g_grid_for((int64_t)M * N, 256)), dim3(256), 0,
                            st, d.E, M, N);

@@ -67,12 +67,24 @@ def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0,
     """x (B*F, C) -> new x.  Returns (x_out, z, a) (z, a kept for backward)."""
     dev = x.device
     rows, Cc, Hh = B * F, bp.C, bp.H
+    fmt = ops.operand_formats_ok(Cc, Hh)
+    if fmt == 2 and not keep:
+        # plain-bf16 inference (BASELINE config 2): z and the hidden activation live in HBM as
+        # bf16, written by their producers in the layout the lean GEMM kernel reads
+        z = torch.empty(rows, Cc, device=dev, dtype=torch.bfloat16)
+        ops.dwnorm_fwd(x, z, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta, bp.log_scale.reshape(1),
+                       cproj, ldcp, Fc, up, cp_off, te, ldte, te_off, z_format=2)
+        a = torch.empty(rows, Hh, device=dev, dtype=torch.bfloat16)
+        gemm(mat(z, rows, Cc, split=2), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha,
+             split_k=1)
+        out = ops.empty(rows, Cc, device=dev)
+        gemm(mat(a, rows, Hh, split=2), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
+             gamma=bp.gamma.reshape(Cc))
+        return out, z, (a, a, None, 0)
+    zsplit = 1 if fmt == 1 else 0   # (split-bf16 mode) dwnorm writes z as the image the GEMMs read
     z = ops.empty(rows, Cc, device=dev)
     ops.dwnorm_fwd(x, z, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta, bp.log_scale.reshape(1),
-                   cproj, ldcp, Fc, up, cp_off, te, ldte, te_off)
-    # pwconv1 -> PReLU in the producing epilogue: the hidden activation p is written once (next to
-    # the pre-activation a when the backward will need it) instead of being re-derived from a by
-    # every column tile of pwconv2 inside its K loop
+                   cproj, ldcp, Fc, up, cp_off, te, ldte, te_off, z_format=zsplit)
     a = ops.empty(rows, Hh, device=dev)
     if keep:
         p = ops.empty(rows, Hh, device=dev)
@@ -80,18 +92,18 @@ def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0,
         # of the backward pass as well
         share = ops.split_sharing(z, p)
         with share:
-            gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha,
-                 prelu_out=p)
+            gemm(mat(z, rows, Cc, split=zsplit), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1,
+                 prelu=bp.alpha, prelu_out=p)
             out = ops.empty(rows, Cc, device=dev)
             gemm(mat(p, rows, Hh), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
                  gamma=bp.gamma.reshape(Cc))
-        return out, z, (a, p, share)
+        return out, z, (a, p, share, zsplit)
     p = a
-    gemm(mat(z, rows, Cc), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha)
+    gemm(mat(z, rows, Cc, split=zsplit), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha)
     out = ops.empty(rows, Cc, device=dev)
     gemm(mat(p, rows, Hh), mat(bp.w2.reshape(Cc, Hh)), out, bias=bp.b2, res=x,
          gamma=bp.gamma.reshape(Cc))
-    return out, z, (a, p, None)
+    return out, z, (a, p, None, zsplit)
 
 
 def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale: bool,
@@ -99,7 +111,7 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
               g_te=None):
     """Backward of block_fwd.  Destroys z and a (reused as gradient buffers).
     Returns (gx, grads) with grads ordered like BLOCK_KEYS."""
-    a, p_act, share = a
+    a, p_act, share, zsplit = a
     if share is None:
         share = ops.split_sharing()
     dev = x.device
@@ -114,7 +126,7 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
         gemm(mat(gout, rows, Cc), mat(bp.w2.reshape(Cc, Hh)), a, form=1, aux=a, alpha_n=bp.alpha,
              colsum_alpha=g_alpha, colsum=g_b1)
     with share, ops.split_sharing(a):      # a now holds da
-        ops.wgrad(a, Hh, a.stride(0), mat(z, rows, Cc), g_w1)
+        ops.wgrad(a, Hh, a.stride(0), mat(z, rows, Cc, split=zsplit), g_w1)
         # dz = da W1  (z is dead after the weight gradient above: reuse it)
         gemm(mat(a, rows, Hh), mat(bp.w1.reshape(Hh, Cc)), z, form=1)
     share.drop()

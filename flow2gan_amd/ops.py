@@ -90,8 +90,9 @@ def transposed(w2d):
 
 # ------------------------------------------------------------------ operands
 def mat(t, rows: Optional[int] = None, cols: Optional[int] = None, ld: Optional[int] = None,
-        alpha=None, lrelu_src=None, slope: float = 0.0, offset: int = 0) -> Operand:
-    """Plain row-major matrix view of `t` starting `offset` floats in."""
+        alpha=None, lrelu_src=None, slope: float = 0.0, offset: int = 0, split: int = 0) -> Operand:
+    """Plain row-major matrix view of `t` starting `offset` floats in.  split: what `t` holds --
+    0 fp32 values, 1 their split-bf16 image (a producer wrote it: f2g_operand.split), 2 bf16."""
     if rows is None:
         rows = t.shape[0]
     if ld is None:
@@ -99,7 +100,8 @@ def mat(t, rows: Optional[int] = None, cols: Optional[int] = None, ld: Optional[
     if cols is None:
         cols = t.shape[-1]
     o = Operand()
-    o.base = ptr(t) + 4 * offset
+    o.base = ptr(t) + (2 if split == 2 else 4) * offset
+    o.split = split
     o.rows, o.cols = rows, cols
     o.P1 = o.P0 = 1
     o.seglen = cols
@@ -185,6 +187,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     e = Epilogue()
     e.C = ptr(out) + 4 * out_offset
     e.ldc = ldc if ldc is not None else out.stride(0)
+    e.c_bf16 = 1 if out.dtype == torch.bfloat16 else 0   # (lean kernel, plain stores only)
     if rowmap is not None:
         e.P0o, e.seq_stride_o, e.row_stride_o, e.off_o = rowmap
     else:
@@ -216,11 +219,16 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.form = form
     d.split_k = split_k
     d.precision = GEMM_PRECISION
-    if ((GEMM_PRECISION == 1 and form in (0, 2)) or (GEMM_PRECISION == 2 and form == 0)) \
-            and LEAN_SPLIT and L.lib.f2g_gemm_lean_ok(C.byref(d)):
-        # split-bf16 on the lean kernel: both operands as pre-split images (no conversion in the K
-        # loop); weights come from the derived-weight cache, activations are split here
-        d.A, d.B = _split_operand(A), _split_operand(Bm)
+    if ((GEMM_PRECISION == 1 and form in (0, 2)) or (GEMM_PRECISION == 2 and form == 0)) and LEAN_SPLIT:
+        ok = L.lib.f2g_gemm_lean_ok(C.byref(d))
+        if GEMM_PRECISION == 2 and (ok & 2) and (A.split == 2 or BF16_IMAGES):
+            # plain bf16 over TRUE bf16 tensors (64-element slabs): activations written as bf16 by
+            # their producers (or converted here), weights from the derived-weight cache
+            d.A, d.B = _bf16_operand(A), _bf16_operand(Bm)
+        elif ok:
+            # split-bf16 on the lean kernel: both operands as pre-split images (no conversion in
+            # the K loop); weights come from the derived-weight cache, activations are split here
+            d.A, d.B = _split_operand(A), _split_operand(Bm)
     if GEMM_TIMER is not None:
         GEMM_TIMER.launch(d, A, Bm, form)
     else:
@@ -284,6 +292,63 @@ class split_sharing:
             call("f2g_split_bf16", ptr(img), base, n)
             self.imgs[key] = img
         return img
+
+
+BF16_IMAGES = _os.environ.get("F2G_BF16_IMAGES", "1") != "0"   # precision 2: true bf16 operands
+
+
+def to_bf16(t):
+    """bf16 copy (round to nearest even) of a contiguous fp32 tensor through f2g_to_bf16."""
+    out = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    call("f2g_to_bf16", ptr(out), ptr(t), t.numel())
+    out._f2g_const = getattr(t, "_f2g_const", False)
+    return out
+
+
+def _bf16_operand(o: Operand) -> Operand:
+    """Copy of a lean-eligible operand over a true bf16 tensor (f2g_operand.split = 2)."""
+    if o.split == 2:
+        return o
+    if o.split:
+        raise L.F2GError("a split-bf16 image cannot serve as a bf16 operand")
+    t = o._keep[0]
+    n = Operand()
+    C.memmove(C.byref(n), C.byref(o), C.sizeof(Operand))
+    if _is_const(t) and t.is_contiguous() and t.numel() % 4 == 0 and (o.base - ptr(t)) % 16 == 0:
+        img = derived(t, "bf16", to_bf16)
+        n.base = ptr(img) + (o.base - ptr(t)) // 2
+    else:
+        nseq = o.rows // (o.P0 * o.P1)
+        nseg = o.cols // min(o.seglen, o.cols)
+        if o.P0 == 1 and o.P1 == 1:
+            extent = (o.rows - 1) * o.seq_stride + o.cols
+        else:
+            extent = (nseq - 1) * o.seq_stride + \
+                ((o.P1 - 1) * o.step1 - o.pad1 + nseg - 1) * o.line_stride + \
+                ((o.P0 - 1) * o.step0 - o.pad0) * o.unit + min(o.seglen, o.cols)
+        extent = (extent + 3) // 4 * 4
+        img = torch.empty(extent, device=t.device, dtype=torch.bfloat16)
+        call("f2g_to_bf16", ptr(img), o.base, extent)
+        n.base = ptr(img)
+    n.split = 2
+    n._keep = (img,) + tuple(o._keep)
+    return n
+
+
+def operand_formats_ok(Cc: int, Hh: int) -> int:
+    """Can the producers of a ConvNeXt block write its GEMM operands directly in the format the
+    lean kernels consume?  2: bf16 tensors (precision 2: plain-bf16 inference), 1: split-bf16
+    images (precision 1), 0: no (fp32 tensors, converted per GEMM where a lean kernel applies)."""
+    if not LEAN_SPLIT or _os.environ.get("F2G_LEAN", "1") == "0" or not OPERAND_PRODUCERS:
+        return 0
+    if GEMM_PRECISION == 2 and BF16_IMAGES and Cc % 64 == 0 and Hh % 64 == 0 and Cc > 64:
+        return 2
+    if GEMM_PRECISION == 1 and Cc % 128 == 0 and Hh % 128 == 0:
+        return 1
+    return 0
+
+
+OPERAND_PRODUCERS = _os.environ.get("F2G_OPERAND_PRODUCERS", "1") != "0"
 
 
 def _is_const(t) -> bool:
@@ -672,9 +737,11 @@ def _dw_desc(x, ldx, z, ldz, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cpr
 
 
 def dwnorm_fwd(x, z, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=None, ldcp=0, Fc=0,
-               up=1, cp_off=0, te=None, ldte=0, te_off=0, rstd=None):
+               up=1, cp_off=0, te=None, ldte=0, te_off=0, rstd=None, z_format: int = 0):
+    """z_format: 0 fp32, 1 split-bf16 image in an fp32-typed tensor, 2 z is a bf16 tensor."""
     f = _dw_desc(x, x.stride(0), z, z.stride(0), B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale,
                  cproj, ldcp, Fc, up, cp_off, te, ldte, te_off, rstd)
+    f.z_format = z_format
     if GEMM_TIMER is not None:
         # algorithmic bytes: read x, write z, read the condition row once per `up` frames
         nb = 4.0 * B * F * Cc * (2.0 + (1.0 / up if cproj is not None else 0.0))

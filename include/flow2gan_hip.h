@@ -59,7 +59,10 @@ typedef struct {
   int32_t step0, pad0, unit, L0u;
   int64_t seq_stride, line_stride;
   int32_t reflect;
-  int32_t split; /* 1: `base` holds the split-bf16 image written by f2g_split_bf16 (same addressing) */
+  /* 1: `base` holds the split-bf16 image written by f2g_split_bf16 (same addressing);
+   * 2: `base` is a TRUE bf16 tensor (f2g_to_bf16 or a bf16 producer): strides / offsets stay in
+   *    elements, the reduction needs whole 64-element slabs (precision 2, lean kernel only) */
+  int32_t split;
   const float* alpha;
   const float* lrelu_src;
   float lrelu_slope;
@@ -77,7 +80,8 @@ typedef struct {
 typedef struct {
   float* C;
   int64_t ldc;
-  int32_t P0o, _pad;
+  int32_t P0o;
+  int32_t c_bf16; /* 1: C is a bf16 tensor (ldc in elements): plain stores of the lean kernel only */
   int64_t seq_stride_o, row_stride_o, off_o;
   const float* bias;
   const float* res;
@@ -149,6 +153,10 @@ int f2g_gemm_lean_ok(const f2g_gemm_desc* d);
  * (precision 1: three MFMAs per product; precision 2: the high parts only = plain bf16 operands;
  * both operands must be split; anything else is F2G_EINVAL). */
 int f2g_split_bf16(float* dst, const float* src, int64_t n, f2g_stream_t stream);
+/* dst (bf16, n elements, n % 4 == 0) = round-to-nearest-even of src: a TRUE bf16 tensor for operands
+ * with split = 2 (BASELINE config 2: bf16 activations in HBM).  f2g_gemm_lean_ok returns 3 instead
+ * of 1 when a form-0 descriptor can also be served from such tensors. */
+int f2g_to_bf16(void* dst, const float* src, int64_t n, f2g_stream_t stream);
 /* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
  * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels. */
 int f2g_gemm_last_path(void);
@@ -179,6 +187,11 @@ typedef struct {
   const float* te;
   int64_t ldte;
   float* rstd; /* (B*F) out: s = r^-1/2 * exp(log_scale) */
+  /* forward only -- what z holds (it is read by GEMMs only): 0 fp32; 1 the split-bf16 image of the
+   * same values (f2g_split_bf16 layout, same addressing: ldz in floats); 2 a bf16 tensor (ldz in
+   * ELEMENTS).  1 / 2 need C % 4 == 0 and 16-byte aligned rows. */
+  int32_t z_format;
+  int32_t _pad;
 } f2g_dwnorm_fwd_desc;
 int f2g_dwnorm_fwd(const f2g_dwnorm_fwd_desc* d, f2g_stream_t stream);
 

@@ -164,6 +164,49 @@ def test_wgrad_split_bf16_unbounded_windows(ops):
     close(out, w.grad.permute(0, 2, 1).reshape(Cout, 5 * Cin), rtol=5e-5, name="leanw3-window")
 
 
+@pytest.mark.parametrize("R,K,N", [(300, 512, 96), (1000, 64, 1536), (129, 1536, 512)])
+def test_gemm_true_bf16_operands_and_bf16_output(ops, R, K, N):
+    """precision 2 over TRUE bf16 tensors (f2g_operand.split = 2: 64-element slabs): products of the
+    bf16-rounded operands, fp32 accumulation; optional bf16 output written by the epilogue."""
+    A, W, b, ps = rnd(R, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(N, seed=6) * 0.3
+    ref = A.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    was = ops.GEMM_PRECISION
+    ops.set_gemm_precision("bf16")
+    try:
+        out = torch.empty(R, N, device=DEV)
+        ops.gemm(ops.mat(g(A)), ops.mat(g(W)), out, bias=g(b), split_k=1)   # converted here
+        assert ops.L.lib.f2g_gemm_last_path() == 1
+        close(out, ref, rtol=1e-5, name="bf16 lean")
+        a16 = g(A).bfloat16()                                               # a producer's bf16 tensor
+        out16 = torch.empty(R, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(ops.mat(a16, split=2), ops.mat(g(W)), out16, bias=g(b), prelu=g(ps), split_k=1)
+        want = torch.where(ref > 0, ref, ref * ps.double()[None])
+        close(out16.float(), want, rtol=5e-3, name="bf16 lean, bf16 out")
+        assert float((out16.float().cpu().double() - want.float().bfloat16().double()).abs().max()) <= \
+            2.0 ** -7 * float(want.abs().max())
+    finally:
+        ops.GEMM_PRECISION = was
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_dwnorm_writes_gemm_operand_formats(ops, fmt):
+    """dwnorm forward with z_format 1 / 2: the split-bf16 image / the bf16 tensor of exactly the
+    values the fp32 kernel writes."""
+    B, Fr, Cc, K = 2, 37, 256, 7
+    x = rnd(B * Fr, Cc, seed=1)
+    wdw, bdw, beta, ls = rnd(Cc, 1, K, seed=2) * 0.3, rnd(Cc, seed=3) * 0.1, rnd(Cc, seed=4) * 0.1, rnd(1, seed=5) * 0.1
+    z = torch.empty(B * Fr, Cc, device=DEV)
+    ops.dwnorm_fwd(g(x), z, B, Fr, Cc, K, None, g(wdw), g(bdw), g(beta), g(ls))
+    if fmt == 1:
+        zi = torch.empty(B * Fr, Cc, device=DEV)
+        ops.dwnorm_fwd(g(x), zi, B, Fr, Cc, K, None, g(wdw), g(bdw), g(beta), g(ls), z_format=1)
+        assert torch.equal(zi.view(torch.int32), ops.split_bf16(z).view(torch.int32))
+    else:
+        zb = torch.empty(B * Fr, Cc, device=DEV, dtype=torch.bfloat16)
+        ops.dwnorm_fwd(g(x), zb, B, Fr, Cc, K, None, g(wdw), g(bdw), g(beta), g(ls), z_format=2)
+        assert torch.equal(zb, z.bfloat16())
+
+
 def test_gemm_split_bf16_windowed_operand(ops):
     """MPD-style (5,1) conv over a halo layout in split-bf16: the window addressing of the lean
     kernel is unchanged by the split image."""
