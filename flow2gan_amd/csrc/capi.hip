@@ -20,5 +20,5 @@ int f2g_check_launch() {
   return F2G_OK;
 }
 
-extern "C" const char* f2g_version(void) { return "flow2gan_hip 0.2.0 gfx950"; }
+extern "C" const char* f2g_version(void) { return "flow2gan_hip 0.3.0 gfx950"; }
 extern "C" const char* f2g_last_error(void) { return g_err; }

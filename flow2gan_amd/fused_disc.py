@@ -350,6 +350,7 @@ def dft_interleaved(n_fft: int, device):
         wd, _ = dft_matrices(n_fft, device)
         nb = n_fft // 2 + 1
         wi = torch.stack([wd[:nb], wd[nb:]], dim=1).reshape(2 * nb, n_fft).contiguous()
+        wi._f2g_const = True
         _DFT_INT_CACHE[key] = wi
     return _DFT_INT_CACHE[key]
 

@@ -42,6 +42,8 @@ def dft_matrices(n_fft: int, device) -> tuple:
         wi_[-1] = 0.0
         wi = torch.cat([wr, wi_], dim=0).t().contiguous()  # (N, N+2)
         _DFT_CACHE[key] = (wd.float().contiguous().to(device), wi.float().to(device))
+        for t in _DFT_CACHE[key]:
+            t._f2g_const = True   # never written again: operand images of it may be cached (ops.derived)
     return _DFT_CACHE[key]
 
 

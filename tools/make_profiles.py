@@ -32,6 +32,22 @@ stats(f"{G}/prof_serial/p_kernel_stats.csv", f"{P}/{R}_gan_stage2_kernel_stats.t
 stats(f"{G}/prof_lanes/p_kernel_stats.csv", f"{P}/{R}_gan_stage2_kernel_stats_lanes.txt",
       f"# rocprofv3 --kernel-trace --stats -- {CMD}\n"
       "# default mode: launch lanes ON (up to 7 HIP streams): kernel durations overlap and stretch, their sum exceeds the wall time of a step")
+stats(f"{G}/prof_b3/p_kernel_stats.csv", f"{P}/{R}_fast_mode_kernel_stats.txt",
+      f"# F2G_STREAMS=0 rocprofv3 --kernel-trace --stats -- {CMD} --gemm bf16x3\n"
+      "# the same step in the split-bf16 fast mode (pre-split operand images; lean / K-major weight-gradient / direct-conv kernels), launch lanes OFF")
+if os.path.exists(f"{G}/prof_infer/p_kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f"{G}/prof_infer/p_kernel_stats.csv")))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    L = ["# F2G_STREAMS=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --workload infer4 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode --gemm bf16",
+         f"# BASELINE config 2 (4-step inference, B=64, bf16 activations in the blocks): {tot/4e6:.2f} ms of kernel time per 4-step inference (4 in the trace), launch lanes OFF",
+         f"{'kernel':66s} {'calls':>6s} {'total_ms':>9s} {'avg_us':>9s} {'%':>6s}"]
+    for r in rows[:24]:
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Name"]); n = re.sub(r"\(.*", "", n)[:66]
+        L.append(f"{n:66s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:9.1f} {float(r['Percentage']):6.2f}")
+    open(f"{P}/{R}_infer4_bf16_kernel_stats.txt", "w").write("\n".join(L) + "\n")
+for src, dst in (("lean3_bench.txt", "lean3_bench.txt"), ("conv32_b3_bench.txt", "conv32_split_bench.txt")):
+    if os.path.exists(f"{G}/{src}"):
+        open(f"{P}/{R}_{dst}", "w").write(open(f"{G}/{src}").read())
 txt = open(f"{G}/shapes.txt").read().split("\n")
 i = next(k for k, l in enumerate(txt) if l.startswith("form"))
 open(f"{P}/{R}_gemm_shapes_fp32.txt", "w").write(
@@ -42,14 +58,14 @@ res = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     tot = 0.0; n = 0
     for row in csv.DictReader(open(f"{G}/pmcb_{name}/p_counter_collection.csv")):
-        if "gemm_lean_kernel<false>" in row["Kernel_Name"] or "gemm_lean_kernelILb0" in row["Kernel_Name"]:
+        if re.search(r"gemm_lean_kernel<false, \d, 0>", row["Kernel_Name"]):   # exact-fp32 instances
             tot += float(row["Counter_Value"]); n += 1
     res[name] = (tot, n)
 f, nf = res["FETCH_SIZE"]; w, nw = res["WRITE_SIZE"]
 from flow2gan_amd import _lib
 json.dump({"source": "F2G_STREAMS=0 rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py "
-                     "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode; gemm_lean_kernel<false> dispatches (2 steps)",
-           "lib_version": _lib.version(), "kernel": "gemm_lean_kernel<false>",
+                     "--steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode; gemm_lean_kernel<false, EP, 0> dispatches (2 steps)",
+           "lib_version": _lib.version(), "kernel": "gemm_lean_kernel<false, EP, 0> (exact fp32, all epilogue instances)",
            "launches": nf, "fetch_kib_per_launch": f / nf, "write_kib_per_launch": w / nw,
            "hbm_bytes_per_launch_raw": (f / nf + w / nw) * 1024, "hbm_bytes_per_launch_fetch_x2": (2 * f / nf + w / nw) * 1024,
            "note": "gfx950 FETCH_SIZE under-reports wide coalesced reads by up to 2x (MI355X_MICROARCH.md, HBM); both raw and "
