@@ -431,6 +431,161 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_wgrad_kernel(const f2g_conv3
   }
 }
 
+// ---- weight gradient, split-bf16 ---------------------------------------------------------------
+// Same decomposition as conv32_s2_wgrad_kernel (MFMA rows = co, columns = ci, reduction = the pixels
+// of an 8 x 16 output tile; wave w owns taps w, w+8, w+16 over the whole tile and tile row w of taps
+// 24..26), but a bf16 MFMA wants 8 CONSECUTIVE k per lane and k = pixels is the slow axis of both
+// staged operands ([pixel][channel]).  The tile is therefore staged as bf16 planes with 64-byte
+// pixels (hi and lo of the gradient tile and of the two column parities of the input patch, split
+// once while they are staged) and the fragments come from ds_read_b64_tr_b16: a 16-lane group reads
+// 4 pixels x 16 channels and every lane receives the 4 pixels of its channel; two reads = the 8 k of
+// a lane half, a tile row of 16 pixels = one k step.  The four pixels of a read are consecutive
+// columns = 256 contiguous bytes: conflict-free without padding.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_pix8(const unsigned char* p) {   // pixels +0..3 and +4..7
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * 64));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__device__ __forceinline__ void store_split_planes(unsigned char* hi, unsigned char* lo, const float4 v) {
+  float r0, r1, r2, r3, z0, z1;
+  u32x2 h, l;
+  h.x = pack_bf16(v.x, v.y, r0, r1);
+  h.y = pack_bf16(v.z, v.w, r2, r3);
+  l.x = pack_bf16(r0, r1, z0, z1);
+  l.y = pack_bf16(r2, r3, z0, z1);
+  *reinterpret_cast<u32x2*>(hi) = h;
+  *reinterpret_cast<u32x2*>(lo) = l;
+}
+
+constexpr int XPL = 2 * IH * IW * 64;   // bytes of one plane of the input patch (both parities)
+constexpr int GPL = TH * TW * 64;       // bytes of one plane of the gradient tile
+
+__global__ __launch_bounds__(512, 2) void conv32_s2_wgrad3_kernel(const f2g_conv32_desc d, float* gw,
+                                                                  int tiles_h, int tiles_w,
+                                                                  int tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  unsigned char* sm = reinterpret_cast<unsigned char*>(smf);
+  unsigned char* Xh = sm;              // [2 parities][IH][IW] pixels x 32 bf16
+  unsigned char* Xl = sm + XPL;
+  unsigned char* Gh = sm + 2 * XPL;    // [128 px] x 32 bf16
+  unsigned char* Gl = Gh + GPL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int ntiles = d.S * tiles_h * tiles_w;
+  f32x16 acc[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  // transposed-read lane roles: 16-lane group g4 = (channel half, k half); lane i = (pixel i>>2, quad i&3)
+  const int g4 = lane >> 4, i16 = lane & 15;
+  const int kpix = (g4 >> 1) * 8 + (i16 >> 2);             // pixel (tile column) of the first read
+  const int chb = (g4 & 1) * 32 + (i16 & 3) * 8;           // byte offset of this lane's 4 channels
+  int xo[3], xs[3];                                        // patch offsets of the owned / shared taps
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int t = wave + 8 * a;
+    int dh = t / KW, j = t - dh * KW;
+    xo[a] = ((j & 1) * IH * IW + dh * IW + (j >> 1) + kpix) * 64 + chb;
+    t = 24 + a;
+    dh = t / KW;
+    j = t - dh * KW;
+    xs[a] = ((j & 1) * IH * IW + dh * IW + (j >> 1) + kpix) * 64 + chb;
+  }
+  const int go = kpix * 64 + chb;
+  const int t0 = blockIdx.x * tiles_per_block;
+  for (int ti = t0; ti < t0 + tiles_per_block && ti < ntiles; ++ti) {
+    const int s = ti / (tiles_h * tiles_w), rem = ti - s * (tiles_h * tiles_w);
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int h0 = th * TH, w0 = tw * TW;
+    const float* xsrc = d.x + (long long)s * d.x_seq;
+    const float* gsrc = d.y + (long long)s * d.y_seq;
+    __syncthreads();   // the previous tile's readers are done
+    const int x0 = 2 * w0 - (KW - 1) / 2;
+    for (int i = tid; i < IH * (2 * IW - 1) * (C / 4); i += 512) {
+      const int c4 = i & 7;
+      const int px = i >> 3;
+      const int r = px / (2 * IW - 1), xr = px - r * (2 * IW - 1);
+      const int h = h0 - 1 + r, x = x0 + xr;
+      const bool ok = h >= 0 && h < d.H && x >= 0 && x < d.Win;
+      const float* p = ok ? xsrc + (long long)h * d.x_line + (long long)x * C + c4 * 4 : c32_zero;
+      const int off = ((xr & 1) * IH * IW + r * IW + (xr >> 1)) * 64 + c4 * 8;
+      store_split_planes(Xh + off, Xl + off, *reinterpret_cast<const float4*>(p));
+    }
+    if (tid < IH * 8) {   // the odd parity has one column less: keep its last column defined
+      const int r = tid >> 3, c4 = tid & 7;
+      const int off = (IH * IW + r * IW + IW - 1) * 64 + c4 * 8;
+      *reinterpret_cast<u32x2*>(Xh + off) = u32x2{0u, 0u};
+      *reinterpret_cast<u32x2*>(Xl + off) = u32x2{0u, 0u};
+    }
+    for (int i = tid; i < TH * TW * (C / 4); i += 512) {
+      const int c4 = i & 7, px = i >> 3;
+      const int h = h0 + (px >> 4), w = w0 + (px & 15);
+      const bool ok = h < d.H && w < d.Wout;
+      const float* p = ok ? gsrc + (long long)h * d.y_line + (long long)w * C + c4 * 4 : c32_zero;
+      store_split_planes(Gh + px * 64 + c4 * 8, Gl + px * 64 + c4 * 8, *reinterpret_cast<const float4*>(p));
+    }
+    __syncthreads();
+    // owned taps: the 8 tile rows = 8 k steps of 16 pixels
+#pragma unroll
+    for (int row = 0; row < TH; ++row) {
+      const bf16x8 ah = tr_pix8(Gh + go + row * 16 * 64), al = tr_pix8(Gl + go + row * 16 * 64);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const bf16x8 bh = tr_pix8(Xh + xo[q] + row * IW * 64), bl = tr_pix8(Xl + xo[q] + row * IW * 64);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[q], 0, 0, 0);
+      }
+    }
+    // taps 24..26: this wave's tile row
+    {
+      const int row = wave;
+      const bf16x8 ah = tr_pix8(Gh + go + row * 16 * 64), al = tr_pix8(Gl + go + row * 16 * 64);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const bf16x8 bh = tr_pix8(Xh + xs[q] + row * IW * 64), bl = tr_pix8(Xl + xs[q] + row * IW * 64);
+        acc[3 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[3 + q], 0, 0, 0);
+        acc[3 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[3 + q], 0, 0, 0);
+        acc[3 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[3 + q], 0, 0, 0);
+      }
+    }
+  }
+  // ---- flush (as the fp32 kernel)
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int t = wave + 8 * q;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      atomicAdd(gw + co * (KH * KW * C) + t * C + li, acc[q][e]);
+    }
+  }
+  float* red = smf;   // [8 waves][16][64]
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[3 + q][e];
+    __syncthreads();
+    if (wave == q) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += red[(w8 * 16 + e) * 64 + lane];
+        const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        atomicAdd(gw + co * (KH * KW * C) + (24 + q) * C + li, v);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
@@ -492,6 +647,23 @@ extern "C" int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stre
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->y) || (d->x_line & 3) || (d->x_seq & 3) || (d->y_line & 3) || (d->y_seq & 3))
     return F2G_EINVAL;
+  const int tiles_h = (d->H + TH - 1) / TH, tiles_w = (d->Wout + TW - 1) / TW;
+  const int ntiles = d->S * tiles_h * tiles_w;
+  int per = (ntiles + 511) / 512;   // <= 512 blocks (two per CU): bounds the atomics
+  if (per < 1) per = 1;
+  if (d->precision == 1) {   // split-bf16 (the operands are split while they are staged)
+    const size_t smem3 = (size_t)(2 * XPL + 2 * GPL) > (size_t)8 * 16 * 64 * 4 ? (size_t)(2 * XPL + 2 * GPL)
+                                                                              : (size_t)8 * 16 * 64 * 4;
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_wgrad3_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+      attr3 = true;
+    }
+    hipLaunchKernelGGL(conv32_s2_wgrad3_kernel, dim3((ntiles + per - 1) / per), dim3(512), smem3,
+                       (hipStream_t)stream, *d, gw, tiles_h, tiles_w, per);
+    return f2g_check_launch();
+  }
   const size_t smem = (size_t)(2 * SUB + GT) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -499,10 +671,6 @@ extern "C" int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stre
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  const int tiles_h = (d->H + TH - 1) / TH, tiles_w = (d->Wout + TW - 1) / TW;
-  const int ntiles = d->S * tiles_h * tiles_w;
-  int per = (ntiles + 511) / 512;   // <= 512 blocks (two per CU): bounds the atomics
-  if (per < 1) per = 1;
   hipLaunchKernelGGL(conv32_s2_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(512), smem,
                      (hipStream_t)stream, *d, gw, tiles_h, tiles_w, per);
   return f2g_check_launch();

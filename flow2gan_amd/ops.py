@@ -450,6 +450,8 @@ def conv32_s2_wgrad(x, g, S: int, H: int, Win: int, Wout: int, gw):
     d.S, d.H, d.Win, d.Wout = S, H, Win, Wout
     d.w, d.bias, d.lrelu_slope = None, None, 0.0
     d.y, d.y_seq, d.y_line = ptr(g), H * Wout * 32, Wout * 32
+    if GEMM_PRECISION == 1 and CONV32_SPLIT:
+        d.precision = 1
     if GEMM_TIMER is not None:
         GEMM_TIMER.time(lambda: call("f2g_conv32_s2_wgrad", C.byref(d), ptr(gw)),
                         2.0 * S * H * Wout * 32 * 27 * 32, (2, 32, 27 * 32, S * H * Wout))

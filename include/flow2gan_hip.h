@@ -416,7 +416,8 @@ typedef struct {
   float lrelu_slope;  /* 0 = none */
   /* fwd / dgrad: 0 = exact fp32 MFMA; 1 = split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulation):
    * `w` is then the f2g_split_bf16 image of the same weight matrix, the patch is split while it
-   * is staged in LDS.  wgrad ignores it (always exact fp32). */
+   * is staged in LDS; wgrad splits both staged operands (bf16 planes read with
+   * ds_read_b64_tr_b16: its reduction runs over pixels). */
   int32_t precision;
   float* y;
   int64_t y_seq, y_line;

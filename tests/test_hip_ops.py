@@ -681,7 +681,7 @@ def test_direct_conv32_dgrad_matches_autograd(ops, S, H, Win):
     close(gx, ref, name="conv32 dgrad")
 
 
-@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 21, 51), (1, 5, 2), (2, 8, 64)])
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 21, 51), (1, 5, 2), (2, 8, 64), (5, 17, 26)])
 def test_direct_conv32_split_bf16(ops, S, H, Win):
     """Split-bf16 instances of the direct MRD conv (forward and data gradient): patch split while it
     is staged, pre-split weight tiles, 3 bf16 MFMAs per product -- ~2^-16 per product."""
@@ -703,8 +703,14 @@ def test_direct_conv32_split_bf16(ops, S, H, Win):
         ops.conv32_s2_fwd(g(x), S, H, Win, Wout, g(wp), g(b), 0.1, y)
         gx = torch.full((S * H * Win, 32), 7.0, device=DEV)
         ops.conv32_s2_dgrad(g(gy), S, H, Win, Wout, g(wT), gx)
+        gw = torch.zeros(32, 27 * 32, device=DEV)
+        ops.conv32_s2_wgrad(g(x), g(gy), S, H, Win, Wout, gw)
     finally:
         ops.GEMM_PRECISION = was
+    wd = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd.detach(), wd, None, stride=(1, 2), padding=(1, 4)).backward(
+        gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
+    close(gw, wd.grad.permute(0, 2, 3, 1).reshape(32, 27 * 32), rtol=1e-4, name="conv32 wgrad split-bf16")
     close(y, ref.detach(), rtol=3e-5, name="conv32 split-bf16")
     close(gx, xd.grad.permute(0, 2, 3, 1).reshape(S * H * Win, 32), rtol=3e-5, name="conv32 dgrad split-bf16")
 

@@ -18,12 +18,15 @@ for S, H, Win in [(128, 47, 410), (128, 94, 205), (128, 188, 103), (128, 47, 205
     wT = torch.nn.Parameter(torch.randn(27, 32, 32, device=dev) * 0.05)
     b = torch.randn(32, device=dev)
     y = torch.empty(S * H * Wout, 32, device=dev); gx = torch.empty(S * H * Win, 32, device=dev)
+    gwb = torch.zeros(32, 27 * 32, device=dev)
     fl = 2.0 * S * H * Wout * 32 * 27 * 32
     r = []
     for mode in ("fp32", "bf16x3"):
         ops.set_gemm_precision(mode)
         r.append(timeit(lambda: ops.conv32_s2_fwd(x, S, H, Win, Wout, wp, b, 0.1, y)))
         r.append(timeit(lambda: ops.conv32_s2_dgrad(gy, S, H, Win, Wout, wT, gx)))
+        r.append(timeit(lambda: ops.conv32_s2_wgrad(x, gy, S, H, Win, Wout, gwb)))
     ops.set_gemm_precision("fp32")
-    print(f"S={S} H={H} Win={Win}: fwd fp32 {fl/r[0]/1e12:6.1f} TF ({r[0]*1e6:5.0f} us) split {fl/r[2]/1e12:6.1f} TF ({r[2]*1e6:5.0f} us) | "
-          f"dgrad fp32 {fl/r[1]/1e12:6.1f} TF ({r[1]*1e6:5.0f} us) split {fl/r[3]/1e12:6.1f} TF ({r[3]*1e6:5.0f} us)", flush=True)
+    print(f"S={S} H={H} Win={Win}: fwd fp32 {fl/r[0]/1e12:6.1f} TF ({r[0]*1e6:5.0f} us) split {fl/r[3]/1e12:6.1f} TF ({r[3]*1e6:5.0f} us) | "
+          f"dgrad fp32 {fl/r[1]/1e12:6.1f} TF ({r[1]*1e6:5.0f} us) split {fl/r[4]/1e12:6.1f} TF ({r[4]*1e6:5.0f} us) | "
+          f"wgrad fp32 {fl/r[2]/1e12:6.1f} TF ({r[2]*1e6:5.0f} us) split {fl/r[5]/1e12:6.1f} TF ({r[5]*1e6:5.0f} us)", flush=True)
