@@ -932,13 +932,19 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r,
 // 3 plain bf16 over TRUE bf16 tensors (f2g_to_bf16 images / bf16 producers: 2 bytes per element,
 // operand strides in elements): the same 128-byte staged row now holds 64 k, so a slab carries
 // twice the reduction for the same load, LDS and barrier work (16 MFMAs per wave and slab).
-template <bool SK, int EP, int PM>
-__global__ __launch_bounds__(256, 2)
+// WM: wave rows of the block = 2 (128 x 128 tile, 4 waves, two blocks per CU) or 4 (256 x 128, 8
+// waves, one block per CU).  The bf16 instances are bound by L2 -> CU operand delivery (PMC: 13 TB/s
+// of L2 reads on the 1024-channel MPD layer at 128 x 128 = 32 FLOP per byte): the taller tile
+// moves a quarter less per FLOP with the same waves per SIMD.
+template <bool SK, int EP, int PM, int WM = 2>
+__global__ __launch_bounds__(WM * 128, 4 / WM)
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
   constexpr bool P3 = PM == 1 || PM == 2, HI = PM == 2, BF = PM == 3;
   constexpr int BKE = BF ? 64 : BK;   // elements per slab
   constexpr int ES = BF ? 2 : 4;      // bytes per element
-  constexpr int BM = 128, BN = 128, TSZ = BM * LDR;
+  constexpr int BM = 64 * WM, BN = 128, TSZ = BM * LDR, TSB = BN * LDR;
+  constexpr int RS = 16 * WM;         // rows staged per pass of the block (32 or 64)
+  constexpr int QB = BN / RS;         // passes over the B tile (4 or 2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
@@ -946,7 +952,8 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   // filled with 8-byte stores, served 16 lanes = two rows at a time over 32 banks: rows r and r + 4
   // (4 x 36 dwords = 16 mod 32) share no bank, rows r and r + 1 would share 12 of 16.
   const int ch = tid & 7;
-  const int rr = P3 ? (((tid >> 4) & 3) + 8 * (tid >> 6) + 4 * ((tid >> 3) & 1)) : (tid >> 3);
+  const int t8 = tid & 255;
+  const int rr = (P3 ? (((t8 >> 4) & 3) + 8 * (t8 >> 6) + 4 * ((t8 >> 3) & 1)) : (t8 >> 3)) + 32 * (tid >> 8);
   __amdgpu_buffer_rsrc_t ra =
       __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, 0x80000000u, 0x00020000);
   // B is a plain [n][k] matrix: the resource ends with its last row, so the rows of a partial
@@ -954,15 +961,18 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   // rows (their distance, 32 rows, is uniform and rides in the scalar offset)
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
       (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * ES), 0x00020000);
-  const int qstepB = (int)(32 * d.B.seq_stride * ES);
+  const int qstepB = (int)(RS * d.B.seq_stride * ES);
   // scalar K walk of A: segments of `seglen` columns, `line_stride` floats apart
   const int seglen = d.A.seglen < d.A.cols ? d.A.seglen : d.A.cols;
   const int spseg = seglen / BKE;                                 // slabs per segment
   const int segjump = (int)((d.A.line_stride - seglen) * ES);     // bytes skipped at a segment end
+  // LDS: [A buffer 0 | A buffer 1 | B buffer 0 | B buffer 1]; a slab offset `bo` (0 / TSZ) selects the
+  // A buffer, the B buffer of the same index lies bo / TSZ * TSB further on
   float* wA = smem + rr * LDR + ch * (P3 ? 2 : 4);
   float* wB = smem + 2 * TSZ + rr * LDR + ch * (P3 ? 2 : 4);
   const float* rA = smem + (wm * 64 + li) * LDR + h * ((P3 || BF) ? 4 : 16);
   const float* rB = smem + 2 * TSZ + (wn * 64 + li) * LDR + h * ((P3 || BF) ? 4 : 16);
+  auto bofB = [](int bo) { return WM == 2 ? bo : (bo ? TSB : 0); };
 
   // ---- work of this block.  Classic: one tile (blockIdx.x/y), K chunk blockIdx.z.  Stream-K
   // (upb > 0): the (tile, slab) units of the whole problem are numbered tile-major and every
@@ -1021,7 +1031,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
     unsigned offA[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      offA[q] = lean_row_offset(d.A, m0 + rr + 32 * q, ES);
+      offA[q] = lean_row_offset(d.A, m0 + rr + RS * q, ES);
       if (offA[q] != 0x80000000u) offA[q] += ch * 16;
     }
     const unsigned offB = (unsigned)((long long)(n0 + rr) * d.B.seq_stride * ES) + ch * 16;
@@ -1034,22 +1044,25 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         la[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q], soa, 0);
-        lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB, sob + q * qstepB, 0);
+        if (q < QB) lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB, sob + q * qstepB, 0);
       }
     };
     auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {
+      const int bb = bofB(bufoff);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if constexpr (P3) {
-          *reinterpret_cast<u32x2*>(wA + bufoff + q * 32 * LDR) = u32x2{la[q].x, la[q].y};
+          *reinterpret_cast<u32x2*>(wA + bufoff + q * RS * LDR) = u32x2{la[q].x, la[q].y};
           if constexpr (!HI)
-            *reinterpret_cast<u32x2*>(wA + bufoff + q * 32 * LDR + 16) = u32x2{la[q].z, la[q].w};
-          *reinterpret_cast<u32x2*>(wB + bufoff + q * 32 * LDR) = u32x2{lb[q].x, lb[q].y};
-          if constexpr (!HI)
-            *reinterpret_cast<u32x2*>(wB + bufoff + q * 32 * LDR + 16) = u32x2{lb[q].z, lb[q].w};
+            *reinterpret_cast<u32x2*>(wA + bufoff + q * RS * LDR + 16) = u32x2{la[q].z, la[q].w};
+          if (q < QB) {
+            *reinterpret_cast<u32x2*>(wB + bb + q * RS * LDR) = u32x2{lb[q].x, lb[q].y};
+            if constexpr (!HI)
+              *reinterpret_cast<u32x2*>(wB + bb + q * RS * LDR + 16) = u32x2{lb[q].z, lb[q].w};
+          }
         } else {
-          *reinterpret_cast<u32x4*>(wA + bufoff + q * 32 * LDR) = la[q];
-          *reinterpret_cast<u32x4*>(wB + bufoff + q * 32 * LDR) = lb[q];
+          *reinterpret_cast<u32x4*>(wA + bufoff + q * RS * LDR) = la[q];
+          if (q < QB) *reinterpret_cast<u32x4*>(wB + bb + q * RS * LDR) = lb[q];
         }
       }
     };
@@ -1062,7 +1075,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           a[mi] = *reinterpret_cast<const float4*>(rA + bufoff + mi * 32 * LDR + s4 * 4);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          b[ni] = *reinterpret_cast<const float4*>(rB + bufoff + ni * 32 * LDR + s4 * 4);
+          b[ni] = *reinterpret_cast<const float4*>(rB + bofB(bufoff) + ni * 32 * LDR + s4 * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1108,17 +1121,17 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               fa[2 * j + i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + (2 * ks + j) * 8);
-              fb[2 * j + i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + (2 * ks + j) * 8);
+              fb[2 * j + i] = *reinterpret_cast<const bf16x8*>(rB + bofB(off) + i * 32 * LDR + (2 * ks + j) * 8);
             }
           return;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           fa[i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8);
-          fb[i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + ks * 8);
+          fb[i] = *reinterpret_cast<const bf16x8*>(rB + bofB(off) + i * 32 * LDR + ks * 8);
           if constexpr (!HI) {
             fa[2 + i] = *reinterpret_cast<const bf16x8*>(rA + off + i * 32 * LDR + ks * 8 + 16);
-            fb[2 + i] = *reinterpret_cast<const bf16x8*>(rB + off + i * 32 * LDR + ks * 8 + 16);
+            fb[2 + i] = *reinterpret_cast<const bf16x8*>(rB + bofB(off) + i * 32 * LDR + ks * 8 + 16);
           }
         }
       };
@@ -1156,14 +1169,16 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         lstore(nxtoff, wa, wb);
         // issue order: fragments, the loads of the slab after next, one LDS store behind each of
         // the first MFMAs
+        constexpr int NM = HI ? 4 : (BF ? 8 : 12);        // MFMAs per half slab
+        constexpr int NW = 4 + QB;                        // LDS store instructions per slab
+        constexpr int WPM = (NW + NM - 1) / NM;
         __builtin_amdgcn_sched_group_barrier(0x100, HI ? 4 : 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 4 + QB, 0);
 #pragma unroll
-        for (int i = 0; i < (HI ? 4 : 8); ++i) {
+        for (int i = 0; i < NM; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x200, HI ? 2 : 1, 0);
+          if (i * WPM < NW) __builtin_amdgcn_sched_group_barrier(0x200, WPM, 0);
         }
-        if constexpr (PM == 1) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -1434,10 +1449,19 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   // split = 2 -> true bf16 tensors (precision 2 only)
   const int pm = d.A.split == 2 ? 3 : (d.precision == 1 ? 1 : (d.precision == 2 ? 2 : 0));
   const int bk = pm == 3 ? 64 : BK;
-  constexpr size_t smem = (size_t)4 * 128 * LDR * sizeof(float);
   int kchunk = ((K + split - 1) / split + bk - 1) / bk * bk;
   int zs = (K + kchunk - 1) / kchunk;
-  dim3 grid((M + 127) / 128, (N + 127) / 128, zs);
+  // 256 x 128 tiles (8 waves) for the bf16 instances when the taller grid still fills the chip
+  // and the reduction is long enough to amortise the larger prologue / epilogue (measured: +11 % on
+  // the 1024-channel MPD layers, -7 % at K = 384 / 512)
+  // (F2G_LEAN_TALL: 0 never, 1 when K >= 640 and there are >= 400 tall tiles, 2 whenever possible)
+  static const int tall_mode = getenv("F2G_LEAN_TALL") ? atoi(getenv("F2G_LEAN_TALL")) : 1;
+  const long long tall_tiles = (long long)((M + 255) / 256) * ((N + 127) / 128);
+  const bool tall = (pm == 1 || pm == 3) && upb == 0 && zs == 1 && tall_mode > 0 &&
+                    (tall_mode > 1 || (tall_tiles >= 400 && K >= 640));
+  const int bm = tall ? 256 : 128;
+  const size_t smem = (size_t)(2 * bm + 2 * 128) * LDR * sizeof(float);
+  dim3 grid((M + bm - 1) / bm, (N + 127) / 128, zs);
   if (grid.x == 0 || grid.y == 0) return F2G_OK;
   if (upb > 0) {
     const long long total = (long long)grid.x * grid.y * (K / bk);
@@ -1480,7 +1504,17 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 3>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<true, 3, 3>)};
     for (const void* k : ks)
-      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * LDR * 4);
+    const void* kt[8] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 1, 4>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 1, 4>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 1, 4>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 1, 4>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 3, 4>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 3, 4>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 3, 4>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 3, 4>)};
+    for (const void* k : kt)
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 256 + 2 * 128) * LDR * 4);
     attr_done = true;
   }
   g_last_path = upb > 0 ? 2 : 1;
@@ -1499,12 +1533,28 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 0>), grid, dim3(256), smem, st, d, M, N, K,  \
                          kchunk, upb);                                                            \
   } while (0)
+#define F2G_LEAN_T(EPV)                                                                           \
+  do {                                                                                            \
+    if (pm == 1)                                                                                  \
+      hipLaunchKernelGGL((gemm_lean_kernel<false, EPV, 1, 4>), grid, dim3(512), smem, st, d, M,   \
+                         N, K, kchunk, upb);                                                      \
+    else                                                                                          \
+      hipLaunchKernelGGL((gemm_lean_kernel<false, EPV, 3, 4>), grid, dim3(512), smem, st, d, M,   \
+                         N, K, kchunk, upb);                                                      \
+  } while (0)
+  if (tall) {
+    if (ep == 0) F2G_LEAN_T(0);
+    else if (ep == 1) F2G_LEAN_T(1);
+    else if (ep == 2) F2G_LEAN_T(2);
+    else F2G_LEAN_T(3);
+  } else
   if (upb > 0) F2G_LEAN(true, 3);
   else if (ep == 0) F2G_LEAN(false, 0);
   else if (ep == 1) F2G_LEAN(false, 1);
   else if (ep == 2) F2G_LEAN(false, 2);
   else F2G_LEAN(false, 3);
 #undef F2G_LEAN
+#undef F2G_LEAN_T
   return f2g_check_launch();
 }
 
