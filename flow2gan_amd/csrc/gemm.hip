@@ -1730,12 +1730,175 @@ void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
 }
 
+// ---- lean weight-gradient kernel, exact fp32 ---------------------------------------------------
+// Same operands as gemm_leanw3_kernel (A plain R x M, B plain or an unbounded 1-D window), fp32 MFMA.
+// v_mfma_f32_32x32x2_f32 takes ONE k per lane half, so K-major tiles are its natural layout: the
+// slab [32 k][128 m] is stored as it arrives (ds_write_b128) and lane (m = li, k = 2s + hh) reads
+// single floats, 32 consecutive ones per lane half: conflict-free ds_read_b32 at per-lane base +
+// immediate offsets.  As in the forward lean kernel nothing in the K loop touches the vector ALU:
+// the K advance of both operands is scalar.  For a window operand the slab's first row (sequence,
+// position) is walked by SALU and the rows of a slab add a per-thread constant; only a slab that
+// straddles a sequence end (or starts before the buffer) pays a few VALU instructions to redirect
+// the rows behind the boundary.
+template <bool BWIN>
+__global__ __launch_bounds__(256, 2)
+void gemm_leanw_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
+  constexpr int TP = 32 * 128;            // floats of one operand tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [buf][A tile | B tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(128, 128, m0, n0);
+  const int kbeg = blockIdx.z * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+  if (nt <= 0) return;
+  const int rid = tid >> 5, c = tid & 31;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.A.base, 0, (unsigned)((long long)K * d.A.seq_stride * 4), 0x00020000);
+  const long long b_bytes = BWIN ? (long long)(d.B.rows / d.B.P0) * d.B.seq_stride * 4
+                                 : (long long)K * d.B.seq_stride * 4;
+  __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)b_bytes, 0x00020000);
+  const long long rowB = BWIN ? (long long)d.B.step0 * d.B.unit * 4 : d.B.seq_stride * 4;   // bytes per row
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    offA[q] = (unsigned)(((long long)(rid + 8 * q) * d.A.seq_stride + m0 + 4 * c) * 4);
+    offB[q] = (unsigned)((long long)(rid + 8 * q) * rowB + (n0 + 4 * c) * 4);
+  }
+  const int stepA = (int)(BK * d.A.seq_stride * 4);
+  int ka = (int)((long long)kbeg * d.A.seq_stride * 4);
+  const int ka0 = ka;
+  // B: scalar byte offset of the slab's first row.  Window operand: (sequence sq, position p0)
+  int sq = 0, p0 = 0;
+  long long kb = (long long)kbeg * d.B.seq_stride * 4;
+  const int wrapjump = BWIN ? (int)((d.B.seq_stride - (long long)d.B.P0 * d.B.step0 * d.B.unit) * 4) : 0;
+  if (BWIN) {
+    sq = kbeg / d.B.P0;
+    p0 = kbeg - sq * d.B.P0;
+    kb = ((long long)sq * d.B.seq_stride + (long long)(p0 * d.B.step0 - d.B.pad0) * d.B.unit) * 4;
+  }
+  const long long kb_first = kb;
+  const int p_first = p0;
+  float* wA = smem + rid * 128 + c * 4;
+  float* wB = smem + TP + rid * 128 + c * 4;
+  const float* rA = smem + h * 128 + wm * 64 + li;
+  const float* rB = smem + TP + h * 128 + wn * 64 + li;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  auto gload = [&](int soa, long long sob, int pp, u32x4 (&la)[4], u32x4 (&lb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) la[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q], soa, 0);
+    if (BWIN && (pp + BK > d.B.P0 || sob < 0 || sob + 32 * rowB + 512 > 0x7fffffffll)) {
+      // (rare, uniform) the slab straddles a sequence end or touches the buffer's ends: per-row offsets
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = rid + 8 * q;
+        long long off = sob + (long long)offB[q] + (pp + r >= d.B.P0 ? wrapjump : 0);
+        if (pp + r >= 2 * d.B.P0) off = -1;   // (P0 >= 32 is required: at most one wrap; defensive)
+        const unsigned vo = (off >= 0 && off < b_bytes) ? (unsigned)off : 0x80000000u;
+        lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, vo, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB[q], (int)sob, 0);
+    }
+  };
+  auto advance = [&]() {
+    ka += stepA;
+    if (BWIN) {
+      p0 += BK;
+      kb += BK * rowB;
+      if (p0 >= d.B.P0) {
+        p0 -= d.B.P0;
+        kb += wrapjump;
+      }
+    } else {
+      kb += BK * rowB;
+    }
+  };
+  auto lstore = [&](int bufoff, const u32x4 (&la)[4], const u32x4 (&lb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<u32x4*>(wA + bufoff + q * 8 * 128) = la[q];
+      *reinterpret_cast<u32x4*>(wB + bufoff + q * 8 * 128) = lb[q];
+    }
+  };
+  auto mfma_slab = [&](int bufoff) {
+    // fragments one k pair ahead of the MFMAs that use them (an LDS round trip is longer than one
+    // MFMA), issue order pinned: 4 reads, then {4 MFMA, 4 reads} per k pair
+    float a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[0][i] = rA[bufoff + i * 32];
+      b[0][i] = rB[bufoff + i * 32];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {   // k = 2*s2 + h
+      const int cu = s2 & 1, nx = cu ^ 1;
+      if (s2 + 1 < 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[nx][i] = rA[bufoff + (s2 + 1) * 256 + i * 32];
+          b[nx][i] = rB[bufoff + (s2 + 1) * 256 + i * 32];
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cu][mi], b[cu][ni], acc[mi][ni], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      if (s2 + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  };
+  constexpr int BUFF = 2 * TP;
+  {
+    u32x4 la[4], lb[4];
+    gload(ka, kb, p0, la, lb);
+    lstore(0, la, lb);
+  }
+  __syncthreads();
+  auto step = [&](int t, int curoff, int nxtoff) {
+    u32x4 la[4], lb[4];
+    advance();
+    const bool again = t + 1 < nt;   // the last iteration re-reads the first slab (never used)
+    gload(again ? ka : ka0, again ? kb : kb_first, again ? p0 : p_first, la, lb);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_slab(curoff);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(nxtoff, la, lb);
+    __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    step(t, 0, BUFF);
+    step(t + 1, BUFF, 0);
+  }
+  if (t < nt) step(t, 0, BUFF);
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
+}
+
 // form 2 on the kernel above: split-bf16 with both operands pre-split, whole 128 x 128 tiles,
 // A a plain matrix, B plain or an `unbounded` single-segment 1-D window
 inline bool leanw_ok(const f2g_gemm_desc& d) {
   const f2g_operand& A = d.A;
   const f2g_operand& B = d.B;
   if (d.form != 2 || A.rows != B.rows || A.rows <= 0) return false;
+  if (!host_plain(B) && B.P0 < 32) return false;   // a slab crosses at most one sequence end
   if (!host_plain(A) || A.alpha || B.alpha || B.reflect || B.lrelu_src) return false;
   if (A.cols % 128 || B.cols % 128 || !al16(A.base) || !al16(B.base)) return false;
   if ((A.seq_stride & 3) || (B.seq_stride & 3)) return false;
@@ -1744,6 +1907,27 @@ inline bool leanw_ok(const f2g_gemm_desc& d) {
   if (!B.unbounded || B.P1 != 1 || B.P0 < 1 || B.rows % B.P0 || B.seglen < B.cols) return false;
   if ((((long long)B.step0 * B.unit) & 3) || (((long long)B.pad0 * B.unit) & 3)) return false;
   return (long long)(B.rows / B.P0) * B.seq_stride * 4 < 0x7ff00000ll;
+}
+
+int launch_leanw(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+  constexpr size_t smem = 2 * 2 * 32 * 128 * sizeof(float);
+  int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
+  const int zs = (K + kchunk - 1) / kchunk;
+  dim3 grid(M / 128, N / 128, zs);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  g_last_path = 1;
+  if (host_plain(d.B))
+    hipLaunchKernelGGL(gemm_leanw_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  else
+    hipLaunchKernelGGL(gemm_leanw_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  return f2g_check_launch();
 }
 
 int launch_leanw3(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
@@ -1947,6 +2131,15 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
       if (!(d.precision == 1 && d.A.split && d.B.split && lean_on && leanw_ok(d))) return F2G_EINVAL;
       return launch_leanw3(d, M, N, K, split, st);
+    }
+    {   // exact fp32: the K-major lean kernel where its shape conditions hold.  Opt-in
+      // (F2G_LEAN_WGRAD=1): measured 115 -> 118-121 TFLOP/s on the MPD weight gradients, 92 -> 84 on
+      // the 6016-row generator ones, nothing on the laned step (254.2 vs 254.4 ms) -- its single-float
+      // fragments at 1 KB row pitch cost the compiler one address VALU per ds_read2 in half of the
+      // unrolled iterations, which is exactly what the kernel was written to avoid.
+      static const bool leanw_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) &&
+                                   (getenv("F2G_LEAN_WGRAD") && atoi(getenv("F2G_LEAN_WGRAD")) != 0);
+      if (leanw_on && d.precision == 0 && d.E.atomic && leanw_ok(d)) return launch_leanw(d, M, N, K, split, st);
     }
     int am = op_mode(d.A, false), bm = op_mode(d.B, false);
     // split-K chunks are multiples of BK, so PF only needs the total extent % BK == 0

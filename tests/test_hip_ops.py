@@ -120,26 +120,37 @@ def test_gemm_split_bf16_on_the_lean_kernel(ops, R, K, N):
         ops.GEMM_PRECISION = was
 
 
+def _lean_wgrad_expected(mode):
+    # the exact-fp32 K-major kernel is opt-in (F2G_LEAN_WGRAD=1); the split-bf16 one is the default
+    import os
+    return 1 if (mode == "bf16x3" or os.environ.get("F2G_LEAN_WGRAD", "0") not in ("", "0")) else 0
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("R,M,N", [(3000, 128, 256), (777, 384, 128), (64, 256, 1152), (24064, 128, 128)])
-def test_wgrad_split_bf16_transposing_kernel(ops, R, M, N):
-    """Weight gradient in split-bf16 on the K-major kernel (operands transposed by the LDS
-    transpose read): g[m, n] += sum_r dY[r, m] X[r, n], atomic split-K onto an initialised output."""
+def test_wgrad_k_major_lean_kernels(ops, R, M, N, mode):
+    """Weight gradient on the K-major lean kernels (exact fp32: single-float fragments; split-bf16:
+    operands transposed by the LDS transpose read): g[m, n] += sum_r dY[r, m] X[r, n], atomic
+    split-K onto an initialised output, partial last slab."""
     dY, X, g0 = rnd(R, M, seed=1), rnd(R, N, seed=2), rnd(M, N, seed=3)
     was = ops.GEMM_PRECISION
-    ops.set_gemm_precision("bf16x3")
+    ops.set_gemm_precision(mode)
     try:
         out = g(g0)
         ops.wgrad(g(dY), M, M, ops.mat(g(X)), out)
-        assert ops.L.lib.f2g_gemm_last_path() == 1, "split-bf16 wgrad did not take the lean kernel"
+        assert ops.L.lib.f2g_gemm_last_path() == _lean_wgrad_expected(mode), "unexpected wgrad kernel family"
     finally:
         ops.GEMM_PRECISION = was
-    close(out, g0.double() + dY.double().t() @ X.double(), rtol=5e-5, name="leanw3")
+    close(out, g0.double() + dY.double().t() @ X.double(), rtol=5e-5, name="leanw")
 
 
-def test_wgrad_split_bf16_unbounded_windows(ops):
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("S,Hin,stv", [(5, 50, 3), (7, 131, 1), (3, 400, 3)])
+def test_wgrad_unbounded_windows(ops, mode, S, Hin, stv):
     """MPD-style weight gradient: X = (5,1)-tap windows over a halo layout, read past the sequence
-    ends where the gradient map's halo rows are zero (f2g_operand.unbounded)."""
-    S, Hin, Cin, Cout, stv, HALO = 5, 50, 128, 256, 3, 2
+    ends where the gradient map's halo rows are zero (f2g_operand.unbounded); slabs that straddle
+    sequence ends, the first rows before the buffer, the last ones behind it."""
+    Cin, Cout, HALO = 128, 256, 2
     Hout = (Hin + 4 - 5) // stv + 1
     Hp = Hout + 2 * HALO
     x = torch.zeros(S, Hin + 2 * HALO, Cin)
@@ -147,13 +158,14 @@ def test_wgrad_split_bf16_unbounded_windows(ops):
     gy = torch.zeros(S, Hp, Cout)
     gy[:, HALO:HALO + Hout] = rnd(S, Hout, Cout, seed=2)
     was = ops.GEMM_PRECISION
-    ops.set_gemm_precision("bf16x3")
+    ops.set_gemm_precision(mode)
     try:
         out = torch.zeros(Cout, 5 * Cin, device=DEV)
         X = ops.win1d(g(x), S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5, unbounded=True)
         assert X.unbounded == 1
         ops.wgrad(g(gy).reshape(S * Hp, Cout), Cout, Cout, X, out)
-        assert ops.L.lib.f2g_gemm_last_path() == 1
+        # (sequences shorter than a slab stay on the generic kernel)
+        assert ops.L.lib.f2g_gemm_last_path() == (_lean_wgrad_expected(mode) if Hp >= 32 else 0)
     finally:
         ops.GEMM_PRECISION = was
     # conv1d(k=5, stride, pad=2) over the un-haloed input: output row o reads input rows o*stv-2 .. +2
