@@ -1898,7 +1898,6 @@ inline bool leanw_ok(const f2g_gemm_desc& d) {
   const f2g_operand& A = d.A;
   const f2g_operand& B = d.B;
   if (d.form != 2 || A.rows != B.rows || A.rows <= 0) return false;
-  if (!host_plain(B) && B.P0 < 32) return false;   // a slab crosses at most one sequence end
   if (!host_plain(A) || A.alpha || B.alpha || B.reflect || B.lrelu_src) return false;
   if (A.cols % 128 || B.cols % 128 || !al16(A.base) || !al16(B.base)) return false;
   if ((A.seq_stride & 3) || (B.seq_stride & 3)) return false;
@@ -2139,7 +2138,9 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       // unrolled iterations, which is exactly what the kernel was written to avoid.
       static const bool leanw_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) &&
                                    (getenv("F2G_LEAN_WGRAD") && atoi(getenv("F2G_LEAN_WGRAD")) != 0);
-      if (leanw_on && d.precision == 0 && d.E.atomic && leanw_ok(d)) return launch_leanw(d, M, N, K, split, st);
+      // (its scalar row walk assumes that a slab crosses at most one sequence end)
+      if (leanw_on && d.precision == 0 && d.E.atomic && leanw_ok(d) && (host_plain(d.B) || d.B.P0 >= 32))
+        return launch_leanw(d, M, N, K, split, st);
     }
     int am = op_mode(d.A, false), bm = op_mode(d.B, false);
     // split-K chunks are multiples of BK, so PF only needs the total extent % BK == 0
