@@ -1833,37 +1833,58 @@ void gemm_leanw_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
       *reinterpret_cast<u32x4*>(wB + bufoff + q * 8 * 128) = lb[q];
     }
   };
-  auto mfma_slab = [&](int bufoff) {
-    // fragments one k pair ahead of the MFMAs that use them (an LDS round trip is longer than one
-    // MFMA), issue order pinned: 4 reads, then {4 MFMA, 4 reads} per k pair
+  // Fragments: single floats at (k pair s2, sub-tile i) = base + (s2 * 256 + i * 32) floats.  Written
+  // as plain loads the compiler pairs them into ds_read2_b32, whose 8-bit offsets cannot span the
+  // 1 KB row pitch: it then spends one address VALU per read inside the K loop -- next to fp32 MFMAs
+  // that is the expensive kind of instruction.  ds_read_b32 takes a 16-bit immediate: one base VGPR
+  // per operand and immediates for everything else (asm), waits by hand, one k pair ahead.
+  unsigned aA = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(rA);
+  unsigned aB = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(rB);
+  auto mfma_slab = [&](auto bufc, unsigned pa, unsigned pb) {
+    constexpr int bufoff = decltype(bufc)::value;
     float a[2][2], b[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a[0][i] = rA[bufoff + i * 32];
-      b[0][i] = rB[bufoff + i * 32];
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {   // k = 2*s2 + h
-      const int cu = s2 & 1, nx = cu ^ 1;
-      if (s2 + 1 < 16) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[nx][i] = rA[bufoff + (s2 + 1) * 256 + i * 32];
-          b[nx][i] = rB[bufoff + (s2 + 1) * 256 + i * 32];
-        }
-      }
+    auto rd = [](auto s2c, float (&av)[2], float (&bv)[2], unsigned qa, unsigned qb) {
+      constexpr int o = (bufoff + decltype(s2c)::value * 256) * 4;
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(av[0]) : "v"(qa), "n"(o));
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(av[1]) : "v"(qa), "n"(o + 128));
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv[0]) : "v"(qb), "n"(o));
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv[1]) : "v"(qb), "n"(o + 128));
+    };
+    auto mm = [&](const float (&av)[2], const float (&bv)[2]) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cu][mi], b[cu][ni], acc[mi][ni], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-      if (s2 + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    };
+    rd(std::integral_constant<int, 0>{}, a[0], b[0], pa, pb);
+    auto pair = [&](auto s2c) {
+      constexpr int s2 = decltype(s2c)::value;
+      constexpr int cu = s2 & 1, nx = cu ^ 1;
+      if constexpr (s2 + 1 < 16) {
+        rd(std::integral_constant<int, s2 + 1>{}, a[nx], b[nx], pa, pb);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[cu][0]), "+v"(a[cu][1]), "+v"(b[cu][0]), "+v"(b[cu][1]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[cu][0]), "+v"(a[cu][1]), "+v"(b[cu][0]), "+v"(b[cu][1]));
+      }
+      mm(a[cu], b[cu]);
+    };
+    pair(std::integral_constant<int, 0>{});
+    pair(std::integral_constant<int, 1>{});
+    pair(std::integral_constant<int, 2>{});
+    pair(std::integral_constant<int, 3>{});
+    pair(std::integral_constant<int, 4>{});
+    pair(std::integral_constant<int, 5>{});
+    pair(std::integral_constant<int, 6>{});
+    pair(std::integral_constant<int, 7>{});
+    pair(std::integral_constant<int, 8>{});
+    pair(std::integral_constant<int, 9>{});
+    pair(std::integral_constant<int, 10>{});
+    pair(std::integral_constant<int, 11>{});
+    pair(std::integral_constant<int, 12>{});
+    pair(std::integral_constant<int, 13>{});
+    pair(std::integral_constant<int, 14>{});
+    pair(std::integral_constant<int, 15>{});
   };
   constexpr int BUFF = 2 * TP;
   {
@@ -1872,23 +1893,23 @@ void gemm_leanw_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     lstore(0, la, lb);
   }
   __syncthreads();
-  auto step = [&](int t, int curoff, int nxtoff) {
+  auto step = [&](int t, auto curc, int nxtoff) {
     u32x4 la[4], lb[4];
     advance();
     const bool again = t + 1 < nt;   // the last iteration re-reads the first slab (never used)
     gload(again ? ka : ka0, again ? kb : kb_first, again ? p0 : p_first, la, lb);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_slab(curoff);
+    mfma_slab(curc, aA, aB);
     __builtin_amdgcn_sched_barrier(0);
     lstore(nxtoff, la, lb);
     __syncthreads();
   };
   int t = 0;
   for (; t + 1 < nt; t += 2) {
-    step(t, 0, BUFF);
-    step(t + 1, BUFF, 0);
+    step(t, std::integral_constant<int, 0>{}, BUFF);
+    step(t + 1, std::integral_constant<int, BUFF>{}, 0);
   }
-  if (t < nt) step(t, 0, BUFF);
+  if (t < nt) step(t, std::integral_constant<int, 0>{}, BUFF);
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
 }
 
@@ -2131,15 +2152,15 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       if (!(d.precision == 1 && d.A.split && d.B.split && lean_on && leanw_ok(d))) return F2G_EINVAL;
       return launch_leanw3(d, M, N, K, split, st);
     }
-    {   // exact fp32: the K-major lean kernel where its shape conditions hold.  Opt-in
-      // (F2G_LEAN_WGRAD=1): measured 115 -> 118-121 TFLOP/s on the MPD weight gradients, 92 -> 84 on
-      // the 6016-row generator ones, nothing on the laned step (254.2 vs 254.4 ms) -- its single-float
-      // fragments at 1 KB row pitch cost the compiler one address VALU per ds_read2 in half of the
-      // unrolled iterations, which is exactly what the kernel was written to avoid.
-      static const bool leanw_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) &&
-                                   (getenv("F2G_LEAN_WGRAD") && atoi(getenv("F2G_LEAN_WGRAD")) != 0);
+    {   // exact fp32: the K-major lean kernel where its shape conditions hold and every block walks
+      // a long reduction (>= 4096 rows: the MPD weight gradients, 115 -> 125-131 TFLOP/s, step
+      // 254.5 -> 252.6 ms; on the generator's 6016-row weight gradients the generic kernel's 8 waves
+      // hide the short K loops better: 92 vs 83).  F2G_LEAN_WGRAD: 0 off, 1 auto (default), 2 always.
+      static const int leanw_mode = (getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) ? 0
+                                    : (getenv("F2G_LEAN_WGRAD") ? atoi(getenv("F2G_LEAN_WGRAD")) : 1);
       // (its scalar row walk assumes that a slab crosses at most one sequence end)
-      if (leanw_on && d.precision == 0 && d.E.atomic && leanw_ok(d) && (host_plain(d.B) || d.B.P0 >= 32))
+      if (leanw_mode > 0 && d.precision == 0 && d.E.atomic && leanw_ok(d) &&
+          (host_plain(d.B) || d.B.P0 >= 32) && (leanw_mode > 1 || K / split >= 4096))
         return launch_leanw(d, M, N, K, split, st);
     }
     int am = op_mode(d.A, false), bm = op_mode(d.B, false);

@@ -121,9 +121,10 @@ def test_gemm_split_bf16_on_the_lean_kernel(ops, R, K, N):
 
 
 def _lean_wgrad_expected(mode):
-    # the exact-fp32 K-major kernel is opt-in (F2G_LEAN_WGRAD=1); the split-bf16 one is the default
+    # split-bf16: always the K-major kernel; exact fp32: only long reductions per block by default
+    # (F2G_LEAN_WGRAD=2 forces it -- the kernel tests below run under that setting as well)
     import os
-    return 1 if (mode == "bf16x3" or os.environ.get("F2G_LEAN_WGRAD", "0") not in ("", "0")) else 0
+    return 1 if (mode == "bf16x3" or os.environ.get("F2G_LEAN_WGRAD", "1") == "2") else 0
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
@@ -142,6 +143,35 @@ def test_wgrad_k_major_lean_kernels(ops, R, M, N, mode):
     finally:
         ops.GEMM_PRECISION = was
     close(out, g0.double() + dY.double().t() @ X.double(), rtol=5e-5, name="leanw")
+
+
+@pytest.mark.parametrize("windowed", [False, True])
+def test_wgrad_fp32_k_major_kernel_on_long_reductions(ops, windowed):
+    """The exact-fp32 K-major lean kernel (single-float fragments through ds_read_b32 immediates) is
+    chosen when every block walks >= 4096 rows: plain operands and MPD-style unbounded windows."""
+    if windowed:
+        S, Hin, Cin, Cout, stv, HALO = 40, 610, 128, 128, 3, 2
+        Hout = (Hin + 4 - 5) // stv + 1
+        Hp = Hout + 2 * HALO
+        x = torch.zeros(S, Hin + 2 * HALO, Cin)
+        x[:, HALO:HALO + Hin] = rnd(S, Hin, Cin, seed=1)
+        gy = torch.zeros(S, Hp, Cout)
+        gy[:, HALO:HALO + Hout] = rnd(S, Hout, Cout, seed=2)
+        out = torch.zeros(Cout, 5 * Cin, device=DEV)
+        X = ops.win1d(g(x), S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5, unbounded=True)
+        ops.gemm(ops.mat(g(gy).reshape(S * Hp, Cout)), X, out, form=2, atomic=True, split_k=2)
+        assert ops.L.lib.f2g_gemm_last_path() == 1
+        w = torch.zeros(Cout, Cin, 5, dtype=torch.float64, requires_grad=True)
+        F.conv1d(x[:, HALO:HALO + Hin].permute(0, 2, 1).double(), w, None, stride=stv, padding=2).backward(
+            gy[:, HALO:HALO + Hout].permute(0, 2, 1).double())
+        close(out, w.grad.permute(0, 2, 1).reshape(Cout, 5 * Cin), rtol=2e-5, name="leanw fp32 window")
+    else:
+        R, M, N = 16411, 256, 128
+        dY, X, g0 = rnd(R, M, seed=1), rnd(R, N, seed=2), rnd(M, N, seed=3)
+        out = g(g0)
+        ops.gemm(ops.mat(g(dY)), ops.mat(g(X)), out, form=2, atomic=True, split_k=3)
+        assert ops.L.lib.f2g_gemm_last_path() == 1
+        close(out, g0.double() + dY.double().t() @ X.double(), rtol=2e-5, name="leanw fp32")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
