@@ -304,23 +304,23 @@ class MPDLossFn(torch.autograd.Function):
                 # (split-bf16 mode) one image of it serves the weight gradient and every stride
                 # residue of the data gradient, the forward image of acts[l] the weight gradient
                 with ops.split_sharing(g), (st["shares"][l] or ops.split_sharing()):
-                  if train_disc:
-                      grads_p[2 * l + 1] = zbuf[2 + 2 * l + 1]
-                      # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
-                      # the windows they pair with -- partly outside the input -- contribute nothing)
-                      gwp = zbuf[2 + 2 * l]
-                      if l == 0:
-                          X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
-                      else:
-                          X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
-                                    unbounded=True)   # g's halo rows are zero
-                      ops.wgrad(g, Cout, Cout, X, gwp)
-                      grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
-                  if l > 0:
-                      g = land(None, l, lambda mk, fk, ck, g=g, w=w, Hout=Hout, Cout=Cout, stv=stv, Hin=Hin:
-                               _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, mask=mk, fm=fk, colsum=ck))
-                  elif not train_disc:
-                      g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=False)
+                    if train_disc:
+                        grads_p[2 * l + 1] = zbuf[2 + 2 * l + 1]
+                        # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
+                        # the windows they pair with -- partly outside the input -- contribute nothing)
+                        gwp = zbuf[2 + 2 * l]
+                        if l == 0:
+                            X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
+                        else:
+                            X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
+                                      unbounded=True)   # g's halo rows are zero
+                        ops.wgrad(g, Cout, Cout, X, gwp)
+                        grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
+                    if l > 0:
+                        g = land(None, l, lambda mk, fk, ck, g=g, w=w, Hout=Hout, Cout=Cout, stv=stv, Hin=Hin:
+                                 _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, mask=mk, fm=fk, colsum=ck))
+                    elif not train_disc:
+                        g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=False)
             if not train_disc:
                 # g: (B*p*H0, 1) gradient of the folded image of the generated half
                 lanes.chain_enter()  # g_fake is accumulated period after period
