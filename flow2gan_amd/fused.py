@@ -62,6 +62,30 @@ class _Blk:
         self.H = self.w1.shape[0]
 
 
+_APPLY_GRAD = True
+
+
+class GradAwareFunction(torch.autograd.Function):
+    """autograd.Function whose forward can tell whether a backward can follow: forward itself always
+    runs with grad mode off, and ctx.needs_input_grad mirrors the inputs' requires_grad even when
+    the caller is under torch.no_grad() (inference over parameters that require grad)."""
+
+    @classmethod
+    def apply(cls, *args):
+        global _APPLY_GRAD
+        prev = _APPLY_GRAD
+        _APPLY_GRAD = torch.is_grad_enabled()
+        try:
+            return super().apply(*args)
+        finally:
+            _APPLY_GRAD = prev
+
+
+def _keep(ctx) -> bool:
+    """Does this forward have to save activations for a backward pass?"""
+    return _APPLY_GRAD and any(ctx.needs_input_grad)
+
+
 def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0, te=None, ldte=0,
               te_off=0, keep: bool = True):
     """x (B*F, C) -> new x.  Returns (x_out, z, a) (z, a kept for backward)."""
@@ -156,7 +180,7 @@ def cond_encoder_params(enc) -> list:
     return p
 
 
-class CondEncoderFn(torch.autograd.Function):
+class CondEncoderFn(GradAwareFunction):
     """mel (B, n_mels, Fm) -> condition rows (B*Fm, channels)."""
 
     @staticmethod
@@ -181,11 +205,11 @@ class CondEncoderFn(torch.autograd.Function):
         saved = []
         for bp in blks:
             fn = _limit_draw(training)
-            y, z, a = block_fwd(bp, x, B, Fm, None, keep=any(ctx.needs_input_grad))
+            y, z, a = block_fwd(bp, x, B, Fm, None, keep=_keep(ctx))
             flags.append((fn, _limit_draw(training)))
             saved.append((x, z, a))
             x = y
-        if any(ctx.needs_input_grad):
+        if _keep(ctx):
             ctx.saved = (melr, wp, h0, saved)
             ctx.params = params
             ctx.dims = (B, nm, Fm, Cc)
@@ -258,7 +282,7 @@ def _stack_vecs(bs, dev):
     return out
 
 
-class CondPathFn(torch.autograd.Function):
+class CondPathFn(GradAwareFunction):
     """cond rows (B*Fc, Dc) -> cproj_all (B*Fce, nblk*C) with Fce = ceil(F/up) rows per item."""
 
     @staticmethod
@@ -276,7 +300,7 @@ class CondPathFn(torch.autograd.Function):
             ops.copy3(cext, Fce * Dc, Dc, cond, Fc * Dc, Dc, B, n, Dc)
         rows = B * Fce
         a = ops.empty(rows, Hc, device=dev)
-        keep = any(ctx.needs_input_grad)
+        keep = _keep(ctx)
         pact = ops.empty(rows, Hc, device=dev) if keep else a
         gemm(mat(cext, rows, Dc), mat(w0.reshape(Hc, Dc)), a, bias=b0, prelu=alpha,
              prelu_out=pact if keep else None)
@@ -523,7 +547,7 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
     return out
 
 
-class ModelEvalFn(torch.autograd.Function):
+class ModelEvalFn(GradAwareFunction):
     """pred (B, T) = mean_i w[i,b] * branch_i(x, cond, t)."""
 
     @staticmethod
@@ -543,7 +567,7 @@ class ModelEvalFn(torch.autograd.Function):
         x = x.contiguous()
         B, T = x.shape
         pred = ops.empty(B, T, device=dev)
-        keep = any(ctx.needs_input_grad)
+        keep = _keep(ctx)
         saved, views, lens_list = [], [], []
         off = 0
         for i in range(nb):  # everything the lanes share is created on the caller's stream
