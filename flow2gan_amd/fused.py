@@ -266,20 +266,24 @@ def cond_path_params(dec) -> list:
 
 
 def _stack_rows(ws, cols, dev):
-    """Stack L tensors of shape (C, cols[,1]) into (L*C, cols)."""
-    Cc = ws[0].shape[0]
-    out = ops.empty(len(ws) * Cc, cols, device=dev)
-    for j, w in enumerate(ws):
-        ops.copy3(out, 0, cols, w, 0, cols, 1, Cc, cols, out_offset=j * Cc * cols)
-    return out
+    """Stack L tensors of shape (C, cols[,1]) into (L*C, cols) (cached until a parameter changes)."""
+    def build(ts):
+        Cc = ts[0].shape[0]
+        out = ops.empty(len(ts) * Cc, cols, device=dev)
+        for j, w in enumerate(ts):
+            ops.copy3(out, 0, cols, w, 0, cols, 1, Cc, cols, out_offset=j * Cc * cols)
+        return out
+    return ops.derived_multi(list(ws), ("stack_rows", cols), build)
 
 
 def _stack_vecs(bs, dev):
-    Cc = bs[0].shape[0]
-    out = ops.empty(len(bs) * Cc, device=dev)
-    for j, b in enumerate(bs):
-        ops.copy3(out, 0, 0, b, 0, 0, 1, 1, Cc, out_offset=j * Cc)
-    return out
+    def build(ts):
+        Cc = ts[0].shape[0]
+        out = ops.empty(len(ts) * Cc, device=dev)
+        for j, b in enumerate(ts):
+            ops.copy3(out, 0, 0, b, 0, 0, 1, 1, Cc, out_offset=j * Cc)
+        return out
+    return ops.derived_multi(list(bs), "stack_vecs", build)
 
 
 class CondPathFn(GradAwareFunction):

@@ -78,6 +78,27 @@ def derived(t, tag, build):
     return out
 
 
+_DERIVED_MULTI: dict = {}
+
+
+def derived_multi(ts, tag, build):
+    """build(ts) cached for a LIST of parameters (stacked copies) until one of them changes."""
+    import os
+    if os.environ.get("F2G_WEIGHT_CACHE", "1") == "0":
+        return build(ts)
+    key = (tag,) + tuple(id(t) for t in ts)
+    stamp = tuple(t._version for t in ts) + (WEIGHT_EPOCH,)
+    ent = _DERIVED_MULTI.get(key)
+    if ent is not None and ent[0] == stamp and all(r() is t for r, t in zip(ent[2], ts)):
+        return ent[1]
+    out = build(ts)
+    out._f2g_const = True
+    if len(_DERIVED_MULTI) > 4096:     # ids of dead parameters: start over
+        _DERIVED_MULTI.clear()
+    _DERIVED_MULTI[key] = (stamp, out, [weakref.ref(t) for t in ts])
+    return out
+
+
 def transposed(w2d):
     """(n, k) row-major -> cached (k, n) row-major copy."""
     def build(t):
