@@ -9,6 +9,7 @@ Layout: a reference tensor (B, C, F) is a rows matrix (B*F, C); audio stays (B, 
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import List, Optional
 
@@ -400,6 +401,47 @@ class _BranchView:
         self.Ht = self.tw0.shape[0]
 
 
+# Spectra carry n_fft + 2 = 514 / 258 / 130 channels: no multiple of a K slab, which sends every
+# GEMM that reduces over them (in_proj, inverse DFT, STFT backward, out_proj data gradient) to the
+# element-wise loaders.  With the lean kernels available the spectrum rows are padded to a multiple
+# of 64 columns that are ZERO BY CONSTRUCTION -- the producing GEMM runs against weights / DFT
+# tables with zero rows appended, so it writes the zeros itself -- and the consumers reduce over the
+# padded width against zero-padded weights: same sums (plus exact zeros), lean kernels.
+SPEC_PAD = os.environ.get("F2G_SPEC_PAD", "1") != "0" and os.environ.get("F2G_LEAN", "1") != "0"
+
+
+def _spec_ld(Cin: int) -> int:
+    return (Cin + 63) // 64 * 64 if SPEC_PAD else ops.pad4(Cin)
+
+
+def _pad_cols(w2d, Kp: int):
+    """(n, k) -> cached (n, Kp) copy with zero columns appended."""
+    def build(t):
+        n, k = t.shape
+        out = ops.zeros(n, Kp, device=t.device)
+        ops.copy3(out, 0, Kp, t, 0, t.stride(0), 1, n, k)
+        return out
+    return w2d if w2d.shape[1] == Kp else ops.derived(w2d, ("padc", Kp), build)
+
+
+def _pad_rows(w2d, Np: int):
+    """(n, k) -> cached (Np, k) copy with zero rows appended."""
+    def build(t):
+        n, k = t.shape
+        out = ops.zeros(Np, k, device=t.device)
+        ops.copy3(out, 0, k, t, 0, t.stride(0), 1, n, k)
+        return out
+    return w2d if w2d.shape[0] == Np else ops.derived(w2d, ("padr", Np), build)
+
+
+def _pad_vec(b, Np: int):
+    def build(t):
+        out = ops.zeros(Np, device=t.device)
+        ops.copy3(out, 0, 0, t, 0, 0, 1, 1, t.shape[0])
+        return out
+    return b if b.shape[0] == Np else ops.derived(b, ("padv", Np), build)
+
+
 def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pred, accumulate,
                     lens_f, training, keep, lanes=None):
     n_fft, hop, up, window = meta
@@ -410,14 +452,17 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     rows = B * F
     Cc, Cin = bv.C, bv.Cin
     Wd, Wi = dft_matrices(N, dev)
-    ldp = ops.pad4(Cin)
-    packed = ops.empty(rows, ldp, device=dev)
+    ldp = _spec_ld(Cin)
+    Kc = ldp if SPEC_PAD else Cin        # reduction width over a spectrum row
     if ops.fft_applies(N):
+        packed = ops.zeros(rows, ldp, device=dev) if SPEC_PAD else ops.empty(rows, ldp, device=dev)
         ops.stft_fft(x, N, hop, F, packed)
     else:
-        gemm(ops.stft_frames(x, N, hop, F), mat(Wd), packed, split_k=1)   # spectra stay bit-reproducible
+        packed = ops.empty(rows, ldp, device=dev)
+        gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1)   # bit-reproducible
     h0 = ops.empty(rows, Cc, device=dev)
-    gemm(mat(packed, rows, Cin), mat(bv.w_in.reshape(Cc, Cin)), h0, bias=bv.b_in)
+    # (never split, as before the padding: the forward stays bit-reproducible from run to run)
+    gemm(mat(packed, rows, Kc), mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), h0, bias=bv.b_in, split_k=1)
     flags = [_limit_draw(training)]
     xcur = ops.empty(rows, Cc, device=dev)
     ops.biasnorm_fwd(h0, xcur, rows, Cc, bv.beta_in, bv.ls_in.reshape(1))
@@ -447,11 +492,12 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
             saved_blocks.append((xcur, z, a))
         xcur = y
     yspec = ops.empty(rows, ldp, device=dev)
-    gemm(mat(xcur, rows, Cc), mat(bv.w_out.reshape(Cin, Cc)), yspec, bias=bv.b_out)
+    gemm(mat(xcur, rows, Cc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), yspec,
+         bias=_pad_vec(bv.b_out, Kc), split_k=1)
     if lens_f is not None:
         ops.mask_rows(yspec, B, F, Cin, lens_f)
     frames = ops.empty(rows, N, device=dev)
-    gemm(mat(yspec, rows, Cin), mat(Wi), frames)
+    gemm(mat(yspec, rows, Kc), mat(_pad_cols(Wi, Kc)), frames, split_k=1)
     if lanes is not None:
         lanes.chain_enter()  # pred is accumulated branch after branch
     ops.istft_ola(frames, pred, B, F, N, hop, T, window, wbranch_row, wscale, accumulate)
@@ -474,12 +520,13 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
     Cc, Cin = bv.C, bv.Cin
     NC = bv.nblk * Cc
     Wd, Wi = dft_matrices(N, dev)
-    ldp = ops.pad4(Cin)
+    ldp = _spec_ld(Cin)
+    Kc = ldp if SPEC_PAD else Cin
     Fce = cproj.shape[0] // B
     gfr = ops.empty(rows, N, device=dev)
     ops.istft_ola_bwd(g_pred, gfr, B, F, N, hop, T, window, wbranch_row, wscale)
     gy = ops.empty(rows, ldp, device=dev)
-    gemm(mat(gfr, rows, N), mat(Wi), gy, form=1)
+    gemm(mat(gfr, rows, N), mat(_pad_cols(Wi, Kc)), gy, form=1)      # pad columns come out zero
     if lens_f is not None:
         ops.mask_rows(gy, B, F, Cin, lens_f)
     g_wout = ops.zeros(Cin, Cc, device=dev)
@@ -488,7 +535,7 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
     x_last = sv["x_last"]
     ops.wgrad(gy, Cin, ldp, mat(x_last, rows, Cc), g_wout)
     g = ops.empty(rows, Cc, device=dev)
-    gemm(mat(gy, rows, Cin), mat(bv.w_out.reshape(Cin, Cc)), g, form=1)
+    gemm(mat(gy, rows, Kc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), g, form=1)
     g_te_all = ops.zeros(B, NC, device=dev)
     block_grads = [None] * bv.nblk
     flags = sv["flags"]
@@ -511,12 +558,12 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
     ops.wgrad(gh0, Cc, gh0.stride(0), mat(sv["packed"], rows, Cin), g_win)
     if need_gx:
         gpacked = ops.empty(rows, ldp, device=dev)
-        gemm(mat(gh0, rows, Cc), mat(bv.w_in.reshape(Cc, Cin)), gpacked, form=1)
+        gemm(mat(gh0, rows, Cc), mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), gpacked, form=1)
         gxf = ops.empty(rows, N, device=dev)
         if ops.fft_applies(N):
             ops.stft_fft_adjoint(gpacked, N, F, gxf)
         else:
-            gemm(mat(gpacked, rows, Cin), mat(Wd), gxf, form=1)
+            gemm(mat(gpacked, rows, Kc), mat(_pad_rows(Wd, Kc)), gxf, form=1)
         if lanes is not None:
             lanes.chain_enter()  # g_x is accumulated branch after branch
         ops.frames_fold(gxf, g_x, B, F, N, hop, T, accumulate_gx)
