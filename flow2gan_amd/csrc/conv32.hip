@@ -21,7 +21,9 @@ constexpr int PITCH = 36;               // floats per staged pixel (conflict-fre
 constexpr int KH = 3, KW = 9;
 constexpr int IW = TW + (KW - 1) / 2;   // staged columns per parity: 16 + 4 = 20
 constexpr int IH = TH + KH - 1;         // staged rows: 10
-constexpr int SUB = IH * IW * PITCH;    // floats of one parity sub-tile
+constexpr int SUB = IH * IW * PITCH + 16;   // floats of one parity sub-tile (+64 B: the 8-byte stores of
+                                         // the split-bf16 staging put pixels x and x+1 = the two parities
+                                         // into one 16-lane group; without the skew they share every bank)
 constexpr int WB = C * PITCH;           // floats of one weight tile
 constexpr int TG = 2;                   // taps per barrier (weights double-buffered per group)
 
@@ -209,7 +211,10 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
   const float* gs = d.x + (long long)s * d.x_seq;
   for (int i = tid; i < IH * GW * (C / 4); i += 512) {
     const int c4 = i & 7;
-    const int px = i >> 3;
+    int px = i >> 3;
+    // (split-bf16: 8-byte stores, two pixels per 16-lane group: pair pixels p and p+4, whose 144-byte
+    // pitch puts them on disjoint banks; IH*GW is a multiple of 8)
+    if constexpr (P3) px = (px & ~7) | ((px & 1) << 2) | ((px & 7) >> 1);
     const int r = px / GW, xc = px - r * GW;
     const int h = h0 - 1 + r, c = m0 - 2 + xc;
     const bool ok = h >= 0 && h < d.H && c >= 0 && c < d.Wout;
@@ -462,7 +467,8 @@ __device__ __forceinline__ void store_split_planes(unsigned char* hi, unsigned c
   *reinterpret_cast<u32x2*>(lo) = l;
 }
 
-constexpr int XPL = 2 * IH * IW * 64;   // bytes of one plane of the input patch (both parities)
+constexpr int XPAR = IH * IW * 64 + 64;  // bytes of one parity of a plane (+64: see SUB)
+constexpr int XPL = 2 * XPAR;           // bytes of one plane of the input patch (both parities)
 constexpr int GPL = TH * TW * 64;       // bytes of one plane of the gradient tile
 
 __global__ __launch_bounds__(512, 2) void conv32_s2_wgrad3_kernel(const f2g_conv32_desc d, float* gw,
@@ -491,11 +497,11 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_wgrad3_kernel(const f2g_conv
   for (int a = 0; a < 3; ++a) {
     int t = wave + 8 * a;
     int dh = t / KW, j = t - dh * KW;
-    xo[a] = ((j & 1) * IH * IW + dh * IW + (j >> 1) + kpix) * 64 + chb;
+    xo[a] = (j & 1) * XPAR + (dh * IW + (j >> 1) + kpix) * 64 + chb;
     t = 24 + a;
     dh = t / KW;
     j = t - dh * KW;
-    xs[a] = ((j & 1) * IH * IW + dh * IW + (j >> 1) + kpix) * 64 + chb;
+    xs[a] = (j & 1) * XPAR + (dh * IW + (j >> 1) + kpix) * 64 + chb;
   }
   const int go = kpix * 64 + chb;
   const int t0 = blockIdx.x * tiles_per_block;
@@ -514,12 +520,12 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_wgrad3_kernel(const f2g_conv
       const int h = h0 - 1 + r, x = x0 + xr;
       const bool ok = h >= 0 && h < d.H && x >= 0 && x < d.Win;
       const float* p = ok ? xsrc + (long long)h * d.x_line + (long long)x * C + c4 * 4 : c32_zero;
-      const int off = ((xr & 1) * IH * IW + r * IW + (xr >> 1)) * 64 + c4 * 8;
+      const int off = (xr & 1) * XPAR + (r * IW + (xr >> 1)) * 64 + c4 * 8;
       store_split_planes(Xh + off, Xl + off, *reinterpret_cast<const float4*>(p));
     }
     if (tid < IH * 8) {   // the odd parity has one column less: keep its last column defined
       const int r = tid >> 3, c4 = tid & 7;
-      const int off = (IH * IW + r * IW + IW - 1) * 64 + c4 * 8;
+      const int off = XPAR + (r * IW + IW - 1) * 64 + c4 * 8;
       *reinterpret_cast<u32x2*>(Xh + off) = u32x2{0u, 0u};
       *reinterpret_cast<u32x2*>(Xl + off) = u32x2{0u, 0u};
     }
