@@ -936,7 +936,14 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r,
 // waves, one block per CU).  The bf16 instances are bound by L2 -> CU operand delivery (PMC: 13 TB/s
 // of L2 reads on the 1024-channel MPD layer at 128 x 128 = 32 FLOP per byte): the taller tile
 // moves a quarter less per FLOP with the same waves per SIMD.
-template <bool SK, int EP, int PM, int WM = 2>
+// TAP (split-bf16, 256 x 128 only): A is a stride-1 (taps, 1) conv window over a halo layout
+// (win1d, step 1, pad 0).  Tap-major K order makes the plain kernel fetch every activation row once
+// per tap; here the rows a tile needs -- its output rows' padded positions plus taps - 1, including
+// the halo rows of the sequence ends inside the tile -- are staged ONCE per 32-channel slab and
+// the taps walk over them in LDS (a lane's fragment row = its output row's staged row + tap):
+// 260-320 staged rows instead of 5 x 256 per channel slab, about half the L2 -> CU traffic of
+// the kernel that is bound by exactly that.
+template <bool SK, int EP, int PM, int WM = 2, bool TAP = false>
 __global__ __launch_bounds__(WM * 128, 4 / WM)
 void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
   constexpr bool P3 = PM == 1 || PM == 2, HI = PM == 2, BF = PM == 3;
@@ -1028,6 +1035,133 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][ni][e] = b;
     }
+    if constexpr (TAP) {
+      constexpr int RAMAX = 320;                 // staged activation rows per channel slab (host-checked)
+      constexpr int TSA = RAMAX * LDR;
+      float* sA = smem;                          // [2][RAMAX][LDR]
+      float* sB = smem + 2 * TSA;                // [2][128][LDR]
+      const int Cin = d.A.unit, taps = d.A.cols / Cin, P0 = d.A.P0;
+      const int Hp = (int)(d.A.seq_stride / Cin);
+      auto qof = [&](int m) { const int sq = m / P0; return sq * Hp + (m - sq * P0); };
+      const int mlast = (m0 + BM < M ? m0 + BM : M) - 1;
+      const int qb = qof(m0);
+      int rowA[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        int r = m0 + wm * 64 + mi * 32 + li;
+        r = r > mlast ? mlast : r;
+        rowA[mi] = (qof(r) - qb) * LDR + h * 4;
+      }
+      const long long a_bytes = (long long)(d.A.rows / P0) * d.A.seq_stride * 4;
+      __amdgpu_buffer_rsrc_t rat =
+          __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, (unsigned)a_bytes, 0x00020000);
+      unsigned voA[5];
+      int wofA[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int ci = tid + 512 * u, j = ci >> 3, c8 = ci & 7;
+        voA[u] = j < RAMAX ? (unsigned)((long long)j * Cin * 4 + c8 * 16) : 0x80000000u;
+        wofA[u] = (j < RAMAX ? j : 0) * LDR + c8 * 2;
+      }
+      const long long sa0 = (long long)qb * Cin * 4;
+      const unsigned offBt = (unsigned)((long long)(n0 + rr) * d.B.seq_stride * 4) + ch * 16;
+      float* wBt = sB + rr * LDR + ch * 2;
+      const float* rBt = sB + (wn * 64 + li) * LDR + h * 4;
+      const int ncs = Cin / BK, nit = ncs * taps;
+      auto gloadA = [&](int cs, u32x4 (&ax)[5]) {
+        const int so = (int)(sa0 + (long long)cs * BK * 4);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) ax[u] = __builtin_amdgcn_raw_buffer_load_b128(rat, voA[u], so, 0);
+      };
+      auto lstoreA = [&](int buf, const u32x4 (&ax)[5]) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          if (u < 4 || tid + 512 * 4 < RAMAX * 8) {
+            float* p = sA + buf * TSA + wofA[u];
+            *reinterpret_cast<u32x2*>(p) = u32x2{ax[u].x, ax[u].y};
+            *reinterpret_cast<u32x2*>(p + 16) = u32x2{ax[u].z, ax[u].w};
+          }
+        }
+      };
+      auto gloadB = [&](int cs, int tap, u32x4 (&lb)[2]) {
+        const int so = (tap * Cin + cs * BK) * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offBt, so + q * qstepB, 0);
+      };
+      auto lstoreB = [&](int buf, const u32x4 (&lb)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float* p = wBt + buf * TSB + q * RS * LDR;
+          *reinterpret_cast<u32x2*>(p) = u32x2{lb[q].x, lb[q].y};
+          *reinterpret_cast<u32x2*>(p + 16) = u32x2{lb[q].z, lb[q].w};
+        }
+      };
+      bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+      auto fragsT = [&](int cs, int tap, int bbuf, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+        const float* pa = sA + (cs & 1) * TSA + tap * LDR + ks * 8;
+        const float* pb = rBt + bbuf * TSB + ks * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = *reinterpret_cast<const bf16x8*>(pa + rowA[i]);
+          fa[2 + i] = *reinterpret_cast<const bf16x8*>(pa + rowA[i] + 16);
+          fb[i] = *reinterpret_cast<const bf16x8*>(pb + i * 32 * LDR);
+          fb[2 + i] = *reinterpret_cast<const bf16x8*>(pb + i * 32 * LDR + 16);
+        }
+      };
+      auto mfma12 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const bf16x8 av = term == 0 ? fa[2 + mi] : fa[mi];
+              const bf16x8 bv = term == 1 ? fb[2 + ni] : fb[ni];
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
+            }
+      };
+      // (cs, tap) of iteration it, it + 1 and it + 2, walked with scalar counters
+      int cs0 = 0, tp0 = 0, cs1 = 0, tp1 = 1, cs2 = 0, tp2 = 2;
+      auto wrap = [&](int& c, int& t) { if (t >= taps) { t -= taps; ++c; } };
+      wrap(cs1, tp1);
+      wrap(cs2, tp2);
+      wrap(cs2, tp2);
+      u32x4 xb[2], yb[2], ax[5];
+      gloadA(0, ax);
+      gloadB(0, 0, xb);
+      lstoreA(0, ax);
+      lstoreB(0, xb);
+      gloadB(cs1, tp1, xb);     // (nit >= 2: taps >= 2)
+      if (ncs > 1) gloadA(1, ax);
+      __syncthreads();
+      fragsT(0, 0, 0, 0, fa0, fb0);
+      auto stepT = [&](int it, int cur, int nxt, const u32x4 (&wb)[2], u32x4 (&lb)[2]) {
+        fragsT(cs0, tp0, cur, 1, fa1, fb1);
+        const bool more2 = it + 2 < nit;
+        gloadB(more2 ? cs2 : 0, more2 ? tp2 : 0, lb);
+        // the next channel slab's rows: requested at tap 0 (the prologue did it for slab 1), stored
+        // at tap 2 into the buffer slab cs - 1 has left two barriers ago
+        if (tp0 == 0 && cs0 > 0 && cs0 + 1 < ncs) gloadA(cs0 + 1, ax);
+        mfma12(fa0, fb0);
+        lstoreB(nxt, wb);
+        if (tp0 == (taps > 2 ? 2 : taps - 1) && cs0 + 1 < ncs) lstoreA((cs0 + 1) & 1, ax);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        fragsT(cs1, tp1, nxt, 0, fa0, fb0);
+        mfma12(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        cs0 = cs1; tp0 = tp1; cs1 = cs2; tp1 = tp2;
+        ++tp2;
+        wrap(cs2, tp2);
+      };
+      int it = 0;
+      for (; it + 1 < nit; it += 2) {
+        stepT(it, 0, 1, xb, yb);
+        stepT(it + 1, 1, 0, yb, xb);
+      }
+      if (it < nit) stepT(it, 0, 1, xb, yb);
+    } else {
     unsigned offA[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1225,6 +1359,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
 
     }
 
+    }
     const f2g_epilogue& E = d.E;
     const bool simple = !partial && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
                         !E.atomic && !E.accumulate && E.scale == 0.f && !E.mask_src;
@@ -1431,6 +1566,15 @@ inline bool lean_a_ok(const f2g_operand& S) {
   return last * 4 < 0x7ff00000ll;
 }
 
+// A as a stride-1 conv window whose rows a 256-row tile can stage once per channel slab (TAP mode)
+inline bool lean_tap_ok(const f2g_operand& A) {
+  if (A.P1 != 1 || A.step0 != 1 || A.pad0 != 0 || A.unit < BK || A.unit % BK) return false;
+  if (A.cols % A.unit || A.cols / A.unit < 2 || A.seglen < A.cols || A.seq_stride % A.unit) return false;
+  const int taps = A.cols / A.unit, Hp = (int)(A.seq_stride / A.unit);
+  if (A.P0 < 8 || Hp < A.P0 + taps - 1) return false;
+  return 256 + taps - 1 + (Hp - A.P0) * (256 / A.P0 + 1) <= 320;
+}
+
 // the same operand as a TRUE bf16 tensor (split = 2): 16-byte chunks hold 8 elements, slabs 64
 inline bool lean_bf16_ok(const f2g_operand& A, const f2g_operand& B) {
   const long long eu0 = (long long)A.step0 * A.unit, ep0 = (long long)A.pad0 * A.unit;
@@ -1460,7 +1604,11 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   const bool tall = (pm == 1 || pm == 3) && upb == 0 && zs == 1 && tall_mode > 0 &&
                     (tall_mode > 1 || (tall_tiles >= 400 && K >= 640));
   const int bm = tall ? 256 : 128;
-  const size_t smem = (size_t)(2 * bm + 2 * 128) * LDR * sizeof(float);
+  // tap-reusing variant for stride-1 conv windows (F2G_LEAN_TAP=0 turns it off)
+  static const bool tap_on = !(getenv("F2G_LEAN_TAP") && atoi(getenv("F2G_LEAN_TAP")) == 0);
+  const bool tap = tall && pm == 1 && tap_on && lean_tap_ok(d.A);
+  const size_t smem = tap ? (size_t)(2 * 320 + 2 * 128) * LDR * sizeof(float)
+                          : (size_t)(2 * bm + 2 * 128) * LDR * sizeof(float);
   dim3 grid((M + bm - 1) / bm, (N + 127) / 128, zs);
   if (grid.x == 0 || grid.y == 0) return F2G_OK;
   if (upb > 0) {
@@ -1515,6 +1663,10 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 3, 4>)};
     for (const void* k : kt)
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 256 + 2 * 128) * LDR * 4);
+    const void* kp[2] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 1, 4, true>),
+                         reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 1, 4, true>)};
+    for (const void* k : kp)
+      (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 320 + 2 * 128) * LDR * 4);
     attr_done = true;
   }
   g_last_path = upb > 0 ? 2 : 1;
@@ -1542,7 +1694,14 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
       hipLaunchKernelGGL((gemm_lean_kernel<false, EPV, 3, 4>), grid, dim3(512), smem, st, d, M,   \
                          N, K, kchunk, upb);                                                      \
   } while (0)
-  if (tall) {
+  if (tap && (ep == 2 || ep == 3)) {
+    if (ep == 2)
+      hipLaunchKernelGGL((gemm_lean_kernel<false, 2, 1, 4, true>), grid, dim3(512), smem, st, d, M, N, K,
+                         kchunk, upb);
+    else
+      hipLaunchKernelGGL((gemm_lean_kernel<false, 3, 1, 4, true>), grid, dim3(512), smem, st, d, M, N, K,
+                         kchunk, upb);
+  } else if (tall) {
     if (ep == 0) F2G_LEAN_T(0);
     else if (ep == 1) F2G_LEAN_T(1);
     else if (ep == 2) F2G_LEAN_T(2);
