@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflow2gan_hip.so")
+# (F2G_LIB_PATH: lab builds of the same library, tools/micro/ -- measurement aid only)
+LIB_PATH = os.environ.get("F2G_LIB_PATH") or os.path.join(_HERE, "libflow2gan_hip.so")
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers
 

@@ -31,6 +31,9 @@ int g_last_path = 0;   // kernel family of the last dispatch (f2g_gemm_last_path
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
+#ifndef F2G_LABVAR
+#define F2G_LABVAR 0   // lab builds only (tools/micro/build_variants.sh): ablations of the bf16 lean K loop
+#endif
 constexpr int LDR = BK + 4;  // row-major LDS tile leading dim (conflict-free ds_read_b128)
 
 // ------------------------------------------------------------------------------------------
@@ -1295,12 +1298,12 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       frags(0, 0, fa0, fb0);
       auto step3 = [&](int t, int curoff, int nxtoff, const u32x4 (&wa)[4], const u32x4 (&wb)[4],
                        u32x4 (&la)[4], u32x4 (&lb)[4]) {
-        frags(curoff, 1, fa1, fb1);
+        if (!(F2G_LABVAR & 8)) frags(curoff, 1, fa1, fb1);
         advance();
         const bool again = t + 2 < nt;   // past the end: re-read the first slab (never used)
-        gload(again ? ka : ka0, again ? kb : kb0, la, lb);
+        if (!(F2G_LABVAR & 1)) gload(again ? ka : ka0, again ? kb : kb0, la, lb);
         mfma12(fa0, fb0);
-        lstore(nxtoff, wa, wb);
+        if (!(F2G_LABVAR & 2)) lstore(nxtoff, wa, wb);
         // issue order: fragments, the loads of the slab after next, one LDS store behind each of
         // the first MFMAs
         constexpr int NM = HI ? 4 : (BF ? 8 : 12);        // MFMAs per half slab
@@ -1314,9 +1317,9 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           if (i * WPM < NW) __builtin_amdgcn_sched_group_barrier(0x200, WPM, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if (!(F2G_LABVAR & 4)) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        frags(nxtoff, 0, fa0, fb0);
+        if (!(F2G_LABVAR & 8)) frags(nxtoff, 0, fa0, fb0);
         mfma12(fa1, fb1);
         __builtin_amdgcn_sched_group_barrier(0x100, HI ? 4 : 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, HI ? 4 : (BF ? 8 : 12), 0);

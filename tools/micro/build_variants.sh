@@ -1,11 +1,13 @@
 #!/bin/bash
-# lab builds of the GEMM translation unit with F2G_LABVAR switches -> tools/micro/libvarN.so
+# lab builds of the whole library with F2G_LABVAR switches -> tools/micro/libvarN.so (loaded through
+# F2G_LIB_PATH).  Bits (bf16 lean K loop): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no
+# fragment reads -- results are garbage by construction, only the timing means something.
 set -e
 cd "$(dirname "$0")/../../flow2gan_amd/csrc"
 OUT=../../tools/micro
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DF2G_LABVAR=$v -shared \
-     gemm.hip narrow.hip capi.hip -o $OUT/libvar$v.so &
+     capi.hip gemm.hip narrow.hip convnext.hip signal.hip elementwise.hip optim.hip conv32.hip conv2ch.hip fft.hip -o $OUT/libvar$v.so &
 done
 wait
 ls -la $OUT/*.so
