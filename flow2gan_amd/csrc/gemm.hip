@@ -1272,6 +1272,15 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           }
         }
       };
+      f32x16 shadow[2][2];   // (lab, F2G_LABVAR & 16: second accumulator set -> twice the dependent distance)
+      if (F2G_LABVAR & 16) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) shadow[mi][ni][e] = 0.f;
+      }
       auto mfma12 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
         if constexpr (BF) {
 #pragma unroll
@@ -1292,7 +1301,10 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
             for (int ni = 0; ni < 2; ++ni) {
               const bf16x8 av = term == 0 ? fa[2 + mi] : fa[mi];
               const bf16x8 bv = term == 1 ? fb[2 + ni] : fb[ni];
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
+              if ((F2G_LABVAR & 16) && term == 1)
+                shadow[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, shadow[mi][ni], 0, 0, 0);
+              else
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mi][ni], 0, 0, 0);
             }
       };
       frags(0, 0, fa0, fb0);
@@ -1331,6 +1343,14 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         step3(t + 1, TSZ, 0, ya, yb, xa, xb);
       }
       if (t < nt) step3(t, 0, TSZ, xa, xb, ya, yb);
+      if (F2G_LABVAR & 16) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] += shadow[mi][ni][e];
+      }
     } else {
     if (nt > 0) {
       u32x4 la[4], lb[4];
