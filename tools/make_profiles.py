@@ -58,7 +58,7 @@ res = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     tot = 0.0; n = 0
     for row in csv.DictReader(open(f"{G}/pmcb_{name}/p_counter_collection.csv")):
-        if re.search(r"gemm_lean_kernel<false, \d, 0(, \d)?>", row["Kernel_Name"]):   # exact-fp32 instances
+        if re.search(r"gemm_lean_kernel<false, \d, 0[,>]", row["Kernel_Name"]):   # exact-fp32 instances
             tot += float(row["Counter_Value"]); n += 1
     res[name] = (tot, n)
 f, nf = res["FETCH_SIZE"]; w, nw = res["WRITE_SIZE"]
