@@ -7,6 +7,7 @@ mkdir -p $O
 cd $R
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 F2G_GEMM_REPORT=80 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fast-mode 2> $O/shapes.txt > /dev/null
+[ -x tools/micro/gemm_lab ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/micro/gemm_lab.hip -o tools/micro/gemm_lab > /dev/null 2>&1
 ./tools/micro/gemm_lab > $O/gemm_lab.txt 2>&1
 for w in stage1 infer4; do
   python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$w.json
