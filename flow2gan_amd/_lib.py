@@ -104,6 +104,12 @@ class FftDesc(C.Structure):  # == f2g_fft_desc
                 ("_pad", C.c_int32), ("frames", C.c_void_p), ("ld_frames", C.c_int64)]
 
 
+class Mpd0Desc(C.Structure):  # == f2g_mpd0_desc
+    _fields_ = [("x", C.c_void_p), ("S", C.c_int32), ("H", C.c_int32), ("Hout", C.c_int32),
+                ("halo", C.c_int32), ("w", C.c_void_p), ("bias", C.c_void_p), ("slope", C.c_float),
+                ("_pad", C.c_int32), ("y", C.c_void_p)]
+
+
 class SadamGroup(C.Structure):  # == f2g_sadam_group
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("scalar_lr_scale", C.c_float), ("eps", C.c_float), ("param_min_rms", C.c_float),
@@ -157,6 +163,9 @@ _SIGS = {
     "f2g_lrelu_bwd": [_P, _P, _P, _F, _P, _F, _I, _I, _L],
     "f2g_reflect_pad": [_P, _P, _I, _I, _I, _I],
     "f2g_fft_frames": [C.POINTER(FftDesc), _I],
+    "f2g_mpd0_fwd": [C.POINTER(Mpd0Desc)],
+    "f2g_mpd0_wgrad": [C.POINTER(Mpd0Desc), _P],
+    "f2g_mpd0_dgrad": [C.POINTER(Mpd0Desc), _P],
     "f2g_period_fold": [_P, _P, _I, _I, _I, _I],
     "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
     "f2g_fill": [_P, _F, _L],

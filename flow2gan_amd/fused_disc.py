@@ -119,6 +119,13 @@ def _mpd_forward_one(x2, p: int, prm: list, keep_images: bool = False):
         Hout = (H + 4 - 5) // st + 1
         wp = ops.derived(w, "pack", pack_conv_weight)
         y = _halo_rows(S, Hout, Cout, dev)
+        if l == 0 and ops.MPD0_DIRECT and Cout == 32 and st == 3:
+            # 1 -> 32 channels, 5 taps: an HBM stream, not a GEMM (mpd0.hip)
+            ops.mpd0_fwd(x, S, H, Hout, HALO, w.reshape(Cout, 5), b, SLOPE, y)
+            acts.append(y)
+            hs.append(Hout)
+            x, H = y, Hout
+            continue
         if l == 0:   # the folded waveform has no halo (one channel): bounds-tested windows
             A = win1d(x, S, H, Cin, Hout, st, 2, 5)
         else:        # window of output row h starts at padded row h*st
@@ -309,16 +316,22 @@ class MPDLossFn(torch.autograd.Function):
                         # reduction over ALL rows of the padded gradient map (its halo rows are 0, so
                         # the windows they pair with -- partly outside the input -- contribute nothing)
                         gwp = zbuf[2 + 2 * l]
-                        if l == 0:
-                            X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
+                        if l == 0 and ops.MPD0_DIRECT and Cout == 32 and stv == 3:
+                            ops.mpd0_wgrad(acts[0], S, Hin, Hout, HALO, g, gwp)
                         else:
-                            X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
-                                      unbounded=True)   # g's halo rows are zero
-                        ops.wgrad(g, Cout, Cout, X, gwp)
+                            if l == 0:
+                                X = win1d(acts[0], S, Hin, Cin, Hp, stv, 2 + HALO * stv, 5)
+                            else:
+                                X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
+                                          unbounded=True)   # g's halo rows are zero
+                            ops.wgrad(g, Cout, Cout, X, gwp)
                         grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
                     if l > 0:
                         g = land(None, l, lambda mk, fk, ck, g=g, w=w, Hout=Hout, Cout=Cout, stv=stv, Hin=Hin:
                                  _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, mask=mk, fm=fk, colsum=ck))
+                    elif not train_disc and ops.MPD0_DIRECT and Cout == 32 and stv == 3:
+                        gx0 = ops.empty(Sx * Hin, 1, device=dev)
+                        g = ops.mpd0_dgrad(g, Sx, Hin, Hout, HALO, w.reshape(Cout, 5), gx0)
                     elif not train_disc:
                         g = _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, out_halo=False)
             if not train_disc:

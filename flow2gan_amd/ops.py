@@ -989,6 +989,48 @@ def zeros_many(shapes, device):
     return [flat[o:o + n].view(*sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
+# ------------------------------------------------------------------ first MPD layer (1 -> 32 channels)
+MPD0_DIRECT = _os.environ.get("F2G_MPD0_DIRECT", "1") != "0"
+
+
+def _mpd0_desc(x, S, H, Hout, halo, w=None, bias=None, slope=0.0, y=None, x_off=0, y_off=0):
+    d = L.Mpd0Desc()
+    d.x = None if x is None else ptr(x) + 4 * x_off
+    d.S, d.H, d.Hout, d.halo = S, H, Hout, halo
+    d.w, d.bias, d.slope = ptr(w), ptr(bias), slope
+    d.y = ptr(y) + 4 * y_off
+    return d
+
+
+def mpd0_fwd(x, S, H, Hout, halo, w5, bias, slope, y):
+    """y (halo layout (S, Hout + 2*halo, 32)) = lrelu(conv(x (S, H); w5 (32, 5), stride 3, pad 2) + bias)."""
+    d = _mpd0_desc(x, S, H, Hout, halo, w5, bias, slope, y)
+    _timed("f2g_mpd0_fwd", d, 2.0 * S * Hout * 32 * 5, (0, S * Hout, 32, 5))
+    return y
+
+
+def mpd0_wgrad(x, S, H, Hout, halo, g, gw):
+    """gw (32, 5) += weight gradient of the first MPD layer; g = gradient map (halo layout)."""
+    d = _mpd0_desc(x, S, H, Hout, halo, y=g)
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_mpd0_wgrad", C.byref(d), ptr(gw)), 2.0 * S * Hout * 32 * 5,
+                        (2, 32, 5, S * Hout))
+    else:
+        call("f2g_mpd0_wgrad", C.byref(d), ptr(gw))
+    return gw
+
+
+def mpd0_dgrad(g, S, H, Hout, halo, w5, gx, g_off=0):
+    """gx (S*H) = data gradient of the first MPD layer from the gradient map g (halo layout)."""
+    d = _mpd0_desc(None, S, H, Hout, halo, w5, None, 0.0, g, y_off=g_off)
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_mpd0_dgrad", C.byref(d), ptr(gx)), 2.0 * S * Hout * 32 * 5,
+                        (1, S * H, 1, 64))
+    else:
+        call("f2g_mpd0_dgrad", C.byref(d), ptr(gx))
+    return gx
+
+
 # ------------------------------------------------------------------ LDS-butterfly FFT (n_fft >= 1024)
 USE_FFT = _os.environ.get("F2G_FFT", "1") != "0"
 FFT_MIN = 1024          # smaller transforms stay on the DFT GEMM (K <= 512: a short, full-rate GEMM)

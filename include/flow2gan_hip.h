@@ -403,6 +403,26 @@ int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
 int f2g_zero_halo(float* buf, int32_t nseq, int32_t rows_per_seq, int32_t C, int32_t lo,
                   int32_t hi, f2g_stream_t stream);
 
+/* ---- first layer of a period discriminator (discriminators.py:65-67,92-94: Conv2d(1, 32, (5, 1),
+ * stride (3, 1), padding (2, 0)) + leaky ReLU on the folded waveform) as HBM-stream kernels: as a
+ * K = 5 GEMM it ran on element-wise loaders.  x: (S, H) floats; y: the 32-channel map in the halo
+ * layout (S, Hout + 2*halo, 32), Hout = (H - 1) / 3 + 1; w: [32][5] (= the checkpoint's (32,1,5,1)).
+ *   fwd  : y[s, halo + h, :] = lrelu(bias + sum_j w[:, j] x[s, 3h + j - 2])      (halo rows untouched)
+ *   wgrad: gw[32][5] += sum_{s,h} y[s, halo + h, :] (x) x[s, 3h + j - 2]       (y = gradient map, read)
+ *   dgrad: gx[s, i] = sum_{co, j} y[s, halo + (i + 2 - j)/3, co] w[co][j]       (y = gradient map, read) */
+typedef struct {
+  const float* x;
+  int32_t S, H, Hout, halo;
+  const float* w;
+  const float* bias; /* fwd; may be NULL */
+  float slope;       /* fwd: leaky-ReLU slope (0 = plain ReLU ... use 1 for none) */
+  int32_t _pad;
+  float* y;
+} f2g_mpd0_desc;
+int f2g_mpd0_fwd(const f2g_mpd0_desc* d, f2g_stream_t stream);
+int f2g_mpd0_wgrad(const f2g_mpd0_desc* d, float* gw, f2g_stream_t stream);
+int f2g_mpd0_dgrad(const f2g_mpd0_desc* d, float* gx, f2g_stream_t stream);
+
 /* ---- direct LDS-tiled conv for the MRD band layers (discriminators.py:171-181): Conv2d(32, 32,
  * (3, 9), stride (1, 2), padding (1, 4)) + bias + leaky ReLU on channels-last images.
  * x: (S, H, Win, 32), y: (S, H, Wout, 32) with Wout = (Win - 1) / 2 + 1; strides in floats

@@ -391,6 +391,34 @@ def test_conv_period_stride3(ops, Cin, Cout, H, stride):
     close(out, want, name="mpd-conv")
 
 
+@pytest.mark.parametrize("S,H", [(6, 100), (3, 4001), (130, 37)])
+def test_mpd_first_layer_direct_kernels(ops, S, H):
+    """mpd0.hip: Conv2d(1, 32, (5,1), stride (3,1), padding (2,0)) + leaky ReLU into the halo layout,
+    its weight gradient and its data gradient, against torch conv1d + autograd in float64."""
+    HALO = 2
+    Hout = (H + 4 - 5) // 3 + 1
+    x = rnd(S, H, seed=1)
+    w, b = rnd(32, 5, seed=2) * 0.3, rnd(32, seed=3) * 0.1
+    y = torch.full((S * (Hout + 2 * HALO), 32), 7.0, device=DEV)
+    ops.mpd0_fwd(g(x), S, H, Hout, HALO, g(w), g(b), 0.1, y)
+    xd = x.double()[:, None, :].requires_grad_(True)
+    wd = w.double()[:, None, :].requires_grad_(True)
+    pre = F.conv1d(xd, wd, b.double(), stride=3, padding=2)
+    ref = F.leaky_relu(pre, 0.1)
+    yv = y.view(S, Hout + 2 * HALO, 32)
+    close(yv[:, HALO:HALO + Hout], ref.permute(0, 2, 1), name="mpd0 fwd")
+    assert float(yv[:, :HALO].min()) == 7.0 and float(yv[:, HALO + Hout:].max()) == 7.0
+    gy = torch.zeros(S, Hout + 2 * HALO, 32)
+    gy[:, HALO:HALO + Hout] = rnd(S, Hout, 32, seed=4)
+    pre.backward(gy[:, HALO:HALO + Hout].permute(0, 2, 1).double())
+    gw = torch.zeros(32, 5, device=DEV)
+    ops.mpd0_wgrad(g(x), S, H, Hout, HALO, g(gy), gw)
+    close(gw, wd.grad[:, 0, :], rtol=1e-4, name="mpd0 wgrad")
+    gx = torch.full((S * H, 1), 7.0, device=DEV)
+    ops.mpd0_dgrad(g(gy), S, H, Hout, HALO, g(w), gx)
+    close(gx.view(S, H), xd.grad[:, 0, :], name="mpd0 dgrad")
+
+
 @pytest.mark.parametrize("Cin,Cout,kw,sw", [(2, 32, 9, 1), (32, 32, 9, 2), (32, 32, 3, 1), (32, 1, 3, 1)])
 def test_conv2d_band_windowed(ops, Cin, Cout, kw, sw):
     """MRD (3,kw) conv over (time, freq) with stride (1,sw) on a frequency slice of a wider image."""
