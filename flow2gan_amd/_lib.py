@@ -110,6 +110,12 @@ class Mpd0Desc(C.Structure):  # == f2g_mpd0_desc
                 ("_pad", C.c_int32), ("y", C.c_void_p)]
 
 
+class MpdPostDesc(C.Structure):  # == f2g_mpdpost_desc
+    _fields_ = [("y", C.c_void_p), ("S", C.c_int32), ("H", C.c_int32), ("halo", C.c_int32),
+                ("_pad", C.c_int32), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("g", C.c_void_p)]
+
+
 class SadamGroup(C.Structure):  # == f2g_sadam_group
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("scalar_lr_scale", C.c_float), ("eps", C.c_float), ("param_min_rms", C.c_float),
@@ -166,6 +172,9 @@ _SIGS = {
     "f2g_mpd0_fwd": [C.POINTER(Mpd0Desc)],
     "f2g_mpd0_wgrad": [C.POINTER(Mpd0Desc), _P],
     "f2g_mpd0_dgrad": [C.POINTER(Mpd0Desc), _P],
+    "f2g_mpdpost_fwd": [C.POINTER(MpdPostDesc)],
+    "f2g_mpdpost_dgrad": [C.POINTER(MpdPostDesc)],
+    "f2g_mpdpost_wgrad": [C.POINTER(MpdPostDesc), _P],
     "f2g_period_fold": [_P, _P, _I, _I, _I, _I],
     "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
     "f2g_fill": [_P, _F, _L],

@@ -123,6 +123,106 @@ __global__ __launch_bounds__(256) void mpd0_dgrad_kernel(const f2g_mpd0_desc d, 
   }
 }
 
+// ---- last layer of a period discriminator (discriminators.py:76,97-99: Conv2d(1024, 1, (3, 1),
+// padding (1, 0))): one output channel -- as GEMMs with N = 1 / K = 3 / M = 1 these ran on the narrow VALU
+// kernels at 150-300 us per call.  The 1024-channel map (halo layout, zero halo rows: no bounds tests)
+// is streamed once: a row = 256 float4, a lane holds 4 of them.
+constexpr int CP = 1024, KP = 3;
+
+// scores[s*H + h] = bias + sum_j <y[s, halo + h + j - 1, :], w[j]>: a wave walks RH outputs and the
+// RH + 2 rows they touch, every row read once
+constexpr int RH = 8;
+
+__global__ __launch_bounds__(256) void mpdpost_fwd_kernel(const f2g_mpdpost_desc d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int groups = (d.H + RH - 1) / RH;
+  const long long unit = (long long)blockIdx.x * 4 + wave;
+  if (unit >= (long long)d.S * groups) return;
+  const int s = (int)(unit / groups), h0 = (int)(unit - (long long)s * groups) * RH;
+  float4 w[KP][4];
+#pragma unroll
+  for (int j = 0; j < KP; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[j][q] = reinterpret_cast<const float4*>(d.w + j * CP)[q * 64 + lane];
+  const int Hp = d.H + 2 * d.halo;
+  const float4* base = reinterpret_cast<const float4*>(d.y + ((long long)s * Hp + d.halo) * CP);
+  float acc[RH];
+#pragma unroll
+  for (int i = 0; i < RH; ++i) acc[i] = 0.f;
+  auto dot = [](const float4 (&v)[4], const float4 (&u)[4]) {
+    float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r += v[q].x * u[q].x + v[q].y * u[q].y + v[q].z * u[q].z + v[q].w * u[q].w;
+    return r;
+  };
+#pragma unroll
+  for (int i = -1; i <= RH; ++i) {       // input row h0 + i (halo rows / rows past H read as stored: zeros)
+    const int hp = h0 + i;
+    if (hp > d.H) break;                  // (row H is the zero halo row the last output touches)
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = base[(long long)hp * (CP / 4) + q * 64 + lane];
+    if (i + 1 < RH) acc[i + 1] += dot(v, w[0]);                            // output h = hp + 1, tap 0
+    if (i >= 0 && i < RH) acc[i] += dot(v, w[1]);                          // output h = hp, tap 1
+    if (i >= 1) acc[i - 1] += dot(v, w[2]);                                // output h = hp - 1, tap 2
+  }
+  const float b = d.bias ? d.bias[0] : 0.f;
+#pragma unroll
+  for (int i = 0; i < RH; ++i) {
+    const float r = wave_sum(acc[i]);
+    if (lane == 0 && h0 + i < d.H) d.out[(long long)s * d.H + h0 + i] = r + b;
+  }
+}
+
+// gy[s, halo + h, :] = g[s, h+1] w[0] + g[s, h] w[1] + g[s, h-1] w[2]   (rows 0..H-1; halo rows untouched)
+__global__ __launch_bounds__(256) void mpdpost_dgrad_kernel(const f2g_mpdpost_desc d) {
+  const int t = threadIdx.x;
+  const float4 w0 = reinterpret_cast<const float4*>(d.w)[t], w1 = reinterpret_cast<const float4*>(d.w + CP)[t],
+               w2 = reinterpret_cast<const float4*>(d.w + 2 * CP)[t];
+  const long long R = (long long)d.S * d.H;
+  const int Hp = d.H + 2 * d.halo;
+  for (long long r = blockIdx.x; r < R; r += gridDim.x) {
+    const int s = (int)(r / d.H), h = (int)(r - (long long)s * d.H);
+    const float* g = d.g + (long long)s * d.H;
+    const float ga = h + 1 < d.H ? g[h + 1] : 0.f, gb = g[h], gc = h > 0 ? g[h - 1] : 0.f;
+    float4 o;
+    o.x = ga * w0.x + gb * w1.x + gc * w2.x;
+    o.y = ga * w0.y + gb * w1.y + gc * w2.y;
+    o.z = ga * w0.z + gb * w1.z + gc * w2.z;
+    o.w = ga * w0.w + gb * w1.w + gc * w2.w;
+    reinterpret_cast<float4*>(d.y + ((long long)s * Hp + d.halo + h) * CP)[t] = o;
+  }
+}
+
+// gw[j][c] += sum_{s,h} g[s, h] * y[s, halo + h + j - 1, c]: every map row read once, it feeds the
+// three taps with the scores' gradients of its neighbours
+__global__ __launch_bounds__(256) void mpdpost_wgrad_kernel(const f2g_mpdpost_desc d, float* gw, int rows_per) {
+  const int t = threadIdx.x;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+  const int Hq = d.H + 2;                       // rows -1 .. H of a sequence
+  const long long R = (long long)d.S * Hq;
+  const int Hp = d.H + 2 * d.halo;
+  long long r = (long long)blockIdx.x * rows_per;
+  const long long rend = r + rows_per < R ? r + rows_per : R;
+  for (; r < rend; ++r) {
+    const int s = (int)(r / Hq), hp = (int)(r - (long long)s * Hq) - 1;
+    const float* g = d.g + (long long)s * d.H;
+    const float g0 = hp + 1 < d.H ? g[hp + 1] : 0.f;                  // tap 0 of output hp + 1
+    const float g1 = (hp >= 0 && hp < d.H) ? g[hp] : 0.f;             // tap 1 of output hp
+    const float g2 = hp >= 1 ? g[hp - 1] : 0.f;                       // tap 2 of output hp - 1
+    const float4 v = reinterpret_cast<const float4*>(d.y + ((long long)s * Hp + d.halo + hp) * CP)[t];
+    a0.x += g0 * v.x; a0.y += g0 * v.y; a0.z += g0 * v.z; a0.w += g0 * v.w;
+    a1.x += g1 * v.x; a1.y += g1 * v.y; a1.z += g1 * v.z; a1.w += g1 * v.w;
+    a2.x += g2 * v.x; a2.y += g2 * v.y; a2.z += g2 * v.z; a2.w += g2 * v.w;
+  }
+  float* o = gw + 4 * t;
+  atomicAdd(o + 0, a0.x); atomicAdd(o + 1, a0.y); atomicAdd(o + 2, a0.z); atomicAdd(o + 3, a0.w);
+  o += CP;
+  atomicAdd(o + 0, a1.x); atomicAdd(o + 1, a1.y); atomicAdd(o + 2, a1.z); atomicAdd(o + 3, a1.w);
+  o += CP;
+  atomicAdd(o + 0, a2.x); atomicAdd(o + 1, a2.y); atomicAdd(o + 2, a2.z); atomicAdd(o + 3, a2.w);
+}
+
 int grid_rows(long long rows) {
   long long b = (rows + 31) / 32;
   if (b > 256 * 8) b = 256 * 8;
@@ -158,5 +258,36 @@ extern "C" int f2g_mpd0_dgrad(const f2g_mpd0_desc* d, float* gx, f2g_stream_t st
   if (d->S == 0) return F2G_OK;
   hipLaunchKernelGGL(mpd0_dgrad_kernel, dim3(grid_rows((long long)d->S * d->H)), dim3(256), 0,
                      (hipStream_t)stream, *d, gx);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_mpdpost_fwd(const f2g_mpdpost_desc* d, f2g_stream_t stream) {
+  if (!d || !d->y || !d->w || !d->out || d->H <= 0 || d->halo < 1 || (((uintptr_t)d->y) & 15) ||
+      (((uintptr_t)d->w) & 15))
+    return F2G_EINVAL;
+  if (d->S <= 0) return F2G_OK;
+  const long long units = (long long)d->S * ((d->H + RH - 1) / RH);
+  hipLaunchKernelGGL(mpdpost_fwd_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *d);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_mpdpost_dgrad(const f2g_mpdpost_desc* d, f2g_stream_t stream) {
+  if (!d || !d->y || !d->w || !d->g || d->H <= 0 || (((uintptr_t)d->y) & 15) || (((uintptr_t)d->w) & 15))
+    return F2G_EINVAL;
+  if (d->S <= 0) return F2G_OK;
+  long long b = (long long)d->S * d->H;
+  if (b > 256 * 16) b = 256 * 16;
+  hipLaunchKernelGGL(mpdpost_dgrad_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, *d);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_mpdpost_wgrad(const f2g_mpdpost_desc* d, float* gw, f2g_stream_t stream) {
+  if (!d || !d->y || !d->g || !gw || d->H <= 0 || d->halo < 1 || (((uintptr_t)d->y) & 15)) return F2G_EINVAL;
+  if (d->S <= 0) return F2G_OK;
+  const long long R = (long long)d->S * (d->H + 2);
+  int per = (int)((R + 511) / 512);
+  if (per < 1) per = 1;
+  hipLaunchKernelGGL(mpdpost_wgrad_kernel, dim3((unsigned)((R + per - 1) / per)), dim3(256), 0,
+                     (hipStream_t)stream, *d, gw, per);
   return f2g_check_launch();
 }

@@ -142,7 +142,10 @@ def _mpd_forward_one(x2, p: int, prm: list, keep_images: bool = False):
     wpost, bpost = prm[10], prm[11]
     wpp = ops.derived(wpost, "pack", pack_conv_weight)
     scores = ops.empty(S * H, 1, device=dev)
-    gemm(win1d(x, S, H + 2 * HALO, 1024, H, 1, -(HALO - 1), 3), mat(wpp), scores, bias=bpost)
+    if ops.MPD0_DIRECT and x.shape[1] == 1024:    # 1024 -> 1 channel, 3 taps: an HBM stream (mpd0.hip)
+        ops.mpdpost_fwd(x, S, H, HALO, wpp, bpost, scores)
+    else:
+        gemm(win1d(x, S, H + 2 * HALO, 1024, H, 1, -(HALO - 1), 3), mat(wpp), scores, bias=bpost)
     return dict(acts=acts, hs=hs, scores=scores, S=S, p=p, shares=shares)
 
 
@@ -262,7 +265,10 @@ class MPDLossFn(torch.autograd.Function):
                     zshapes += [(MPD_CH[l + 1], 5 * MPD_CH[l]), (MPD_CH[l + 1],)]
                 zbuf = ops.zeros_many(zshapes, dev)
                 gwp = zbuf[0]
-                ops.wgrad(gs, 1, 1, win1d(y5, S, H5 + 2 * HALO, 1024, H5, 1, -(HALO - 1), 3), gwp)
+                if ops.MPD0_DIRECT and y5.shape[1] == 1024:
+                    ops.mpdpost_wgrad(y5, S, H5, HALO, gs, gwp)
+                else:
+                    ops.wgrad(gs, 1, 1, win1d(y5, S, H5 + 2 * HALO, 1024, H5, 1, -(HALO - 1), 3), gwp)
                 grads_p[10] = unpack_conv_grad(gwp, wpost.shape)
                 gb = zbuf[1]
                 ops.colsum(gb, gs, S * H5, 1)
@@ -300,8 +306,14 @@ class MPDLossFn(torch.autograd.Function):
                     ops.lrelu_bwd(gm, y, None, 0.0, SLOPE, 1, n_, n_, y_off=mk[1])
                 return gm
 
-            g = land(None, 5, lambda mk, fk, ck: _conv1d_dgrad(
-                gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5, g_halo=False, mask=mk, fm=fk, colsum=ck))
+            def post_dgrad(mk, fk, ck):
+                if mk is None and ops.MPD0_DIRECT and y5.shape[1] == 1024:
+                    gy5 = _halo_rows(Sx, H5, 1024, dev)
+                    return ops.mpdpost_dgrad(gs, Sx, H5, HALO, ops.derived(wpost, "pack", pack_conv_weight),
+                                             gy5, g_off=roff * H5)
+                return _conv1d_dgrad(gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5, g_halo=False,
+                                     mask=mk, fm=fk, colsum=ck)
+            g = land(None, 5, post_dgrad)
             for l in reversed(range(5)):
                 w = prm[2 * l]
                 Cin, Cout, stv = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]

@@ -1031,6 +1031,39 @@ def mpd0_dgrad(g, S, H, Hout, halo, w5, gx, g_off=0):
     return gx
 
 
+def _mpdpost_desc(y, S, H, halo, w3=None, bias=None, out=None, g=None, g_off=0, y_off=0):
+    d = L.MpdPostDesc()
+    d.y = ptr(y) + 4 * y_off
+    d.S, d.H, d.halo = S, H, halo
+    d.w, d.bias, d.out = ptr(w3), ptr(bias), ptr(out)
+    d.g = None if g is None else ptr(g) + 4 * g_off
+    return d
+
+
+def mpdpost_fwd(y, S, H, halo, w3, bias, out):
+    """out (S*H) = conv_post of an MPD sub-discriminator over the 1024-channel map y (halo layout)."""
+    _timed("f2g_mpdpost_fwd", _mpdpost_desc(y, S, H, halo, w3, bias, out), 2.0 * S * H * 3072, (0, S * H, 1, 3072))
+    return out
+
+
+def mpdpost_dgrad(g, S, H, halo, w3, gy, g_off=0):
+    """gy (halo layout (S, H + 2*halo, 1024), halo rows pre-zeroed) = data gradient of conv_post."""
+    _timed("f2g_mpdpost_dgrad", _mpdpost_desc(gy, S, H, halo, w3, None, None, g, g_off), 2.0 * S * H * 3072,
+           (0, S * H, 1024, 3))
+    return gy
+
+
+def mpdpost_wgrad(y, S, H, halo, g, gw):
+    """gw (3*1024, tap-major) += weight gradient of conv_post."""
+    d = _mpdpost_desc(y, S, H, halo, None, None, None, g)
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_mpdpost_wgrad", C.byref(d), ptr(gw)), 2.0 * S * H * 3072,
+                        (2, 1, 3072, S * H))
+    else:
+        call("f2g_mpdpost_wgrad", C.byref(d), ptr(gw))
+    return gw
+
+
 # ------------------------------------------------------------------ LDS-butterfly FFT (n_fft >= 1024)
 USE_FFT = _os.environ.get("F2G_FFT", "1") != "0"
 FFT_MIN = 1024          # smaller transforms stay on the DFT GEMM (K <= 512: a short, full-rate GEMM)

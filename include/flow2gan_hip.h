@@ -423,6 +423,24 @@ int f2g_mpd0_fwd(const f2g_mpd0_desc* d, f2g_stream_t stream);
 int f2g_mpd0_wgrad(const f2g_mpd0_desc* d, float* gw, f2g_stream_t stream);
 int f2g_mpd0_dgrad(const f2g_mpd0_desc* d, float* gx, f2g_stream_t stream);
 
+/* ---- last layer of a period discriminator (discriminators.py:76,97-99: Conv2d(1024, 1, (3, 1), padding
+ * (1, 0))) as HBM-stream kernels over the 1024-channel map y (halo layout (S, H + 2*halo, 1024), zero
+ * halo rows, halo >= 1); w: [3][1024] (tap-major); out / g: (S*H) scores / their gradient.
+ *   fwd  : out[s*H + h] = bias + sum_j <y[s, halo + h + j - 1, :], w[j]>
+ *   dgrad: y[s, halo + h, :] = g[s,h+1] w[0] + g[s,h] w[1] + g[s,h-1] w[2]      (y = gradient map, written)
+ *   wgrad: gw[3][1024] += sum_{s,h} g[s,h] y[s, halo + h + j - 1, :]           (y = forward map, read) */
+typedef struct {
+  float* y;
+  int32_t S, H, halo, _pad;
+  const float* w;
+  const float* bias;
+  float* out;
+  const float* g;
+} f2g_mpdpost_desc;
+int f2g_mpdpost_fwd(const f2g_mpdpost_desc* d, f2g_stream_t stream);
+int f2g_mpdpost_dgrad(const f2g_mpdpost_desc* d, f2g_stream_t stream);
+int f2g_mpdpost_wgrad(const f2g_mpdpost_desc* d, float* gw, f2g_stream_t stream);
+
 /* ---- direct LDS-tiled conv for the MRD band layers (discriminators.py:171-181): Conv2d(32, 32,
  * (3, 9), stride (1, 2), padding (1, 4)) + bias + leaky ReLU on channels-last images.
  * x: (S, H, Win, 32), y: (S, H, Wout, 32) with Wout = (Win - 1) / 2 + 1; strides in floats

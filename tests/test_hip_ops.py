@@ -419,6 +419,33 @@ def test_mpd_first_layer_direct_kernels(ops, S, H):
     close(gx.view(S, H), xd.grad[:, 0, :], name="mpd0 dgrad")
 
 
+@pytest.mark.parametrize("S,H", [(5, 27), (3, 100), (40, 9)])
+def test_mpd_last_layer_direct_kernels(ops, S, H):
+    """mpd0.hip: conv_post of a period discriminator (Conv2d(1024, 1, (3,1), padding (1,0))) over the
+    halo layout: scores, weight gradient and data gradient against torch conv1d + autograd (fp64)."""
+    HALO, Cc = 2, 1024
+    y = torch.zeros(S, H + 2 * HALO, Cc)
+    y[:, HALO:HALO + H] = rnd(S, H, Cc, seed=1)
+    w, b = rnd(1, Cc, 3, seed=2) * 0.05, rnd(1, seed=3)
+    w3 = w[0].t().contiguous()                                    # [tap][c]
+    out = torch.full((S * H, 1), 7.0, device=DEV)
+    ops.mpdpost_fwd(g(y), S, H, HALO, g(w3), g(b), out)
+    yd = y[:, HALO:HALO + H].permute(0, 2, 1).double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = F.conv1d(yd, wd, b.double(), padding=1)
+    close(out.view(S, H), ref[:, 0], name="mpdpost fwd")
+    gs = rnd(S, H, seed=4)
+    ref.backward(gs[:, None, :].double())
+    gw = torch.zeros(3, Cc, device=DEV)
+    ops.mpdpost_wgrad(g(y), S, H, HALO, g(gs), gw)
+    close(gw, wd.grad[0].t(), rtol=1e-4, name="mpdpost wgrad")
+    gy = torch.zeros(S * (H + 2 * HALO), Cc, device=DEV)
+    ops.mpdpost_dgrad(g(gs), S, H, HALO, g(w3), gy)
+    gv = gy.view(S, H + 2 * HALO, Cc)
+    close(gv[:, HALO:HALO + H], yd.grad.permute(0, 2, 1), name="mpdpost dgrad")
+    assert float(gv[:, :HALO].abs().max()) == 0.0 and float(gv[:, HALO + H:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("Cin,Cout,kw,sw", [(2, 32, 9, 1), (32, 32, 9, 2), (32, 32, 3, 1), (32, 1, 3, 1)])
 def test_conv2d_band_windowed(ops, Cin, Cout, kw, sw):
     """MRD (3,kw) conv over (time, freq) with stride (1,sw) on a frequency slice of a wider image."""
