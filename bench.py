@@ -113,6 +113,8 @@ def main():
     reducer = fdist.GradReducer(force=force_dist)
     g_params = list(gan.generator.parameters())
     d_params = list(gan.discriminator.parameters())
+    from flow2gan_amd.harness import grad_groups
+    g_groups, d_groups = grad_groups(gan, False), grad_groups(gan, True)
 
     opt_d = opt_g = sch_d = sch_g = None
     if args.optimizer:  # finetune.py:917-921 / pretrain.py:794-799 settings
@@ -132,19 +134,20 @@ def main():
     lens = torch.full((B,), T, dtype=torch.int64)
     nts = args.n_timesteps
 
-    # reducer.prepare() zeroes the gradients (views into flat arenas when there is an exchange);
-    # every bucket's all-reduce starts from an autograd hook while backward is still running
+    # reducer.prepare() zeroes the gradients (views into flat arenas when there is an exchange); a
+    # Fourier branch's / period discriminator's bucket starts its all-reduce when its launch lane has
+    # finished its backward, the rest from autograd hooks while backward is still running
     def step():
         if args.workload == "gan_stage2":
             # discriminator step on its batch
-            reducer.prepare(d_params)
+            reducer.prepare(d_params, groups=d_groups)
             cond = logmel(audio_d)
             mp, mr = gan(cond, audio_d, lens, nts, True)
             (D_WEIGHTS[0] * mp + D_WEIGHTS[1] * mr).backward()
             reducer.finish()
             optimize(opt_d, sch_d)
             # generator step on a new batch
-            reducer.prepare(g_params)
+            reducer.prepare(g_params, groups=g_groups)
             cond = logmel(audio_g)
             ls = gan(cond, audio_g, lens, nts, False)
             sum(w * l for w, l in zip(G_WEIGHTS, ls)).backward()
@@ -153,7 +156,7 @@ def main():
             return 2 * B * (T / sr)
         if args.workload == "stage1":
             gen.train()
-            reducer.prepare(g_params)
+            reducer.prepare(g_params, groups=g_groups)
             cond = logmel(audio_g)
             gen(cond, audio_g, lens).backward()
             reducer.finish()
@@ -207,8 +210,12 @@ def main():
                         "product, fp32 accumulate; lean / K-major weight-gradient / direct-conv kernels)",
                 "value": round(world * a2 / e2, 2), "unit": "audio-s/s",
                 "ms_per_step": round(1e3 * e2 / max(2, args.steps // 2), 2),
-                "parity": "<=1e-4 RMS waveform vs reference (the golden parity tests run in this mode "
-                          "too); per-product error ~2^-16 instead of 2^-24"}
+                "parity": "<=1e-4 RMS waveform and losses to 2e-4 vs reference (the golden parity tests "
+                          "run in this mode too); per-product error ~2^-16 instead of 2^-24. GRADIENTS "
+                          "are held to looser bounds than in exact fp32, because more discriminator "
+                          "pixels land on the other side of a leaky-ReLU / L1 / hinge kink: tiny-config "
+                          "G-step gradients to 0.3 of each tensor's max (fp32: 5e-3), full-width "
+                          "B=2 gradients to 0.1 (fp32: 1e-2), tests/test_hip_gan.py"}
         if not args.no_roofline:
             # the same per-launch HIP-event pass as the headline's roofline, in this mode
             torch.cuda.synchronize()

@@ -162,6 +162,7 @@ _SIGS = {
     "f2g_spec_power": [_P, _L, _P, _L, _I, _I, _I],
     "f2g_spec_power_bwd": [_P, _L, _P, _L, _P, _I, _I, _I],
     "f2g_fm_spec_loss": [_P, _P, _P, _P, _I, _I, _I, _P, _F, _F, _F, _F, _F],
+    "f2g_masked_mse": [_P, _P, _P, _P, _I, _I, _P, _F],
     "f2g_l1_loss": [_P, _P, _P, _P, _I, _I, _L, _F, _F, _P],
     "f2g_hinge_loss": [_P, _P, _P, _L, _F, _F, _P],
     "f2g_peaknorm_fwd": [_P, _P, _P, _I, _I],

@@ -317,6 +317,25 @@ __global__ __launch_bounds__(256) void fm_spec_loss_kernel(float* loss, float* g
   if (threadIdx.x == 0) atomicAdd(loss, acc);
 }
 
+__global__ __launch_bounds__(256) void masked_mse_kernel(float* loss, float* g_err, const float* pred,
+                                                         const float* ref, int B, int T,
+                                                         const int* lens, float inv_denom) {
+  __shared__ float sh[4];
+  const long long total = (long long)B * T;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / T);
+    const int t = (int)(i - (long long)b * T);
+    const bool live = !lens || t < lens[b];
+    const float e = live ? pred[i] - ref[i] : 0.f;
+    acc += e * e;
+    if (g_err) g_err[i] = 2.f * inv_denom * e;
+  }
+  acc = block_sum256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, acc * inv_denom);
+}
+
 __global__ __launch_bounds__(256) void l1_loss_kernel(float* loss, float* gb, const float* a,
                                                       const float* b, int rows, int cols,
                                                       long long ld, float w, float clip,
@@ -692,6 +711,16 @@ extern "C" int f2g_fm_spec_loss(float* loss, float* g_err, const float* s_err, c
   hipLaunchKernelGGL(fm_spec_loss_kernel, dim3(f2g_grid_for((int64_t)B * F * n_filt, 256, 1024)),
                      dim3(256), 0, ST, loss, g_err, s_err, s_gt, B, F, n_filt, lens, eps, power, lo,
                      hi, inv_denom);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_masked_mse(float* loss, float* g_err, const float* pred, const float* ref,
+                              int32_t B, int32_t T, const int32_t* lens, float inv_denom,
+                              f2g_stream_t stream) {
+  if (!loss || !pred || !ref) return F2G_EINVAL;
+  if (B <= 0 || T <= 0) return F2G_OK;
+  hipLaunchKernelGGL(masked_mse_kernel, dim3(f2g_grid_for((int64_t)B * T, 256, 1024)), dim3(256), 0,
+                     ST, loss, g_err, pred, ref, B, T, lens, inv_denom);
   return f2g_check_launch();
 }
 

@@ -249,7 +249,11 @@ bool plainish(const f2g_operand& S) {
 // negative on error.
 int f2g_gemm_narrow(const f2g_gemm_desc& d, hipStream_t st) {
   const f2g_epilogue& E = d.E;
-  if (E.res || E.aux || E.colsum_alpha || E.prelu_slope) return 0;
+  // operands / epilogue fields these VALU kernels do not implement go to the generic path, which
+  // applies them or rejects the descriptor
+  if (E.res || E.aux || E.colsum_alpha || E.prelu_slope || E.mask_src || E.fm_ref || E.c_bf16 ||
+      d.A.split || d.B.split)
+    return 0;
   if (d.form == 0 || d.form == 1) {
     const bool f1 = d.form == 1;
     const int M = d.A.rows, N = f1 ? d.B.cols : d.B.rows, K = d.A.cols;

@@ -32,8 +32,10 @@ def setup_dist(rank: Optional[int] = None, world_size: Optional[int] = None,
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
-    if backend == "gloo":
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # host names need not resolve
+    if backend == "gloo" and os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+        # single-node rendezvous over loopback: host names need not resolve.  A multi-node job
+        # (any other MASTER_ADDR) keeps gloo's own interface choice.
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     # a missing peer must surface as an error within minutes, not after torch's 30-minute default
     timeout = datetime.timedelta(seconds=float(os.environ.get("F2G_DIST_TIMEOUT_S", "600")))
     dist.init_process_group(backend, rank=rank, world_size=world_size, timeout=timeout)
@@ -159,18 +161,27 @@ class GradReducer:
     # branch buckets travel under the remaining branches' backward.  The arenas are persistent
     # (288 GB of HBM: 486 MB of gradient arenas is noise), so there is no pack / unpack copy.
 
-    def prepare(self, params: Iterable[torch.nn.Parameter]) -> None:
+    def prepare(self, params: Iterable[torch.nn.Parameter], groups=None) -> None:
+        """`groups`: optional lists of parameters whose gradients become final TOGETHER (one
+        Fourier branch, one period discriminator): buckets never span two groups, so a group's
+        bucket can leave the moment its kernel lane has finished (fused.deliver_grads)."""
+        from . import fused
         params = [p for p in params if p.requires_grad]
         if get_world_size() == 1 and not (self.force and dist.is_initialized()):
             # nothing to exchange: plain zero_grad(set_to_none=True), autograd keeps its own buffers
             for p in params:
                 p.grad = None
             self._active = None
+            fused.GRAD_SINK = None
             return
-        key = tuple(id(p) for p in params)
+        gid = {}
+        for gi, grp in enumerate(groups or []):
+            for p in grp:
+                gid[id(p)] = gi
+        key = tuple((id(p), gid.get(id(p), -1)) for p in params)
         plan = self._plans.get(key)
         if plan is None:
-            plan = _Plan(params, self.bucket_bytes)
+            plan = _Plan(params, self.bucket_bytes, gid)
             self._plans[key] = plan
             for p in params:
                 if id(p) not in self._hooked:
@@ -180,6 +191,7 @@ class GradReducer:
         plan.exchange = world > 1 or (self.force and dist.is_initialized())
         plan.arm()
         self._active = plan
+        fused.GRAD_SINK = _Sink(self, plan)
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         plan = self._active
@@ -195,12 +207,18 @@ class GradReducer:
             raise RuntimeError("GradReducer: gradient arrived for a bucket that has already been "
                                "exchanged -- exactly one backward() per prepare()/finish() pair")
         b.fired.add(id(p))
+        if b.flat.is_cuda:
+            # the stream this gradient was accumulated on (a launch lane, or autograd's stream)
+            cur = torch.cuda.current_stream(b.flat.device)
+            if cur.cuda_stream not in b.streams:
+                b.streams[cur.cuda_stream] = cur
         if len(b.fired) == len(b.params) and not b.sent:
             self._send(plan, b)
 
     @torch.no_grad()
     def _send(self, plan: "_Plan", b: "_Bucket") -> None:
         b.sent = True
+        plan.sent_order.append(b.index)
         if not plan.exchange:
             return
         world = get_world_size()
@@ -211,6 +229,8 @@ class GradReducer:
                 b.flat.div_(world)
         else:
             comm.wait_stream(torch.cuda.current_stream(b.flat.device))
+            for st in b.streams.values():     # every lane that accumulated into this bucket
+                comm.wait_stream(st)
             with torch.cuda.stream(comm):
                 dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
                 if world > 1:
@@ -221,6 +241,8 @@ class GradReducer:
         """Send what has not left yet, wait for the exchange; parameters that received no
         gradient in this backward get `.grad = None` back (as without the reducer).  Returns the
         bytes exchanged."""
+        from . import fused
+        fused.GRAD_SINK = None
         plan, self._active = self._active, None
         if plan is None:
             return 0
@@ -236,9 +258,58 @@ class GradReducer:
         return plan.bytes
 
 
+class _Sink:
+    """What fused.deliver_grads talks to while an exchange is armed: the coarse autograd nodes
+    (one model evaluation = three branches on three launch lanes; the five period discriminators)
+    hand over a finished lane's parameter gradients HERE, inside their backward, instead of
+    returning them to autograd when the whole node is done -- so that lane's bucket starts its
+    all-reduce on the communication stream while the other lanes still compute (the reference gets
+    this from DDP's bucket hooks, finetune.py:915).  A parameter used by several nodes of one
+    backward (n_timesteps > 1) is sent after its last use."""
+
+    def __init__(self, reducer: "GradReducer", plan: "_Plan"):
+        self.reducer, self.plan = reducer, plan
+        self.uses: dict = {}
+
+    def add_use(self, params) -> Optional[int]:
+        """Forward side: announce one more backward contribution for this parameter group.
+        Returns the key to deliver with, or None when the group is not (wholly) in the plan."""
+        ps = [p for p in params if p.requires_grad]
+        if not ps or any(id(p) not in self.plan.view_of for p in ps):
+            return None
+        if any(p.grad is None or p.grad.data_ptr() != self.plan.view_of[id(p)].data_ptr() for p in ps):
+            return None
+        key = id(ps[0])
+        self.uses[key] = self.uses.get(key, 0) + 1
+        return key
+
+    @torch.no_grad()
+    def deliver(self, key: int, params, grads) -> None:
+        """Backward side, on the stream the gradients were computed on: accumulate them into the
+        arena views; after the group's last use, count them in (which sends full buckets)."""
+        from . import ops
+        for p, g in zip(params, grads):
+            if g is None or not p.requires_grad:
+                continue
+            v = self.plan.view_of[id(p)]
+            if v.is_cuda:
+                n = v.numel()
+                ops.axpby_rows(v.view(1, n), v.view(1, n), g.contiguous().view(1, n), sa=1.0, sb=1.0)
+            else:
+                v.add_(g)
+            self.plan.touched.add(id(p))
+        self.uses[key] -= 1
+        if self.uses[key] == 0:
+            for p in params:
+                if id(p) in self.plan.touched:
+                    self.reducer._on_grad(p)
+
+
 class _Bucket:
-    def __init__(self, params: List[torch.nn.Parameter]):
+    def __init__(self, params: List[torch.nn.Parameter], index: int = 0):
         self.params = params
+        self.index = index
+        self.streams: dict = {}
         n = sum(p.numel() for p in params)
         self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
         self.views, off = [], 0
@@ -250,24 +321,32 @@ class _Bucket:
 
 
 class _Plan:
-    def __init__(self, params: List[torch.nn.Parameter], limit: int):
+    def __init__(self, params: List[torch.nn.Parameter], limit: int, gid: Optional[dict] = None):
         self.buckets: List[_Bucket] = []
         groups: dict = {}
-        for p in reversed(params):  # backward order; one arena per (dtype, device)
-            groups.setdefault((p.dtype, p.device), []).append(p)
+        gid = gid or {}
+        # backward order; one arena per (dtype, device) and per delivery group
+        for p in reversed(params):
+            groups.setdefault((p.dtype, p.device, gid.get(id(p), -1)), []).append(p)
         for plist in groups.values():
             for chunk in GradReducer._buckets(plist, limit):
-                self.buckets.append(_Bucket(chunk))
+                self.buckets.append(_Bucket(chunk, len(self.buckets)))
         self.bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        self.view_of = {id(p): v for b in self.buckets for p, v in zip(b.params, b.views)}
         self.exchange = False
         self.bytes = 0
+        self.sent_order: List[int] = []
+        self.touched: set = set()
 
     @torch.no_grad()
     def arm(self) -> None:
         self.bytes = 0
+        self.sent_order = []
+        self.touched = set()
         for b in self.buckets:
             b.flat.zero_()
             b.fired.clear()
+            b.streams = {}
             b.sent = False
             for p, v in zip(b.params, b.views):
                 p.grad = v

@@ -65,6 +65,32 @@ class _Blk:
 
 _APPLY_GRAD = True
 
+# Set by dist.GradReducer.prepare while a gradient exchange is armed (None otherwise): coarse nodes
+# whose backward runs several independent launch lanes hand a finished lane's parameter gradients
+# over through it (dist._Sink) instead of returning them when the whole node is done.
+GRAD_SINK = None
+
+
+def sink_register(params):
+    """Forward side of deliver_grads: returns (sink, key) or None."""
+    sink = GRAD_SINK
+    if sink is None or not _APPLY_GRAD:
+        return None
+    key = sink.add_use(params)
+    return None if key is None else (sink, key)
+
+
+def deliver_grads(ticket, params, grads):
+    """Backward side: with a ticket from sink_register, accumulate `grads` into the armed arenas on
+    the current stream and return Nones for autograd; without one, return `grads` unchanged."""
+    if ticket is None:
+        return grads
+    sink, key = ticket
+    if GRAD_SINK is not sink:       # the exchange this forward announced itself to is over
+        return grads
+    sink.deliver(key, params, grads)
+    return [None] * len(grads)
+
 
 class GradAwareFunction(torch.autograd.Function):
     """autograd.Function whose forward can tell whether a backward can follow: forward itself always
@@ -635,6 +661,10 @@ class ModelEvalFn(GradAwareFunction):
             saved.append(sv)
         lanes.join()
         if keep:
+            # per-branch gradient hand-over to an armed exchange (dist._Sink)
+            ctx.tickets = [sink_register(list(flat[sum(nparams[:i]): sum(nparams[:i + 1])]))
+                           for i in range(nb)]
+            ctx.flat = flat
             ctx.saved = saved
             ctx.views = views
             ctx.lens = lens_list
@@ -662,12 +692,16 @@ class ModelEvalFn(GradAwareFunction):
             wrow = None if ctx.wbranch is None else ctx.wbranch[i]
             with lanes.lane(i):
                 g_cp = ops.zeros(cproj.shape[0], cproj.shape[1], device=dev) if need_gc else None
-                g_flat += _branch_backward(ctx.views[i], ctx.metas[i], ctx.saved[i], (B, T), cproj,
-                                           g_pred, wrow, ctx.bscale, ctx.lens[i], g_x, i > 0, g_cp,
-                                           need_gx, lanes)
+                gl = _branch_backward(ctx.views[i], ctx.metas[i], ctx.saved[i], (B, T), cproj,
+                                      g_pred, wrow, ctx.bscale, ctx.lens[i], g_x, i > 0, g_cp,
+                                      need_gx, lanes)
+                # branch i is done on its lane: its bucket may leave while the others compute
+                off = sum(ctx.nparams[:i])
+                g_flat += deliver_grads(ctx.tickets[i], list(ctx.flat[off: off + ctx.nparams[i]]), gl)
             g_cprojs.append(g_cp)
         lanes.join()
         ctx.saved = None
+        ctx.flat = None
         return tuple([g_x, None, None, None, None, None, None] + g_cprojs + g_flat)
 
 
@@ -806,3 +840,32 @@ class FmLossFn(torch.autograd.Function):
         ops.axpby_rows(flat, flat, None, ca=g.reshape(1).contiguous())
         ctx.saved = None
         return g_err, None, None, None, None, None, None, None, None, None, None
+
+
+class MseLossFn(torch.autograd.Function):
+    """Unweighted stage-1 loss (generator.py:181-184, spec_scaling_loss=False): the masked mean of
+    (pred - ref)^2 over the valid samples of every item."""
+
+    @staticmethod
+    def forward(ctx, pred, ref, lens_cpu):
+        dev = pred.device
+        B, T = pred.shape
+        if lens_cpu is None:
+            lens, n = None, B * T
+        else:
+            assert T == max(int(l) for l in lens_cpu)
+            lens = torch.tensor([int(l) for l in lens_cpu], dtype=torch.int32, device=dev)
+            n = sum(int(l) for l in lens_cpu)
+        loss = ops.zeros(1, device=dev)
+        g_err = ops.empty(B, T, device=dev)
+        ops.masked_mse(loss, g_err, pred.contiguous(), ref.contiguous(), B, T, lens, 1.0 / n)
+        ctx.saved = g_err
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g_err = ctx.saved
+        flat = g_err.view(1, -1)
+        ops.axpby_rows(flat, flat, None, ca=g.reshape(1).contiguous())   # no host sync
+        ctx.saved = None
+        return g_err, None, None

@@ -224,6 +224,11 @@ class MPDLossFn(torch.autograd.Function):
         ctx.saved = saved
         ctx.params = params
         ctx.meta = (B, T, train_disc, tuple(periods))
+        # D-step: each period discriminator's gradients are handed to an armed exchange as soon as
+        # its launch lane has finished its backward (dist._Sink)
+        from .fused import sink_register
+        ctx.tickets = [sink_register(list(params[12 * i: 12 * i + 12])) if train_disc else None
+                       for i in range(len(periods))]
         return losses[0], losses[1]
 
     @staticmethod
@@ -351,7 +356,8 @@ class MPDLossFn(torch.autograd.Function):
                 lanes.chain_enter()  # g_fake is accumulated period after period
                 ops.period_fold_bwd(g_fake, g, B, T, p, hs[0], True)
                 lanes.chain_leave()
-            pgrads += grads_p
+            from .fused import deliver_grads
+            pgrads += deliver_grads(ctx.tickets[i], list(params[12 * i: 12 * i + 12]), grads_p)
         lanes.join()
         ctx.saved = None
         return tuple([None, g_fake, None, None] + pgrads)

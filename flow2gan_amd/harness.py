@@ -68,6 +68,22 @@ def compute_loss_stage2(audio: Tensor, audio_lens: Tensor, model: nn.Module,
     return loss, info
 
 
+def grad_groups(gan: nn.Module, disc: bool):
+    """Parameter groups whose gradients become final together (GradReducer.prepare(groups=...)):
+    G-step: one per Fourier branch (the condition encoder and everything else accumulate over all
+    branches and close last); D-step: one per period discriminator."""
+    from . import fused
+    try:
+        if disc:
+            return [list(d.parameters()) for d in gan.discriminator[0].discriminators]
+        gen = gan.generator if hasattr(gan, "generator") else gan
+        # exactly the parameters ModelEvalFn hands over per branch (the per-branch condition path
+        # belongs to CondPathFn, whose backward runs after every branch)
+        return [fused.branch_params(e) for e in gen.estimators]
+    except (AttributeError, TypeError, IndexError):
+        return None          # not this package's GAN: one group, autograd hooks only
+
+
 @dataclass
 class GanStepper:
     """Batch schedule of finetune.py:569-631 around compute_loss_stage2."""
@@ -87,7 +103,9 @@ class GanStepper:
         self.batch_idx_train += 1
         disc = self.train_disc
         params = list((self.gan.discriminator if disc else self.gan.generator).parameters())
-        self.reducer.prepare(params)  # zero grads; buckets leave from autograd hooks during backward
+        # zero grads; a Fourier branch's / period discriminator's bucket leaves when its launch lane
+        # has finished (fused.deliver_grads), everything else from autograd hooks during backward
+        self.reducer.prepare(params, groups=grad_groups(self.gan, disc))
         loss, info = compute_loss_stage2(audio, audio_lens, self.gan, self.cond_module,
                                          self.n_timesteps, self.scales, True, disc)
         loss.backward()

@@ -8,7 +8,7 @@ and parity tests, computed on the same HIP kernels without autograd.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -23,9 +23,10 @@ class DiscriminatorP(nn.Module):
     """reference discriminators.py:52-107."""
 
     def __init__(self, period: int, in_channels: int = 1, kernel_size: int = 5, stride: int = 3,
-                 lrelu_slope: float = 0.1):
+                 lrelu_slope: float = 0.1, num_embeddings: Optional[int] = None):
         super().__init__()
         assert (in_channels, kernel_size, stride, lrelu_slope) == (1, 5, 3, 0.1)
+        _no_embeddings(num_embeddings)
         self.period = period
         pad = (kernel_size // 2, 0)
         self.convs = nn.ModuleList([
@@ -45,8 +46,9 @@ class DiscriminatorP(nn.Module):
         return p + [self.conv_post.weight, self.conv_post.bias]
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, cond_embedding_id: Optional[torch.Tensor] = None):
         """x (B, T) -> (score (B, H*p), fmap list of (B, C, H, p))."""
+        _no_embeddings(cond_embedding_id)
         B = x.shape[0]
         st = FD._mpd_forward_one(x.contiguous(), self.period, self._params())
         p = self.period
@@ -61,8 +63,19 @@ class DiscriminatorP(nn.Module):
         return torch.flatten(sc, 1, -1), fmap
 
 
+def _no_embeddings(v) -> None:
+    """The conditional variant (an embedding table indexed by `bandwidth_id`,
+    discriminators.py:73-75,97-99,180-181,210-212) is never built by GAN (gan.py:40-42); the
+    arguments are accepted with the reference's default and refused otherwise."""
+    if v is not None:
+        raise NotImplementedError("flow2gan_amd builds the non-conditional discriminators only "
+                                  "(num_embeddings=None, bandwidth_id=None), as GAN does")
+
+
 class _MultiD(nn.Module):
-    def forward(self, y: torch.Tensor, y_hat: torch.Tensor):
+    def forward(self, y: torch.Tensor, y_hat: torch.Tensor,
+                bandwidth_id: Optional[torch.Tensor] = None):
+        _no_embeddings(bandwidth_id)
         y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
         for d in self.discriminators:
             y_d_r, fmap_r = d(y)
@@ -77,8 +90,10 @@ class _MultiD(nn.Module):
 class MultiPeriodDiscriminator(_MultiD):
     """reference discriminators.py:18-49."""
 
-    def __init__(self, periods: Tuple[int, ...] = (2, 3, 5, 7, 11)):
+    def __init__(self, periods: Tuple[int, ...] = (2, 3, 5, 7, 11),
+                 num_embeddings: Optional[int] = None):
         super().__init__()
+        _no_embeddings(num_embeddings)
         self.periods = tuple(periods)
         self.discriminators = nn.ModuleList([DiscriminatorP(period=p) for p in periods])
 
@@ -86,9 +101,10 @@ class MultiPeriodDiscriminator(_MultiD):
 class DiscriminatorR(nn.Module):
     """reference discriminators.py:143-219."""
 
-    def __init__(self, window_length: int, channels: int = 32, hop_factor: float = 0.25,
-                 bands=FD.MRD_BANDS):
+    def __init__(self, window_length: int, num_embeddings: Optional[int] = None,
+                 channels: int = 32, hop_factor: float = 0.25, bands=FD.MRD_BANDS):
         super().__init__()
+        _no_embeddings(num_embeddings)
         assert channels == FD.MRD_CH and hop_factor == 0.25 and tuple(bands) == FD.MRD_BANDS
         self.window_length = window_length
         self.hop_factor = hop_factor
@@ -116,8 +132,9 @@ class DiscriminatorR(nn.Module):
         return p + [self.conv_post.weight, self.conv_post.bias]
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor):
+    def forward(self, x: torch.Tensor, cond_embedding_id: Optional[torch.Tensor] = None):
         """x (B, T) -> (score (B, 1, frames, freq), fmap list of (B, C, frames, freq))."""
+        _no_embeddings(cond_embedding_id)
         B = x.shape[0]
         st = FD._mrd_forward_one(x.contiguous(), self.window_length, self._params())
         Ft, Wcat, C = st["Ft"], st["Wcat"], FD.MRD_CH
@@ -139,7 +156,9 @@ class DiscriminatorR(nn.Module):
 class MultiResolutionDiscriminator(_MultiD):
     """reference discriminators.py:110-141."""
 
-    def __init__(self, fft_sizes: Tuple[int, ...] = (2048, 1024, 512)):
+    def __init__(self, fft_sizes: Tuple[int, ...] = (2048, 1024, 512),
+                 num_embeddings: Optional[int] = None):
         super().__init__()
+        _no_embeddings(num_embeddings)
         self.fft_sizes = tuple(fft_sizes)
         self.discriminators = nn.ModuleList([DiscriminatorR(window_length=w) for w in fft_sizes])

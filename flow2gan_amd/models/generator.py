@@ -77,11 +77,9 @@ class BaseAudioGenerator(nn.Module):
         assert len(conv_kernel_sizes) == self.num_branches
         assert len(num_layers) == self.num_branches
         # Every named config (config.py:31-95) uses the defaults; the other switches of the
-        # reference's constructor are implemented as well, except spec_scaling_loss=False (the
-        # unweighted spectral loss of generator.py:191-192), which is rejected loudly.
-        if not spec_scaling_loss:
-            raise ValueError("flow2gan_amd implements the scaled spectral loss only "
-                             "(spec_scaling_loss=True, as in every named config)")
+        # reference's constructor (use_cond_encoder, pred_x1, branch_reduction, spec_scaling_loss)
+        # are implemented as well and pinned by reference vectors (tests/golden/tiny_switches.npz,
+        # tiny_mse.npz).
         if branch_reduction not in ("mean", "sum"):
             raise ValueError(f"Unsupported branch_reduction: {branch_reduction}")
         self.sampling_rate = sampling_rate
@@ -198,6 +196,8 @@ class BaseAudioGenerator(nn.Module):
     def compute_loss(self, pred: Tensor, ref: Tensor, audio_lens: Tensor,
                      gt_audio: Optional[Tensor] = None) -> Tensor:
         """generator.py:172-200 (ref is gt_audio for the x1-prediction objective)."""
+        if not self.spec_scaling_loss:     # generator.py:181-184: masked mean squared error
+            return fused.MseLossFn.apply(pred, ref, _lens_list(audio_lens))
         ls = self.loss_spec
         return fused.FmLossFn.apply(pred, ref, _lens_list(audio_lens), ls.n_fft, ls.hop_length,
                                     ls.fb, self.loss_eps, self.loss_power, self.loss_scale_min,

@@ -41,21 +41,60 @@ def pad4(n: int) -> int:
 # ------------------------------------------------------------------ derived-weight cache
 # Re-laid copies of parameters (transposes for data gradients, window-major conv weights) are
 # rebuilt only when the parameter changed: keyed on the parameter object (weakly), its version
-# counter (every in-place torch write bumps it) and WEIGHT_EPOCH, which writers that go through
-# raw pointers (the HIP optimizer) bump.  In a D-step the generator's copies survive, and vice versa.
+# counter (every in-place torch write bumps it) and an epoch that writers going through RAW
+# POINTERS must bump: `bump_weight_epoch(params)` for exactly the tensors they wrote (the HIP
+# optimizer does this for its own parameters, so a D-step leaves the generator's copies alone and
+# vice versa), `bump_weight_epoch()` for "anything may have changed" (e.g. after `p.data.copy_()`,
+# which does not move the version counter of `p`).  Cached copies of copies (`_f2g_const` owners:
+# the split / bf16 image of a transposed weight, DFT and filterbank tables) are immutable by
+# construction -- when their source changes a NEW tensor replaces them -- and carry no epoch.
 import weakref
 
 WEIGHT_EPOCH = 0
+_OWNER_EPOCH: dict = {}
 _DERIVED: dict = {}
 
 
-def bump_weight_epoch() -> None:
+def bump_weight_epoch(params=None) -> None:
+    """Tell the derived-weight cache that parameters were written behind autograd's back."""
     global WEIGHT_EPOCH
-    WEIGHT_EPOCH += 1
+    if params is None:
+        WEIGHT_EPOCH += 1
+        return
+    for t in params:
+        owner = t._base if t._base is not None else t
+        _OWNER_EPOCH[id(owner)] = _OWNER_EPOCH.get(id(owner), 0) + 1
+
+
+def _stamp(owner) -> tuple:
+    if getattr(owner, "_f2g_const", False) and not isinstance(owner, torch.nn.Parameter):
+        return (owner._version,)
+    return (owner._version, WEIGHT_EPOCH, _OWNER_EPOCH.get(id(owner), 0))
+
+
+# While a list is installed here (streaming.ChunkRunner during its warm-up and capture), every
+# cached copy handed out is appended to it: a captured HIP graph holds raw pointers into those
+# copies, so its owner must keep them alive for as long as it may replay.
+DERIVED_KEEP = None
+
+
+def weights_signature(params) -> tuple:
+    """Changes whenever one of `params` may have changed, through autograd-visible writes (version
+    counters) or raw-pointer writers (the epochs above)."""
+    ps = list(params)
+    return (WEIGHT_EPOCH, tuple(p._version for p in ps),
+            tuple(_OWNER_EPOCH.get(id(p), 0) for p in ps))
 
 
 def derived(t, tag, build):
     """build(t) cached per (tensor object or its view base, tag) until the tensor changes."""
+    out = _derived(t, tag, build)
+    if DERIVED_KEEP is not None:
+        DERIVED_KEEP.append(out)
+    return out
+
+
+def _derived(t, tag, build):
     import os
     if os.environ.get("F2G_WEIGHT_CACHE", "1") == "0":
         return build(t)
@@ -63,11 +102,15 @@ def derived(t, tag, build):
     oid = id(owner)          # (tensors compare element-wise: never use them as dictionary keys)
     ent = _DERIVED.get(oid)
     if ent is None or ent[0]() is not owner:
-        ent = (weakref.ref(owner, lambda _r, oid=oid: _DERIVED.pop(oid, None)), {})
+        def _gone(_r, oid=oid):
+            _DERIVED.pop(oid, None)
+            _OWNER_EPOCH.pop(oid, None)
+        ent = (weakref.ref(owner, _gone), {})
         _DERIVED[oid] = ent
+        _OWNER_EPOCH.pop(oid, None)       # a recycled id: the epoch of a dead tensor
     slot = ent[1]
     key = (tag, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
-    stamp = (owner._version, WEIGHT_EPOCH)
+    stamp = _stamp(owner)
     hit = slot.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
@@ -83,11 +126,18 @@ _DERIVED_MULTI: dict = {}
 
 def derived_multi(ts, tag, build):
     """build(ts) cached for a LIST of parameters (stacked copies) until one of them changes."""
+    out = _derived_multi(ts, tag, build)
+    if DERIVED_KEEP is not None:
+        DERIVED_KEEP.append(out)
+    return out
+
+
+def _derived_multi(ts, tag, build):
     import os
     if os.environ.get("F2G_WEIGHT_CACHE", "1") == "0":
         return build(ts)
     key = (tag,) + tuple(id(t) for t in ts)
-    stamp = tuple(t._version for t in ts) + (WEIGHT_EPOCH,)
+    stamp = tuple(_stamp(t._base if t._base is not None else t) for t in ts)
     ent = _DERIVED_MULTI.get(key)
     if ent is not None and ent[0] == stamp and all(r() is t for r, t in zip(ent[2], ts)):
         return ent[1]
@@ -922,6 +972,11 @@ def spec_power_bwd(gpacked, gout, packed, rows, nb, power):
 def fm_spec_loss(loss, g_err, s_err, s_gt, B, F, nf, lens, eps, power, lo, hi, inv_denom):
     call("f2g_fm_spec_loss", ptr(loss), ptr(g_err), ptr(s_err), ptr(s_gt), B, F, nf, ptr(lens),
          float(eps), float(power), float(lo), float(hi), float(inv_denom))
+
+
+def masked_mse(loss, g_err, pred, ref, B, T, lens, inv_denom):
+    call("f2g_masked_mse", ptr(loss), ptr(g_err), ptr(pred), ptr(ref), B, T, ptr(lens),
+         float(inv_denom))
 
 
 def l1_loss(loss, gb, a, b, rows, cols, ld, w, clip=0.0, wdev=None, loss_offset=0, off=0):

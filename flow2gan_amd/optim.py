@@ -161,9 +161,10 @@ class ScaledAdam(Optimizer):
             self._steps[gi] += 1
         call("f2g_sadam_update", tab, chunks, plan["nchunks"], plan["coef"].data_ptr())
         # the parameters were written through raw pointers (no autograd version bump): tell the
-        # derived-weight cache (transposes, window-major conv weights) that they changed
+        # derived-weight cache (transposes, window-major conv weights) that THESE tensors changed
+        # (the other network's cached copies stay valid)
         from . import ops
-        ops.bump_weight_epoch()
+        ops.bump_weight_epoch([p for p, _ in plan["tensors"]])
         return loss
 
     # ---------------------------------------------------------------- introspection / checkpoints

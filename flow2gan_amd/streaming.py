@@ -60,13 +60,21 @@ class ChunkRunner:
     pools), then captures the launch sequence on a side stream into `torch.cuda.CUDAGraph`
     (hipGraph on ROCm); later calls copy the condition (and noise) into the static input buffers
     and replay.  The returned tensor is the graph's static output: consume or copy it before the
-    next call with the same shape."""
+    next call with the same shape.
+
+    Weights: the forward reads cached re-laid copies of the parameters (ops.derived: padded /
+    stacked / transposed / bf16 images), and a captured graph holds raw pointers into them.  Every
+    graph entry therefore (a) keeps the copies it captured alive and (b) carries the weights'
+    signature (autograd version counters + the raw-pointer writers' epochs, ops.weights_signature);
+    when the signature has moved -- an optimizer step, load_state_dict, periodic evaluation during
+    training -- the shape is captured again instead of replaying against stale copies."""
 
     def __init__(self, model, n_timesteps: int = 1, clamp_pred: bool = True):
         self.model = model
         self.n_timesteps = n_timesteps
         self.clamp_pred = clamp_pred
         self.graphs: Dict[Tuple[int, int, int], tuple] = {}
+        self.recaptures = 0
 
     @torch.no_grad()
     def __call__(self, cond: Tensor, noise: Optional[Tensor] = None) -> Tensor:
@@ -74,20 +82,30 @@ class ChunkRunner:
         T = cond.size(2) * self.model.mel_hop_length
         if noise is None:  # the model's own draw (generator.py:315), made outside the graph
             noise = torch.randn(cond.size(0), T, device=cond.device) * self.model.init_noise_scale
+        from . import ops
+        sig = ops.weights_signature(self.model.parameters())
         entry = self.graphs.get(key)
+        if entry is not None and entry[4] != sig:
+            entry = None                      # the weights moved since this shape was captured
+            self.recaptures += 1
         if entry is None:
             static_c, static_n = cond.clone(), noise.clone()
             kw = dict(n_timesteps=self.n_timesteps, clamp_pred=self.clamp_pred)
-            self.model.infer(cond=static_c, noise=static_n, **kw)  # warm-up, eager
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # the launch lanes fork / join with events, which the capture records as parallel
-            # branches of the graph
-            with torch.cuda.graph(graph):
-                out = self.model.infer(cond=static_c, noise=static_n, **kw)
-            entry = (graph, static_c, static_n, out)
+            keep: list = []
+            was, ops.DERIVED_KEEP = ops.DERIVED_KEEP, keep
+            try:
+                self.model.infer(cond=static_c, noise=static_n, **kw)  # warm-up, eager
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                # the launch lanes fork / join with events, which the capture records as parallel
+                # branches of the graph
+                with torch.cuda.graph(graph):
+                    out = self.model.infer(cond=static_c, noise=static_n, **kw)
+            finally:
+                ops.DERIVED_KEEP = was
+            entry = (graph, static_c, static_n, out, sig, keep)
             self.graphs[key] = entry
-        graph, static_c, static_n, out = entry
+        graph, static_c, static_n, out = entry[:4]
         static_c.copy_(cond)
         static_n.copy_(noise)
         graph.replay()

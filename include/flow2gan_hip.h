@@ -331,6 +331,11 @@ int f2g_spec_power_bwd(float* gpacked, int64_t ldp, const float* gout, int64_t l
 int f2g_fm_spec_loss(float* loss, float* g_err, const float* s_err, const float* s_gt, int32_t B,
                      int32_t F, int32_t n_filt, const int32_t* lens, float eps, float power,
                      float lo, float hi, float inv_denom, f2g_stream_t stream);
+/* Unweighted stage-1 loss (generator.py:181-184, spec_scaling_loss=False): with mask[b,t] = t < lens[b]
+ * (lens NULL = all ones), loss += inv_denom * sum mask * (pred - ref)^2 and (optional)
+ * g_err = 2 * inv_denom * mask * (pred - ref); the caller passes inv_denom = 1 / sum(mask). */
+int f2g_masked_mse(float* loss, float* g_err, const float* pred, const float* ref, int32_t B,
+                   int32_t T, const int32_t* lens, float inv_denom, f2g_stream_t stream);
 /* L1 terms over a (rows, cols) view with row stride ld (a, b, gb share the layout):
  *   loss += w * sum |f(a) - f(b)|,  f = log(max(., clip)) if clip > 0 (gan.py:89-99 with
  *   utils.py:221-232) else identity (gan.py:77-87);  gb = -(w * wdev[0]) * sign(.) * f'(b).

@@ -56,7 +56,11 @@ def pytest_runtest_protocol(item, nextitem):
     _say(f"[f2g] start {item.nodeid}")
     t0 = time.time()
     # the traceback goes to fd 2 itself (sys.__stderr__), not to pytest's capture file
-    faulthandler.dump_traceback_later(TEST_TIMEOUT, exit=True, file=sys.__stderr__)
+    # multi-process tests bound every worker group themselves (run_workers(timeout=...), up to
+    # 60 + 150 + 150 s in a row): their watchdog sits above that sum, so that it can only fire
+    # when the bounded launcher itself hangs and never orphans workers of a slow but healthy run
+    limit = max(TEST_TIMEOUT, 480.0) if item.get_closest_marker("multiproc") else TEST_TIMEOUT
+    faulthandler.dump_traceback_later(limit, exit=True, file=sys.__stderr__)
     try:
         yield
     finally:

@@ -240,13 +240,13 @@ def test_concurrent_lanes_match_serial_launch_order(f2g, golden, monkeypatch):
                 assert relerr(got[key][k], v) < 2e-4, (key, k, relerr(got[key][k], v))
 
 
-@pytest.mark.parametrize("model_name,Tn,rep", [("mel_24k_base", 6000, 32),
+@pytest.mark.parametrize("model_name,Tn,rep", [("mel_24k_base", 24000, 32),
                                                ("mel_44k_128band_512x_base", 44100, 16)],
-                         ids=["24k_B64", "44k_B32_T44100"])
+                         ids=["24k_B64_T24000", "44k_B32_T44100"])
 def test_full_width_gan_steps_vs_oracle_then_full_batch(f2g, monkeypatch, model_name, Tn, rep):
     """Full-width GAN stage: D-step and G-step losses + selected gradients against the CPU oracle
-    at B=2, then at the BASELINE batch (B=64 for mel_24k_base; B=32 x 1 s of 44.1 kHz audio for
-    mel_44k_128band_512x_base = config 5) as copies of that batch: every loss is a batch mean and
+    at B=2, then at the BASELINE batch (B=64 x 1 s for mel_24k_base = config 4's per-GPU shape;
+    B=32 x 1 s of 44.1 kHz audio for mel_44k_128band_512x_base = config 5) as copies of that batch: every loss is a batch mean and
     every sample is independent, so losses and gradients must not move."""
     import flow2gan_oracle as O
     from flow2gan_amd.models.config import get_generator_config

@@ -356,6 +356,39 @@ def test_plain_bf16_throughput_mode_stays_close_to_fp32(f2g, golden):
     assert 1e-5 < rel < 2e-2, rel
 
 
+def test_plain_bf16_inference_at_the_baseline_batch(f2g):
+    """BASELINE config 2's own shape and arithmetic: 4-step bf16 inference at B = 64 x 94 frames.
+    The samples of a batch are independent, so a batch of 32 copies of two items must reproduce
+    the B = 2 result row for row (the only difference allowed: tile / split choices of the GEMMs),
+    and the B = 2 result must sit at bf16 distance from the exact-fp32 path."""
+    from flow2gan_amd import ops
+    from flow2gan_amd.models.config import get_generator_config
+    torch.manual_seed(1234)
+    m = f2g.MelAudioGenerator(**get_generator_config("mel_24k_base")).to(DEV).eval()
+    rg = torch.Generator().manual_seed(12)
+    mel = (torch.randn(2, 100, 94, generator=rg) * 1.5 - 4.0).to(DEV)
+    noise = (0.1 * torch.randn(2, 94 * 256, generator=rg)).to(DEV)
+    was = ops.GEMM_PRECISION
+    try:
+        ops.set_gemm_precision("fp32")
+        with torch.no_grad():
+            y32 = m.infer(mel, None, 4, True, noise=noise).clone()
+        ops.set_gemm_precision("bf16")
+        with torch.no_grad():
+            y2 = m.infer(mel, None, 4, True, noise=noise).clone()
+            y64 = m.infer(mel.repeat(32, 1, 1), None, 4, True, noise=noise.repeat(32, 1)).clone()
+    finally:
+        ops.GEMM_PRECISION = was
+    sig = float(y32.double().pow(2).mean().sqrt())
+    e2 = rms(y2, y32)
+    assert 1e-6 < e2 < 0.05 * sig, (e2, sig)
+    assert tuple(y64.shape) == (64, 94 * 256)
+    # fp32 accumulation order may differ between the two grids (split-K / tile shape), which can
+    # move single activations across a bf16 rounding boundary: well below the mode's own error
+    e64 = rms(y64, y2.repeat(32, 1))
+    assert e64 < 0.3 * e2 + 1e-7, (e64, e2)
+
+
 def test_non_default_constructor_switches_against_reference_vectors(f2g, golden, monkeypatch):
     """use_cond_encoder=False, pred_x1=False (velocity objective), branch_reduction="sum"
     (generator.py:86-97,165-168,218,263; unused by the named configs): stage-1 loss, every

@@ -193,6 +193,64 @@ def test_overlapped_grad_reducer_world_size_2_gloo(tmp_path):
     assert torch.load(tmp_path / "ov0.pt") and torch.load(tmp_path / "ov1.pt")
 
 
+def _sink_worker(rank, world, port, out):
+    """Per-lane gradient hand-over (dist._Sink, the mechanism behind fused.deliver_grads): three
+    'branch' groups deliver inside one backward, in the order their lanes finish, and a 'rest'
+    group arrives through autograd hooks afterwards.  Buckets must leave in exactly that order --
+    branch buckets before the rest -- and every rank must end with the mean gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from flow2gan_amd import dist as fdist
+    from flow2gan_amd import fused
+    fdist.setup_dist(rank, world, backend="gloo")
+    torch.manual_seed(0)
+    branches = [[torch.nn.Parameter(torch.randn(n)) for n in sizes]
+                for sizes in ((40, 7), (30,), (20, 5, 1))]
+    rest = [torch.nn.Parameter(torch.randn(9)), torch.nn.Parameter(torch.randn(4))]
+    params = rest + [p for b in branches for p in b]          # model order: rest first
+    red = fdist.GradReducer(bucket_mb=1.0)
+    ok = True
+    for it in range(2):
+        red.prepare(params, groups=branches)
+        sink = fused.GRAD_SINK
+        ok = ok and sink is not None
+        plan = red._active
+        # forward side: branch 0 is used TWICE in this step (two model evaluations), the others once
+        keys = [sink.add_use(b) for b in branches]
+        keys0b = sink.add_use(branches[0])
+        ok = ok and all(k is not None for k in keys) and keys0b == keys[0]
+        grad_of = lambda p, use: torch.full_like(p, float(rank + 1) * (use + 1))
+        # backward side: evaluation 2 (all three lanes), then evaluation 1 (branch 0 again)
+        for i in (2, 1, 0):
+            sink.deliver(keys[i], branches[i], [grad_of(p, 0) for p in branches[i]])
+        sent_before_second_use = list(plan.sent_order)
+        sink.deliver(keys0b, branches[0], [grad_of(p, 1) for p in branches[0]])
+        sent_by_branches = list(plan.sent_order)
+        # the rest arrives through the ordinary autograd hooks
+        loss = sum((p * float(rank + 1)).sum() for p in rest)
+        loss.backward()
+        order = list(plan.sent_order)
+        red.finish()
+        ok = ok and fused.GRAD_SINK is None
+        b_of = lambda p: plan.bucket_of[id(p)].index
+        ok = ok and sent_before_second_use == [b_of(branches[2][0]), b_of(branches[1][0])]
+        ok = ok and sent_by_branches == sent_before_second_use + [b_of(branches[0][0])]
+        ok = ok and order[-1] == b_of(rest[0]) and len(order) == 4
+        ok = ok and len({b_of(p) for b in branches for p in b} | {b_of(rest[0])}) == 4
+        for i, b in enumerate(branches):
+            want = 1.5 * (3.0 if i == 0 else 1.0)     # mean over ranks of (rank+1) * sum of uses
+            ok = ok and all(torch.allclose(p.grad, torch.full_like(p, want)) for p in b)
+        ok = ok and all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in rest)
+    torch.save(ok, os.path.join(out, f"sink{rank}.pt"))
+    fdist.cleanup_dist()
+
+
+def test_branch_buckets_leave_before_the_rest_world_size_2_gloo(tmp_path):
+    from _mp import run_workers
+    run_workers("test_host_side", "_sink_worker", 2, str(tmp_path), timeout=120.0)
+    assert torch.load(tmp_path / "sink0.pt") and torch.load(tmp_path / "sink1.pt")
+
+
 def test_gan_stepper_schedule_matches_reference():
     """finetune.py:569-631: D-only until gen_start_batch_idx, then D/G alternation on new batches;
     only the stepped sub-model gets gradients; reference loss weights."""

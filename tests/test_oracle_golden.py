@@ -141,3 +141,59 @@ def test_scaled_adam_oracle_matches_reference_vectors(golden, case):
                 err = float((params[i] - want).abs().max()) / (float(want.abs().max()) + 1e-12)
                 assert err < 2e-6, (case, k + 1, i, err)
     assert (clipped > 0) == (clip > 0)   # the trajectory exercises the clipping branch
+
+
+def test_full_test_mel_4_step_inference(golden):
+    """Oracle vs the reference's test_from_mel.py flow on the full 205-frame test mel
+    (tests/golden/full_testmel.npz, oracle/make_golden_r3.py)."""
+    g = golden("full_testmel")
+    torch.manual_seed(int(g["seed"]))
+    m = O.build_generator("mel_24k_base").eval()
+    assert digest(m.state_dict()) == bytes(g["digest"]).decode()
+    noise = 0.1 * torch.randn(1, 205 * 256, generator=torch.Generator().manual_seed(int(g["noise_seed"])))
+    with torch.no_grad():
+        y = m.infer(T(g["mel"]), None, 4, True, noise=noise)
+    assert float((y - T(g["audio_n4"])).pow(2).mean().sqrt()) < 1e-6
+
+
+def test_training_trajectory_oracle(golden, monkeypatch):
+    """Oracle GAN + oracle ScaledAdam / Eden2 against the reference's recorded six-step D / G
+    trajectory (tests/golden/tiny_traj.npz): finetune.py:569-631 + optim.py:451-507 together."""
+    from scaled_adam_oracle import ScaledAdamOracle, eden2_lr
+    g = golden("tiny_traj")
+    gen = tiny_from(g)
+    gen.branch_dropout = 0.0
+    torch.manual_seed(int(g["d_seed"]))
+    gan = O.GAN(gen)
+    monkeypatch.setattr(random, "random", lambda: 0.0)
+    lr_g, lr_d, lrb_g, lrb_d = (float(v) for v in g["hyper"])
+    pg = [p for _, p in gan.generator.named_parameters()]
+    pd = [p for _, p in gan.discriminator.named_parameters()]
+    og = ScaledAdamOracle([p.data for p in pg], lr=lr_g, clipping_scale=2.0)
+    od = ScaledAdamOracle([p.data for p in pd], lr=lr_d, clipping_scale=2.0)
+    nd = ng = 0
+    k = 0
+    while f"s{k}/audio" in g:
+        disc = bool(int(g[f"s{k}/train_disc"]))
+        gan.zero_grad()
+        ls = gan(T(g[f"s{k}/mel"]), T(g[f"s{k}/audio"]), T(g[f"s{k}/lens"]), 1, disc,
+                 noise=T(g[f"s{k}/noise"]))
+        assert np.allclose([float(x) for x in ls], g[f"s{k}/losses"], rtol=2e-6, atol=2e-6), k
+        total = sum(w * l for w, l in zip((1.0, 0.1) if disc else (1.0, 0.1, 1.0, 0.1, 45.0), ls))
+        total.backward()
+        if disc:
+            od.g["lr"] = lr_d if nd == 0 else eden2_lr(lr_d, nd, lrb_d, 500.0, 0.1)   # (Eden2 sets the lr in step_batch)
+            od.step([p.grad for p in pd])
+            nd += 1
+        else:
+            og.g["lr"] = lr_g if ng == 0 else eden2_lr(lr_g, ng, lrb_g, 500.0, 0.1)
+            og.step([p.grad for p in pg])
+            ng += 1
+        k += 1
+    assert k == 6
+    for tag, sd in (("G", gan.generator.state_dict()), ("D", gan.discriminator.state_dict())):
+        for key in g:
+            if key.startswith(f"end/{tag}/"):
+                want = T(g[key])
+                got = sd[key[len(f"end/{tag}/"):]]
+                assert float((got - want).norm() / (want.norm() + 1e-12)) < 1e-5, key

@@ -135,3 +135,75 @@ def test_bench_step_under_torchrun_with_two_ranks(tmp_path):
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
     # whole-job aggregate: both ranks' audio over the max-over-ranks time
     assert abs(d["value"] - 2 * 2 * 4 * 1.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+
+
+class _SpyReducer:
+    """GradReducer that remembers, per step, which buckets had left BEFORE finish() was called."""
+
+    def __new__(cls, *a, **kw):
+        from flow2gan_amd import dist as fdist
+
+        class Spy(fdist.GradReducer):
+            def __init__(self, *a, **kw):
+                super().__init__(*a, **kw)
+                self.log = []
+
+            def finish(self):
+                plan = self._active
+                if plan is not None:
+                    self.log.append((list(plan.sent_order), len(plan.buckets), plan))
+                return super().finish()
+
+        return Spy(*a, **kw)
+
+
+def _rccl_single(rank, world, port, outdir):
+    """ONE rank through the real RCCL backend (what F2G_FORCE_DIST=1 does in bench.py), launch lanes
+    ON: arenas, per-lane hand-over, asynchronous all-reduce on the communication stream, the
+    stream ordering between up to seven lanes and that stream -- against the plain path."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    import torch.distributed as dist
+    from flow2gan_amd import dist as fdist
+    from flow2gan_amd import fused, ops
+    from flow2gan_amd.harness import grad_groups
+    assert ops.CONCURRENT
+    fdist.setup_dist(0, 1, backend="nccl")
+    gan, logmel = _build()
+    plain = _steps(gan, logmel, 0, fdist.GradReducer())            # world 1, not forced: no exchange
+    spy = _SpyReducer(bucket_mb=8.0, force=True)
+    got = _steps(gan, logmel, 0, spy)
+    torch.cuda.synchronize()
+    assert fused.GRAD_SINK is None
+    (d_order, d_n, d_plan), (g_order, g_n, g_plan) = spy.log
+    # every bucket had left before finish(): from a lane's hand-over or an autograd hook
+    assert sorted(d_order) == list(range(d_n)) and sorted(g_order) == list(range(g_n)), (d_order, g_order)
+    assert d_n >= 6 and g_n >= 4
+    # G-step: the three branch groups' buckets leave before anything of the rest (cond encoder,
+    # condition paths), which closes last
+    branch_ids = {id(p) for grp in grad_groups(gan, False) for p in grp}
+    is_branch = {b.index: all(id(p) in branch_ids for p in b.params) for b in g_plan.buckets}
+    assert any(is_branch.values()) and not all(is_branch.values())
+    first_rest = min(i for i, bi in enumerate(g_order) if not is_branch[bi])
+    assert all(is_branch[bi] for bi in g_order[:first_rest])
+    assert not any(is_branch[bi] for bi in g_order[first_rest:]), g_order
+    worst = {}
+    for name in ("D", "G"):
+        w = 0.0
+        for k, v in got[name].items():
+            want = plain[name][k]
+            w = max(w, float((v - want).abs().max()) / (float(want.abs().max()) + 1e-9))
+        worst[name] = w
+    torch.save(worst, os.path.join(outdir, "rccl_single.pt"))
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_exchange_with_lanes_matches_plain_path(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from _mp import run_workers
+    run_workers("test_zz_hip_dist", "_rccl_single", 1, str(tmp_path), timeout=200.0)
+    worst = torch.load(tmp_path / "rccl_single.pt")
+    # same kernels, same lanes; what differs is atomics' order and the arena accumulation
+    assert worst["D"] < 2e-4 and worst["G"] < 2e-4, worst

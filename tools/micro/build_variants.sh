@@ -5,9 +5,11 @@
 set -e
 cd "$(dirname "$0")/../../flow2gan_amd/csrc"
 OUT=../../tools/micro
+# the same source list as the product library
+SRCS=$(sed -n 's/^SRCS *= *//p' Makefile)
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DF2G_LABVAR=$v -shared \
-     capi.hip gemm.hip narrow.hip convnext.hip signal.hip elementwise.hip optim.hip conv32.hip conv2ch.hip fft.hip -o $OUT/libvar$v.so &
+     $SRCS -o $OUT/libvar$v.so &
 done
 wait
 ls -la $OUT/*.so
