@@ -116,6 +116,13 @@ class MpdPostDesc(C.Structure):  # == f2g_mpdpost_desc
                 ("g", C.c_void_p)]
 
 
+class FusedMlpDesc(C.Structure):  # == f2g_fused_mlp_desc
+    _fields_ = [("z", C.c_void_p), ("ldz", C.c_int64), ("wp", C.c_void_p), ("b1", C.c_void_p),
+                ("alpha", C.c_void_p), ("b2", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int64),
+                ("gamma", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("rows", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("parts", C.c_int32)]
+
+
 class SadamGroup(C.Structure):  # == f2g_sadam_group
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("scalar_lr_scale", C.c_float), ("eps", C.c_float), ("param_min_rms", C.c_float),
@@ -196,9 +203,11 @@ _SIGS = {
     "f2g_lrelu_bwd_colsum": [_P, _P, _P, _F, _P, _F, _I, _I, _L, _P],
     "f2g_zero_halo": [_P, _I, _I, _I, _I, _I],
     "f2g_sadam_update": [_P, _P, _I, _P],
+    "f2g_mlp_pack": [_P, _P, _L, _P, _L, _I, _I],
+    "f2g_fused_mlp": [C.POINTER(FusedMlpDesc)],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
-                                 "f2g_gemm_lean_ok",
+                                 "f2g_gemm_lean_ok", "f2g_fused_mlp_ok",
                                  "f2g_dwnorm_bwd_workspace",
                                  "f2g_dwconv_bwd_workspace", "f2g_sadam_chunk_elems"])
 
@@ -223,6 +232,8 @@ def _load():
         fn.restype = C.c_int64
     lib.f2g_gemm_lean_ok.argtypes = [C.POINTER(GemmDesc)]
     lib.f2g_gemm_lean_ok.restype = C.c_int
+    lib.f2g_fused_mlp_ok.argtypes = [C.c_int32, C.c_int32]
+    lib.f2g_fused_mlp_ok.restype = C.c_int
     lib.f2g_sadam_chunk_elems.argtypes = []
     lib.f2g_sadam_chunk_elems.restype = C.c_int32
     lib.f2g_version.restype = C.c_char_p

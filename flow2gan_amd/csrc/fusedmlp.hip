@@ -1,0 +1,396 @@
+// Fused pointwise MLP of a ConvNeXt block (reference flow2gan/models/modules.py:487-489 and the
+// residual of :491-495):
+//     out = W2 . PReLU(W1 . z + b1) + b2 + gamma * x
+// for bf16 operands with fp32 accumulation (BASELINE config 2, the plain-bf16 inference mode).  The
+// 3C-wide hidden activation never exists in HBM: a block owns BM = 32 * RT rows, keeps their z tile
+// (BM x C bf16) in LDS for its whole life, walks the hidden dimension in slabs of 128 columns
+// (phase A: a = z . W1_slab^T, K = C; PReLU; the slab goes to LDS as bf16; phase B: out += p .
+// W2_slab^T, K = 128) and holds the BM x C fp32 output tile in accumulator registers:
+//
+//   * 4 waves, ONE per SIMD (the 512-register budget): wave w owns hidden columns w*32..+32 of a
+//     slab in phase A and output columns w*C/4..+C/4 in phase B -- RT x NT = 12 accumulator tiles
+//     (192 registers) for the three shapes of mel_24k_base / mel_44k: (C, BM) = (768, 64),
+//     (512, 96), (384, 128).
+//   * Weights never pass through LDS.  f2g_mlp_pack writes W1 and W2 as ONE stream per wave in the
+//     exact order and lane layout the MFMA B operand wants (1 KiB = one 32 x 16 fragment, lane l =
+//     8 consecutive k of row l & 31), so a wave reads its weights with fully coalesced 16-byte
+//     loads straight into registers through a 16-deep ring (16 KiB in flight per wave: the L2
+//     latency is hidden by prefetch distance instead of by co-resident waves), and every weight
+//     byte enters the CU exactly once per block.
+//   * LDS serves only the A operands: z rows (pitch 2C + 16 bytes) and the p slab (pitch 272
+//     bytes), both conflict-free for ds_read_b128 (pitch = 4 dwords mod 64).
+// Algorithmic traffic per block: z tile + residual in, output tile out, the weight stream
+// (12 C^2 bytes) from L2; FLOPs 12 C^2 per row.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef F2G_MLPVAR
+#define F2G_MLPVAR 0   // lab builds only (tools/micro/fusedmlp_lab.hip): timing ablations, results garbage
+#endif
+constexpr int HS = 128;            // hidden columns per slab
+#ifndef F2G_MLP_RING
+#define F2G_MLP_RING 16
+#endif
+constexpr int RING_WANTED = F2G_MLP_RING;   // weight fragments in flight per wave
+constexpr int PP = HS * 2 + 16;    // LDS pitch of a p row (bytes)
+
+__device__ __forceinline__ bf16x8 as_frag(const u32x4& v) {
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// spb: slabs per block.  gridDim.y = J > 1 cuts the hidden dimension between J blocks of a row tile
+// (a tile count well below the 256 CUs -- 94 tiles at C = 768, B = 64 -- would leave most of the chip
+// idle, and more rows per block are not to be had: the output tile fills the registers): every
+// part adds its partial output tile atomically onto a zeroed `out`, part 0 carries b2 and the residual.
+template <int RT, int NT>
+__global__ __launch_bounds__(256, 1)
+void fused_mlp_kernel(const f2g_fused_mlp_desc d, int spb) {
+  constexpr int BM = 32 * RT, C = 128 * NT;
+  constexpr int ZP = C * 2 + 16;               // LDS pitch of a z row (bytes)
+  constexpr int KA = C / 16;                   // k steps (= weight fragments) of phase A
+  constexpr int KB = HS / 16;                  // k steps of phase B (NT fragments each)
+  constexpr int PER_SLAB = KA + KB * NT;       // fragments per slab and wave (a multiple of RING)
+  constexpr int RING = PER_SLAB % RING_WANTED == 0 ? RING_WANTED : 16;
+  static_assert(PER_SLAB % RING == 0, "ring indices must be static across slabs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* zs = smem;
+  unsigned char* ps = smem + BM * ZP;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  // (wave-uniform by construction; said explicitly so that everything derived from it -- the scalar
+  // offset of the weight stream above all -- lives in SGPRs instead of behind waterfall loops)
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * BM;
+  const int S = d.H / HS;
+  const int s_beg = blockIdx.y * spb;
+  const int s_end = s_beg + spb < S ? s_beg + spb : S;
+  const bool lead = blockIdx.y == 0, split = gridDim.y > 1;
+
+  // ---- weight stream of this wave: fragments [slab][KA of W1 | KB x NT of W2], 1 KiB each
+  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.wp, 0, (unsigned)((long long)2 * C * d.H * 2), 0x00020000);
+  const unsigned wlane = lane * 16;
+  int wso = (w * S + s_beg) * PER_SLAB * 1024;  // scalar byte offset of the next fragment to REQUEST
+  u32x4 ring[RING];
+#pragma unroll
+  for (int i = 0; i < RING; ++i) {
+    ring[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wso, 0);
+    wso += 1024;
+  }
+
+  // ---- z tile -> LDS (rows past the end read as zeros: out of the buffer's range)
+  if (!(F2G_MLPVAR & 4)) {
+    __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)d.z, 0, (unsigned)((long long)d.rows * d.ldz * 2), 0x00020000);
+    constexpr int CPR = C / 8;                 // 16-byte chunks per row
+    constexpr int NCH = BM * CPR / 256;        // chunks per thread
+    static_assert((BM * CPR) % 256 == 0, "tile chunks must divide among the threads");
+    constexpr int G = 8;                       // loads in flight per thread
+#pragma unroll
+    for (int g0 = 0; g0 < NCH; g0 += G) {
+      u32x4 v[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (g0 + g < NCH) {
+          const int id = tid + 256 * (g0 + g), r = id / CPR, cc = id - r * CPR;
+          const long long off = (long long)(m0 + r) * d.ldz * 2 + cc * 16;
+          v[g] = __builtin_amdgcn_raw_buffer_load_b128(
+              rz, (m0 + r) < d.rows ? (unsigned)off : 0xfffffff0u, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (g0 + g < NCH) {
+          const int id = tid + 256 * (g0 + g), r = id / CPR, cc = id - r * CPR;
+          *reinterpret_cast<u32x4*>(zs + r * ZP + cc * 16) = v[g];
+        }
+      }
+    }
+  }
+
+  f32x16 out[RT][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float b = (d.b2 && lead) ? d.b2[w * (C / 4) + nt * 32 + li] : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out[rt][nt][e] = b;
+  }
+  __syncthreads();
+
+  const unsigned char* za = zs + li * ZP + h * 16;     // A fragments of phase A: row li (+ 32 rt)
+  const unsigned char* pa = ps + li * PP + h * 16;     // A fragments of phase B
+  unsigned char* pw = ps + (4 * h) * PP + (w * 32 + li) * 2;   // this lane's p stores
+
+  for (int s = s_beg; s < s_end; ++s) {
+    const int hc = s * HS + w * 32 + li;               // this lane's hidden column in the slab
+    const float b1v = d.b1 ? d.b1[hc] : 0.f;
+    const float alv = d.alpha[hc];
+    // ---- phase A: a (BM x 32 per wave) = z . W1_slab^T
+    f32x16 a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a[rt][e] = 0.f;
+    bf16x8 fz[2][RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) fz[0][rt] = *reinterpret_cast<const bf16x8*>(za + rt * 32 * ZP);
+#pragma unroll
+    for (int ks = 0; ks < KA; ++ks) {
+      if (ks + 1 < KA) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          fz[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(za + rt * 32 * ZP + (ks + 1) * 32);
+      }
+      const bf16x8 fb = as_frag(ring[ks % RING]);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        a[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz[ks & 1][rt], fb, a[rt], 0, 0, 0);
+      if (!(F2G_MLPVAR & 1)) ring[ks % RING] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wso, 0);
+      wso += 1024;
+      // keep the written order: left alone, the scheduler sinks the refills to just before their
+      // use (3 loads in flight instead of 16) and the fragment reads to just before their MFMA
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- PReLU, round to bf16, slab -> LDS (C/D layout: column li, rows (e&3) + 8 (e>>2) + 4 h)
+    if (F2G_MLPVAR & 8) {
+      float t = b1v + alv;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += a[rt][e];
+      if (t == 12345.678f) *reinterpret_cast<float*>(pw) = t;
+    } else
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = a[rt][e] + b1v;
+        const float p = fmaxf(v, 0.f) + alv * fminf(v, 0.f);
+        *reinterpret_cast<__bf16*>(pw + (rt * 32 + (e & 3) + 8 * (e >> 2)) * PP) = (__bf16)p;
+      }
+    if (!(F2G_MLPVAR & 8)) __syncthreads();
+    // ---- phase B: out (BM x C/4 per wave) += p . W2_slab^T
+    bf16x8 fp[2][RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) fp[0][rt] = *reinterpret_cast<const bf16x8*>(pa + rt * 32 * PP);
+#pragma unroll
+    for (int k2 = 0; k2 < KB; ++k2) {
+      if (k2 + 1 < KB) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          fp[(k2 + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(pa + rt * 32 * PP + (k2 + 1) * 32);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        constexpr int base = KA % RING;
+        const int slot = (base + k2 * NT + nt) % RING;
+        const bf16x8 fb = as_frag(ring[slot]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          out[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fp[k2 & 1][rt], fb, out[rt][nt], 0, 0, 0);
+        if (!(F2G_MLPVAR & 1)) ring[slot] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wso, 0);
+        wso += 1024;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!(F2G_MLPVAR & 8)) __syncthreads();     // every wave has read the slab before the next one overwrites it
+  }
+
+  if (F2G_MLPVAR & 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += out[rt][nt][e];
+    if (t == 12345.678f) d.out[tid] = t;
+    return;
+  }
+  // ---- out = acc (+ b2 already inside) + gamma * x.  In the C/D layout a lane holds ONE column of
+  // 16 rows: stored as it lies, that is 16 dword loads + 16 dword stores per tile and lane, and the
+  // stores are issue-bound (measured: 38-41 us of a 92-119 us kernel).  Every wave therefore turns
+  // its tiles through 4 KiB of the (now dead) z tile: 16 ds_write_b32, 4 ds_read_b128, and the
+  // residual / output travel as 16-byte accesses of whole 128-byte row segments.
+  const bool hasres = d.res != nullptr && lead;
+  if (!split) {
+    float* scr = reinterpret_cast<float*>(smem) + w * 1024;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    // tiles in the order t = nt * RT + rt; the residual of tile t + 1 is requested before tile t is
+    // turned (two tiles of loads in flight per wave, the schedule pinned tile by tile: left alone
+    // the compiler hoists all twelve tiles' loads = 192 registers it does not have).  Buffer
+    // addressing: one per-lane offset, the tile / row-group part in a scalar register, rows past
+    // the end out of the resources' range (loads return zeros, stores are dropped).
+    __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(hasres ? d.res : d.out), 0, (unsigned)((long long)d.rows * (hasres ? d.ldres : d.ldo) * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)d.out, 0, (unsigned)((long long)d.rows * d.ldo * 4), 0x00020000);
+    const int ldr = (int)d.ldres, ldo = (int)d.ldo;
+    const unsigned vres = (unsigned)((rr * ldr + c4) * 4), vout = (unsigned)((rr * ldo + c4) * 4);
+    auto load_res = [&](int t, u32x4 (&rv)[4]) {
+      const int nt = t / RT, rt = t - nt * RT;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        rv[j] = __builtin_amdgcn_raw_buffer_load_b128(
+            rres, vres, ((m0 + rt * 32 + 8 * j) * ldr + w * (C / 4) + nt * 32) * 4, 0);
+    };
+    u32x4 rbuf[2][4];
+    if (hasres) load_res(0, rbuf[0]);
+#pragma unroll
+    for (int t = 0; t < RT * NT; ++t) {
+      const int nt = t / RT, rt = t - nt * RT;
+      if (hasres && t + 1 < RT * NT) load_res(t + 1, rbuf[(t + 1) & 1]);
+      float4 gam = {0.f, 0.f, 0.f, 0.f};
+      if (hasres)
+        gam = d.gamma ? *reinterpret_cast<const float4*>(d.gamma + w * (C / 4) + nt * 32 + c4)
+                      : float4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) scr[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + li] = out[rt][nt][e];
+      // (one wave: its LDS operations execute in order; the compiler keeps the order through `scr`)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 v = *reinterpret_cast<const float4*>(scr + (rr + 8 * j) * 32 + c4);
+        if (hasres) {
+          const float4 r = __builtin_bit_cast(float4, rbuf[t & 1][j]);
+          v.x += gam.x * r.x;
+          v.y += gam.y * r.y;
+          v.z += gam.z * r.z;
+          v.w += gam.w * r.w;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, vout,
+                                               ((m0 + rt * 32 + 8 * j) * ldo + w * (C / 4) + nt * 32) * 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  // partial tiles of a hidden-dimension split: atomic accumulation, element by element
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = w * (C / 4) + nt * 32 + li;
+    const float gam = hasres ? (d.gamma ? d.gamma[col] : 1.f) : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row0 = m0 + rt * 32 + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + (e & 3) + 8 * (e >> 2);
+        float v = out[rt][nt][e];
+        if (hasres && row < d.rows) v += gam * d.res[(long long)row * d.ldres + col];
+        if (row < d.rows) atomicAdd(d.out + (long long)row * d.ldo + col, v);
+      }
+    }
+  }
+}
+
+// W1 (H, C) and W2 (C, H), fp32 row-major -> the per-wave bf16 fragment stream (see the kernel).
+__global__ __launch_bounds__(256)
+void mlp_pack_kernel(uint4* __restrict__ dst, const float* __restrict__ w1, long long ld1,
+                     const float* __restrict__ w2, long long ld2, int C, int H) {
+  const int NT = C / 128, KA = C / 16, KB = HS / 16, per = KA + KB * NT, S = H / HS;
+  const long long total = (long long)4 * S * per * 64;      // one 16-byte piece per thread
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    long long f = i >> 6;
+    const int j = (int)(f % per);
+    f /= per;
+    const int s = (int)(f % S), w = (int)(f / S);
+    const float* src;
+    if (j < KA) {
+      src = w1 + (long long)(s * HS + w * 32 + (l & 31)) * ld1 + j * 16 + (l >> 5) * 8;
+    } else {
+      const int jj = j - KA, k2 = jj / NT, nt = jj - k2 * NT;
+      src = w2 + (long long)(w * (C / 4) + nt * 32 + (l & 31)) * ld2 + s * HS + k2 * 16 + (l >> 5) * 8;
+    }
+    union { __bf16 b[8]; uint4 v; } u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u.b[k] = (__bf16)src[k];
+    dst[i] = u.v;
+  }
+}
+
+template <int RT, int NT>
+int launch_fused(const f2g_fused_mlp_desc& d, hipStream_t st) {
+  constexpr int BM = 32 * RT, C = 128 * NT;
+  constexpr size_t smem = (size_t)BM * (C * 2 + 16) + (size_t)BM * PP;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<RT, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  const int tiles = (d.rows + BM - 1) / BM, S = d.H / HS;
+  // hidden-dimension split: as many parts as keep the grid within one round of the 256 CUs, each
+  // part at least 4 slabs long (F2G_MLP_SPLIT=1 turns it off, n forces n parts)
+  static const int env_parts = getenv("F2G_MLP_SPLIT") ? atoi(getenv("F2G_MLP_SPLIT")) : 0;
+  const int forced = d.parts > 0 ? d.parts : env_parts;
+  // (measured: the atomic accumulation of the partial tiles costs more than the idle CUs -- 6016 x 768:
+  // 117 us whole, 127 us in two parts; 24064 x 384: 83 -> 196 us -- so the library never splits on
+  // its own; the path stays for callers / experiments that ask for it)
+  int J = forced > 0 ? forced : 1;
+  if (J > S) J = S;
+  if (J < 1) J = 1;
+  const int spb = (S + J - 1) / J;
+  J = (S + spb - 1) / spb;
+  if (J > 1) {   // partial tiles are accumulated atomically
+    if (d.ldo == C) {
+      if (hipMemsetAsync(d.out, 0, (size_t)d.rows * C * sizeof(float), st) != hipSuccess) return F2G_ELAUNCH;
+    } else if (hipMemset2DAsync(d.out, (size_t)d.ldo * sizeof(float), 0, (size_t)C * sizeof(float),
+                                (size_t)d.rows, st) != hipSuccess) {
+      return F2G_ELAUNCH;
+    }
+  }
+  hipLaunchKernelGGL((fused_mlp_kernel<RT, NT>), dim3(tiles, J), dim3(256), smem, st, d, spb);
+  return f2g_check_launch();
+}
+
+}  // namespace
+
+extern "C" int f2g_fused_mlp_ok(int32_t C, int32_t H) {
+  return (C == 768 || C == 512 || C == 384) && H % HS == 0 && H >= HS &&
+         (long long)2 * C * H * 2 < 0x7ff00000ll;
+}
+
+extern "C" int f2g_mlp_pack(void* dst, const float* w1, int64_t ld1, const float* w2, int64_t ld2,
+                            int32_t C, int32_t H, f2g_stream_t stream) {
+  if (!dst || !w1 || !w2) return F2G_EINVAL;
+  if (!f2g_fused_mlp_ok(C, H)) {
+    f2g_set_error("f2g_mlp_pack: C must be 384 / 512 / 768 and H a multiple of 128");
+    return F2G_EINVAL;
+  }
+  const long long total = (long long)2 * C * H / 8;
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(f2g_grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, reinterpret_cast<uint4*>(dst), w1, (long long)ld1, w2,
+                     (long long)ld2, C, H);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_fused_mlp(const f2g_fused_mlp_desc* dp, f2g_stream_t stream) {
+  if (!dp) return F2G_EINVAL;
+  const f2g_fused_mlp_desc& d = *dp;
+  if (!d.z || !d.wp || !d.alpha || !d.out || d.rows < 0) return F2G_EINVAL;
+  auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (!f2g_fused_mlp_ok(d.C, d.H) || (d.ldz & 7) || d.ldz < d.C ||
+      (long long)d.rows * d.ldz * 2 >= 0x7ff00000ll || (d.res && (d.ldres < d.C || (d.ldres & 3) || !al16(d.res))) ||
+      d.ldo < d.C || (d.ldo & 3) || !al16(d.out) || (long long)d.rows * d.ldo * 4 >= 0x7ff00000ll ||
+      (d.res && (long long)d.rows * d.ldres * 4 >= 0x7ff00000ll) || !al16(d.z) || !al16(d.wp) || (d.gamma && !al16(d.gamma))) {
+    f2g_set_error("f2g_fused_mlp: unsupported shape (C in {384, 512, 768}, H % 128 == 0, ldz % 8 == 0, "
+                  "16-byte aligned tensors with row strides in whole float4s)");
+    return F2G_EINVAL;
+  }
+  if (d.rows == 0) return F2G_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (d.C == 768) return launch_fused<2, 6>(d, st);
+  if (d.C == 512) return launch_fused<3, 4>(d, st);
+  return launch_fused<4, 3>(d, st);
+}

@@ -193,19 +193,26 @@ class GradReducer:
         self._active = plan
         fused.GRAD_SINK = _Sink(self, plan)
 
-    def _on_grad(self, p: torch.nn.Parameter) -> None:
+    def _on_grad(self, p: torch.nn.Parameter, from_sink: bool = False) -> None:
         plan = self._active
         if plan is None:
             return
         b = plan.bucket_of.get(id(p))
         if b is None:
             return
+        if not from_sink and id(p) in plan.echo:
+            # autograd runs a parameter's AccumulateGrad node -- and this hook -- even when the
+            # node that owns it returned None for it (its gradient went through the sink): the
+            # one echo per backward is not a gradient
+            plan.echo.discard(id(p))
+            return
         if b.sent:
             # a second backward() between prepare() and finish() would accumulate into an arena
             # that has already been averaged and would never be exchanged: ranks would diverge
             # silently.  One backward per prepare(); gradient accumulation needs reduce().
             raise RuntimeError("GradReducer: gradient arrived for a bucket that has already been "
-                               "exchanged -- exactly one backward() per prepare()/finish() pair")
+                               "exchanged -- exactly one backward() per prepare()/finish() pair "
+                               f"(parameter of shape {tuple(p.shape)}, bucket {b.index})")
         b.fired.add(id(p))
         if b.flat.is_cuda:
             # the stream this gradient was accumulated on (a launch lane, or autograd's stream)
@@ -302,7 +309,8 @@ class _Sink:
         if self.uses[key] == 0:
             for p in params:
                 if id(p) in self.plan.touched:
-                    self.reducer._on_grad(p)
+                    self.plan.echo.add(id(p))
+                    self.reducer._on_grad(p, from_sink=True)
 
 
 class _Bucket:
@@ -337,12 +345,14 @@ class _Plan:
         self.bytes = 0
         self.sent_order: List[int] = []
         self.touched: set = set()
+        self.echo: set = set()
 
     @torch.no_grad()
     def arm(self) -> None:
         self.bytes = 0
         self.sent_order = []
         self.touched = set()
+        self.echo = set()
         for b in self.buckets:
             b.flat.zero_()
             b.fired.clear()

@@ -125,6 +125,12 @@ def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0,
         z = torch.empty(rows, Cc, device=dev, dtype=torch.bfloat16)
         ops.dwnorm_fwd(x, z, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta, bp.log_scale.reshape(1),
                        cproj, ldcp, Fc, up, cp_off, te, ldte, te_off, z_format=2)
+        if ops.fused_mlp_applies(Cc, Hh):
+            # pwconv1 -> PReLU -> pwconv2 + residual in one launch, hidden activation on chip
+            out = ops.empty(rows, Cc, device=dev)
+            ops.fused_mlp(z, ops.mlp_pack(bp.w1, bp.w2), bp.b1,
+                          bp.alpha, bp.b2, x, bp.gamma.reshape(Cc), out, rows, Cc, Hh)
+            return out, z, (None, None, None, 0)
         a = torch.empty(rows, Hh, device=dev, dtype=torch.bfloat16)
         gemm(mat(z, rows, Cc, split=2), mat(bp.w1.reshape(Hh, Cc)), a, bias=bp.b1, prelu=bp.alpha,
              split_k=1)

@@ -94,9 +94,10 @@ class BaseAudioGenerator(nn.Module):
         self.branch_dropout = branch_dropout
         self.cond_hop_length = cond_hop_length
 
-        self.loss_spec = LinearFilterSpectrogram(
-            sample_rate=sampling_rate, n_fft=loss_n_fft, hop_length=loss_hop_length,
-            n_filter=loss_n_filters, center=True, power=2)
+        if spec_scaling_loss:      # generator.py:85-93: the unweighted loss has no spectrogram module
+            self.loss_spec = LinearFilterSpectrogram(
+                sample_rate=sampling_rate, n_fft=loss_n_fft, hop_length=loss_hop_length,
+                n_filter=loss_n_filters, center=True, power=2)
         if use_cond_encoder:   # generator.py:86-97: without it the estimators see the raw condition
             self.cond_encoder = CondEncoder(
                 cond_dim=cond_dim, channels=cond_enc_channels, hidden_factor=cond_enc_hidden_factor,

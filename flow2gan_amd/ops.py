@@ -102,9 +102,9 @@ def _derived(t, tag, build):
     oid = id(owner)          # (tensors compare element-wise: never use them as dictionary keys)
     ent = _DERIVED.get(oid)
     if ent is None or ent[0]() is not owner:
-        def _gone(_r, oid=oid):
-            _DERIVED.pop(oid, None)
-            _OWNER_EPOCH.pop(oid, None)
+        def _gone(_r, oid=oid, d=_DERIVED, e=_OWNER_EPOCH):   # (bound now: globals are gone at exit)
+            d.pop(oid, None)
+            e.pop(oid, None)
         ent = (weakref.ref(owner, _gone), {})
         _DERIVED[oid] = ent
         _OWNER_EPOCH.pop(oid, None)       # a recycled id: the epoch of a dead tensor
@@ -651,7 +651,7 @@ class GemmTimer:
         mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
         self.shapes.append((form, mm, nn, kk))
 
-    def time(self, fn, flops: float, shape):
+    def time(self, fn, flops: float, shape, path: str = "direct-conv"):
         """Any other launch that stands in for an f2g_gemm (the direct band-conv kernel)."""
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
@@ -659,7 +659,7 @@ class GemmTimer:
         fn()
         e.record()
         self.records.append((s, e, flops))
-        self.paths.append("direct-conv")
+        self.paths.append(path)
         self.shapes.append(shape)
 
     def report(self, top: int = 25) -> str:
@@ -790,6 +790,47 @@ def wgrad(dY, M: int, ldy: int, X: Operand, g_out, ldg: Optional[int] = None, ou
     tiles = ((M + 127) // 128) * ((X.cols + 127) // 128)
     gemm(A, X, g_out, form=2, ldc=ldg, atomic=True, split_k=split_for(rows, tiles),
          out_offset=out_offset)
+
+
+# ------------------------------------------------------------------ fused pointwise MLP (bf16)
+FUSED_MLP = _os.environ.get("F2G_FUSED_MLP", "1") != "0"
+
+
+def fused_mlp_applies(Cc: int, Hh: int) -> bool:
+    """pwconv1 -> PReLU -> pwconv2 (+ residual) as ONE kernel with the hidden activation on chip
+    (csrc/fusedmlp.hip): plain-bf16 inference, C in {384, 512, 768}."""
+    return FUSED_MLP and GEMM_PRECISION == 2 and bool(L.lib.f2g_fused_mlp_ok(Cc, Hh))
+
+
+def mlp_pack(w1, w2):
+    """The block's two weight matrices (H, C[, 1]) and (C, H[, 1]) as the fused kernel's bf16
+    fragment stream, cached until one of them changes.  Pass the PARAMETERS themselves (the cache
+    is keyed on the tensor objects: a fresh reshape() view per call would never hit)."""
+    def build(ts):
+        a, b = ts
+        Hh, Cc = a.shape[0], a.shape[1]
+        out = torch.empty(2 * Cc * Hh, device=a.device, dtype=torch.bfloat16)
+        call("f2g_mlp_pack", ptr(out), ptr(a), Cc, ptr(b), Hh, Cc, Hh)
+        return out
+    return derived_multi([w1, w2], "mlp_pack", build)
+
+
+def fused_mlp(z, wp, b1, alpha, b2, res, gamma, out, rows: int, Cc: int, Hh: int, parts: int = 0):
+    """out (rows, C) fp32 = W2 . PReLU(W1 . z + b1) + b2 + gamma * res; z bf16 (rows, C).
+    parts: 0 = library's choice, n = cut the hidden dimension between n blocks per row tile."""
+    d = L.FusedMlpDesc()
+    d.parts = parts
+    d.z, d.ldz, d.wp = ptr(z), z.stride(0), ptr(wp)
+    d.b1, d.alpha, d.b2 = ptr(b1), ptr(alpha), ptr(b2)
+    d.res, d.ldres, d.gamma = ptr(res), (res.stride(0) if res is not None else 0), ptr(gamma)
+    d.out, d.ldo = ptr(out), out.stride(0)
+    d.rows, d.C, d.H = rows, Cc, Hh
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_fused_mlp", C.byref(d)), 4.0 * rows * Cc * Hh,
+                        (0, rows, Cc, 2 * Hh), path="fused-mlp")
+    else:
+        call("f2g_fused_mlp", C.byref(d))
+    return out
 
 
 # ------------------------------------------------------------------ fused block kernels

@@ -573,6 +573,41 @@ int f2g_sadam_prepare(const f2g_sadam_tensor* tensors, const f2g_sadam_group* gr
 int f2g_sadam_update(const f2g_sadam_tensor* tensors, const f2g_sadam_chunk* chunks,
                      int32_t nchunks, const float* coef, f2g_stream_t stream);
 
+/* ---- fused pointwise MLP of a ConvNeXt block, bf16 operands / fp32 accumulate (csrc/fusedmlp.hip) ----
+ * Replaces pwconv1 -> PReLU -> pwconv2 and the residual of ConvNeXtBlock.forward
+ * (flow2gan/models/modules.py:487-495) for inference in the plain-bf16 mode (BASELINE config 2):
+ *     out[r, :] = W2 . PReLU(W1 . z[r, :] + b1; alpha) + b2 + gamma * res[r, :]
+ * with the (rows, H) hidden activation kept on chip (a 128-column slab at a time in LDS, the output
+ * tile in accumulator registers).  z: bf16 (rows, C), row stride ldz elements (what f2g_dwnorm_fwd
+ * writes with z_format = 2); wp: the weights as f2g_mlp_pack lays them out; b1 / alpha: (H) fp32;
+ * b2 / gamma: (C) fp32 (b1, b2, gamma may be NULL; res NULL = no residual); out fp32 (rows, C).
+ * Supported: C in {384, 512, 768}, H a multiple of 128 (f2g_fused_mlp_ok). */
+typedef struct {
+  const void* z;
+  int64_t ldz;
+  const void* wp;
+  const float* b1;
+  const float* alpha;
+  const float* b2;
+  const float* res;
+  int64_t ldres;
+  const float* gamma;
+  float* out;
+  int64_t ldo;
+  int32_t rows, C, H;
+  int32_t parts; /* 0: the library decides; n >= 1: cut the hidden dimension between n blocks per row
+                  * tile (n > 1: partial output tiles are added atomically onto a zeroed `out`) */
+} f2g_fused_mlp_desc;
+int f2g_fused_mlp_ok(int32_t C, int32_t H);
+/* dst (2*C*H bf16 = 4*C*H bytes) = W1 (H, C; row stride ld1) and W2 (C, H; row stride ld2), fp32,
+ * rounded to bf16 and re-ordered into one contiguous stream per wave of the fused kernel, in MFMA
+ * B-fragment order (1 KiB = rows n0..n0+31 x 16 consecutive k; lane l holds k = 8*(l>>5)..+7 of
+ * row l&31): wave w, slab s: C/16 fragments of W1 rows s*128 + w*32..+32, then for each of the 8
+ * k steps of the slab the C/128 fragments of W2 rows w*C/4.. over hidden columns s*128 + 16*k2... */
+int f2g_mlp_pack(void* dst, const float* w1, int64_t ld1, const float* w2, int64_t ld2, int32_t C,
+                 int32_t H, f2g_stream_t stream);
+int f2g_fused_mlp(const f2g_fused_mlp_desc* d, f2g_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -383,10 +383,19 @@ def test_plain_bf16_inference_at_the_baseline_batch(f2g):
     e2 = rms(y2, y32)
     assert 1e-6 < e2 < 0.05 * sig, (e2, sig)
     assert tuple(y64.shape) == (64, 94 * 256)
-    # fp32 accumulation order may differ between the two grids (split-K / tile shape), which can
-    # move single activations across a bf16 rounding boundary: well below the mode's own error
-    e64 = rms(y64, y2.repeat(32, 1))
-    assert e64 < 0.3 * e2 + 1e-7, (e64, e2)
+    # The B = 64 grid uses other tile shapes / K splits than the B = 2 grid: the fp32 sums come out
+    # in another order, single activations cross a bf16 rounding boundary, and 4 steps x 8 blocks
+    # carry that on -- so B = 64 differs from B = 2 by about the mode's own error (measured: 0.9 of
+    # it), and it is held to the same bound against the exact-fp32 waveform ...
+    e64 = rms(y64, y32.repeat(32, 1))
+    assert 1e-6 < e64 < 0.05 * sig and e64 < 3.0 * e2, (e64, e2, sig)
+    # ... while inside ONE launch grid every copy of an item runs the same arithmetic in the same
+    # order wherever its rows lie in the tiles: the 32 copies agree (up to atomics' order in a
+    # library-chosen split), which is what pins the tile edges at M = 6016 / 12032 / 24064
+    for k in (1, 7, 31):
+        for item in (0, 1):
+            d = rms(y64[2 * k + item], y64[item])
+            assert d < 0.5 * e2, (k, item, d, e2)
 
 
 def test_non_default_constructor_switches_against_reference_vectors(f2g, golden, monkeypatch):

@@ -879,3 +879,56 @@ def test_direct_conv32_wgrad_matches_autograd(ops, S, H, Win):
     gw = torch.zeros(32, 27 * 32, device=DEV)
     ops.conv32_s2_wgrad(g(xr), g(gy), S, H, Win, Wout, gw)
     close(gw, w.grad.permute(0, 2, 3, 1).reshape(32, 27 * 32), rtol=1e-4, name="conv32 wgrad")
+
+
+@pytest.mark.parametrize("C,rows", [(768, 200), (512, 300), (384, 128 * 3), (512, 31)])
+def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
+    """csrc/fusedmlp.hip against a torch fp32 restatement of the same arithmetic (bf16 operands,
+    fp32 accumulation, the hidden activation rounded to bf16 between the two products):
+    out = W2 . bf16(PReLU(W1 . z + b1)) + b2 + gamma * x   (modules.py:487-495).  Row counts that
+    end inside a tile, and one smaller than a tile."""
+    H = 3 * C
+    g = torch.Generator().manual_seed(C + rows)
+    z = torch.randn(rows, C, generator=g).to(torch.bfloat16)
+    w1 = torch.randn(H, C, generator=g) * 0.05
+    w2 = torch.randn(C, H, generator=g) * 0.03
+    b1 = torch.randn(H, generator=g) * 0.1
+    al = 0.25 + 0.2 * torch.randn(H, generator=g)
+    b2 = torch.randn(C, generator=g) * 0.1
+    x = torch.randn(rows, C, generator=g)
+    gam = 0.5 + torch.rand(C, generator=g)
+    w1b, w2b = w1.to(torch.bfloat16).float(), w2.to(torch.bfloat16).float()
+    a = z.float().double() @ w1b.double().t() + b1.double()
+    p = (a.clamp(min=0) + al.double() * a.clamp(max=0)).float().to(torch.bfloat16)
+    want = p.double() @ w2b.double().t() + b2.double() + gam.double() * x.double()
+    out = torch.full((rows, C), float("nan"), device=DEV)
+    wp = ops.mlp_pack(w1.to(DEV), w2.to(DEV))
+    assert wp.dtype == torch.bfloat16 and wp.numel() == 2 * C * H
+    # the packed stream is a permutation of the two rounded matrices
+    assert abs(float(wp.float().double().sum()) - float(w1b.double().sum() + w2b.double().sum())) < 1e-2
+    ops.fused_mlp(z.to(DEV), wp, b1.to(DEV), al.to(DEV), b2.to(DEV), x.to(DEV), gam.to(DEV), out,
+                  rows, C, H)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    # p is rounded to bf16 from an fp32 sum whose order differs: a few elements may land on the
+    # neighbouring bf16 value (2^-8 relative of one hidden unit's contribution)
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    assert err < 2e-3 * scale, (err, scale)
+    rms_err = float((got - want).pow(2).mean().sqrt())
+    assert rms_err < 1e-4 * scale, (rms_err, scale)
+    # every way of cutting the hidden dimension between blocks: one part (plain stores), an uneven
+    # cut, one slab per part (atomic accumulation onto the zeroed output)
+    for parts in (1, 2, 5, H // 128):
+        outp = torch.full((rows, C), float("nan"), device=DEV)
+        ops.fused_mlp(z.to(DEV), wp, b1.to(DEV), al.to(DEV), b2.to(DEV), x.to(DEV), gam.to(DEV),
+                      outp, rows, C, H, parts=parts)
+        errp = float((outp.cpu().double() - want).abs().max())
+        assert errp < 2e-3 * scale, (parts, errp, scale)
+    # without residual / biases
+    out2 = torch.empty(rows, C, device=DEV)
+    ops.fused_mlp(z.to(DEV), wp, None, al.to(DEV), None, None, None, out2, rows, C, H)
+    a0 = z.float().double() @ w1b.double().t()
+    p0 = (a0.clamp(min=0) + al.double() * a0.clamp(max=0)).float().to(torch.bfloat16)
+    want2 = p0.double() @ w2b.double().t()
+    assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())

@@ -70,11 +70,14 @@ def test_get_model_local_checkpoint_full_test_mel(f2g, golden, tmp_path):
     torch.manual_seed(int(g["seed"]))
     src = f2g.MelAudioGenerator(**get_generator_config("mel_24k_base"))
     sd = src.state_dict()
-    h = hashlib.sha256()
-    for k in sorted(sd):
-        h.update(k.encode())
-        h.update(sd[k].numpy().astype(np.float32).tobytes())
-    assert h.hexdigest() == bytes(g["digest"]).decode(), "seeded init differs from the reference's"
+    # seeded init == the reference's: bit-identical where the host's erfinv is (the digest test of
+    # tests/test_host_side.py, run in the build container); here, on whatever CPU the GPU box has,
+    # the probes recorded from the reference must agree to the last few ulps
+    probes = golden("full_width")
+    for k in probes:
+        if k.startswith("probe/"):
+            got = sd[k[len("probe/"):]].reshape(-1)[:256]
+            assert float((got - T(probes[k])).abs().max()) < 1e-7, k
     ck = tmp_path / "libritts-mel-4-step.pt"
     torch.save({"model": sd, "batch_idx_train": 123}, ck)
     del src
