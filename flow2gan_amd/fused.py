@@ -486,15 +486,25 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     Wd, Wi = dft_matrices(N, dev)
     ldp = _spec_ld(Cin)
     Kc = ldp if SPEC_PAD else Cin        # reduction width over a spectrum row
+    # plain-bf16 inference: a GEMM result whose only reader is the next GEMM leaves its producer as
+    # bf16 (the lean kernel's plain-store epilogue) instead of passing through a conversion launch
+    bf16_chain = (not keep) and ops.GEMM_PRECISION == 2 and SPEC_PAD and ops.BF16_IMAGES \
+        and ops.LEAN_SPLIT and Kc % 64 == 0 and N % 64 == 0
     if ops.fft_applies(N):
         packed = ops.zeros(rows, ldp, device=dev) if SPEC_PAD else ops.empty(rows, ldp, device=dev)
         ops.stft_fft(x, N, hop, F, packed)
+        pk = mat(packed, rows, Kc)
+    elif bf16_chain:
+        packed = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16)
+        gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1)
+        pk = mat(packed, rows, Kc, split=2)
     else:
         packed = ops.empty(rows, ldp, device=dev)
         gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1)   # bit-reproducible
+        pk = mat(packed, rows, Kc)
     h0 = ops.empty(rows, Cc, device=dev)
     # (never split, as before the padding: the forward stays bit-reproducible from run to run)
-    gemm(mat(packed, rows, Kc), mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), h0, bias=bv.b_in, split_k=1)
+    gemm(pk, mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), h0, bias=bv.b_in, split_k=1)
     flags = [_limit_draw(training)]
     xcur = ops.empty(rows, Cc, device=dev)
     ops.biasnorm_fwd(h0, xcur, rows, Cc, bv.beta_in, bv.ls_in.reshape(1))
@@ -523,13 +533,14 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
         if keep:
             saved_blocks.append((xcur, z, a))
         xcur = y
-    yspec = ops.empty(rows, ldp, device=dev)
+    ybf = bf16_chain and lens_f is None
+    yspec = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16) if ybf else ops.empty(rows, ldp, device=dev)
     gemm(mat(xcur, rows, Cc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), yspec,
          bias=_pad_vec(bv.b_out, Kc), split_k=1)
     if lens_f is not None:
         ops.mask_rows(yspec, B, F, Cin, lens_f)
     frames = ops.empty(rows, N, device=dev)
-    gemm(mat(yspec, rows, Kc), mat(_pad_cols(Wi, Kc)), frames, split_k=1)
+    gemm(mat(yspec, rows, Kc, split=2 if ybf else 0), mat(_pad_cols(Wi, Kc)), frames, split_k=1)
     if lanes is not None:
         lanes.chain_enter()  # pred is accumulated branch after branch
     ops.istft_ola(frames, pred, B, F, N, hop, T, window, wbranch_row, wscale, accumulate)

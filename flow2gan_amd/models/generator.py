@@ -143,12 +143,17 @@ class BaseAudioGenerator(nn.Module):
         """Per-branch cond_mlp + stacked cond_proj, once per forward/infer: the reference
         recomputes them in every model evaluation (modules.py:620, 482) with identical results."""
         outs = []
-        for est in self.estimators:
+        # three independent chains of small / mid-size GEMMs: one launch lane each (serially they
+        # are 0.45 ms at the head of every inference, with the chip mostly idle)
+        lanes = ops.Lanes(cond.rows.device, len(self.estimators), "condpath")
+        for i, est in enumerate(self.estimators):
             F = 1 + T // est.hop_length
             up = est.cond_upsample_factor
             Fce = (F + up - 1) // up
-            outs.append(fused.CondPathFn.apply(cond.rows, cond.batch, cond.frames, Fce,
-                                               *fused.cond_path_params(est.decoder)))
+            with lanes.lane(i):
+                outs.append(fused.CondPathFn.apply(cond.rows, cond.batch, cond.frames, Fce,
+                                                   *fused.cond_path_params(est.decoder)))
+        lanes.join()
         return outs
 
     def _metas(self):
