@@ -9,6 +9,8 @@
 // 16 consecutive output columns read a stride-1, bank-conflict-free run for every tap), streams the
 // 27 (32 x 32) weight tiles through a double buffer, and feeds the fp32 MFMAs straight from the
 // patch at tap-shifted addresses: global traffic per output tile drops from 27 x 16 KB to 50 KB.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -183,6 +185,202 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_fwd_kernel(const f2g_conv32_
   }
 }
 
+// ---- persistent forward kernel (round 3; exact fp32) -------------------------------------------
+// The kernel above spends 30 % of a block's life outside the MFMAs (70 % of the fp32 rate on the
+// largest band, less on bands whose width wastes tile columns): every block stages its patch with
+// nothing to overlap it but the CU's second block -- which was launched in the same phase --, half
+// of the waves idle through a cross-wave reduction at the end, and a barrier separates every 16
+// MFMAs of a wave.  Here
+//   * a block is PERSISTENT: it walks over tiles b, b + G, ... and requests the next tile's patch
+//     (13 x 16 bytes per thread, kept in registers) before it computes the current one, so the
+//     global latency of the patch hides under 432 MFMAs per wave;
+//   * 4 waves per block, every wave runs ALL 27 taps of its 32 pixels (no tap halves, no
+//     reduction; 32 MFMAs per wave between barriers), 2 blocks per CU;
+//   * the weight double buffer keeps cycling across tiles (the last tap group of a tile fetches
+//     taps 0, 1 for the next);
+//   * two tile shapes, 8 x 16 and 16 x 8 output pixels: the launcher takes the one that wastes fewer
+//     columns of the band (widths 13 ... 129: 20 -> 24 instead of 32, 51 -> 56 instead of 64, ...).
+// (register arrays of native vectors: arrays of HIP's float4 STRUCT are filled through memcpy
+// intrinsics, which kept them in scratch memory)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TH_, int TW_>
+__global__ __launch_bounds__(256, 2) void conv32_s2_fwd_p_kernel(const f2g_conv32_desc d, int tiles_w,
+                                                                int tiles_h, int ntiles) {
+  constexpr int IHv = TH_ + KH - 1, IWv = TW_ + (KW - 1) / 2;     // staged rows; columns per parity
+  constexpr int SUBv = IHv * IWv * PITCH + 16;
+  constexpr int XW = 2 * IWv - 1;                                  // staged input columns
+  constexpr int NCHK = (IHv * XW * (C / 4) + 255) / 256;          // 16-byte chunks per thread
+  static_assert(TH_ * TW_ == 128, "a block owns 128 output pixels");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* At = sm;                  // [2 parities][IHv][IWv][PITCH]
+  float* Bt = sm + 2 * SUBv;       // [2 buffers][TG taps][C][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int c4 = tid & 7;          // (256 threads: the channel chunk of a thread is the same in every pass)
+  // staging plan, tile-independent: LDS offset (floats; -1 = no such chunk), source offset relative
+  // to the patch origin, (row, column) for the bounds test
+  int so[NCHK], go[NCHK], rx[NCHK];
+#pragma unroll
+  for (int q = 0; q < NCHK; ++q) {
+    const int px = (tid >> 3) + 32 * q;
+    const int r = px / XW, xr = px - r * XW;
+    const bool v = px < IHv * XW;
+    so[q] = v ? (xr & 1) * SUBv + (r * IWv + (xr >> 1)) * PITCH + c4 * 4 : -1;
+    go[q] = (int)(r * d.x_line) + xr * C + c4 * 4;
+    rx[q] = r | (xr << 8);
+  }
+  auto tile_pos = [&](int tile, int& sq, int& h0, int& w0) {
+    const int tw = tile % tiles_w, rest = tile / tiles_w;
+    const int th = rest % tiles_h;
+    sq = rest / tiles_h;
+    h0 = th * TH_;
+    w0 = tw * TW_;
+  };
+  auto load_patch = [&](int tile, f32x4 (&pf)[NCHK]) {
+    int sq, h0, w0;
+    tile_pos(tile, sq, h0, w0);
+    const int x0 = 2 * w0 - (KW - 1) / 2;
+    const float* org = d.x + (long long)sq * d.x_seq + (long long)(h0 - 1) * d.x_line + (long long)x0 * C;
+#pragma unroll
+    for (int q = 0; q < NCHK; ++q) {
+      const int h = h0 - 1 + (rx[q] & 255), x = x0 + (rx[q] >> 8);
+      const bool ok = so[q] >= 0 && h >= 0 && h < d.H && x >= 0 && x < d.Win;
+      pf[q] = *reinterpret_cast<const f32x4*>(ok ? org + go[q] : c32_zero);
+    }
+  };
+  auto store_patch = [&](const f32x4 (&pf)[NCHK]) {
+#pragma unroll
+    for (int q = 0; q < NCHK; ++q)
+      if (so[q] >= 0) *reinterpret_cast<f32x4*>(At + so[q]) = pf[q];
+  };
+  // weights: a tap group = 2 taps x 32 co x 8 chunks = two 16-byte pieces per thread
+  const int wco = tid >> 3;
+  const float* wrow = d.w + (long long)wco * (KH * KW * C) + c4 * 4;
+  auto load_w = [&](int g, f32x4 (&wn)[TG]) {        // group g (g == NG: group 0 of the next tile)
+    constexpr int NGc = (KH * KW + TG - 1) / TG;
+#pragma unroll
+    for (int u = 0; u < TG; ++u) {
+      int t = g < NGc ? g * TG + u : u;
+      t = t < KH * KW ? t : KH * KW - 1;
+      wn[u] = *reinterpret_cast<const f32x4*>(wrow + t * C);
+    }
+  };
+  auto store_w = [&](int buf, const f32x4 (&wn)[TG]) {
+#pragma unroll
+    for (int u = 0; u < TG; ++u)
+      *reinterpret_cast<f32x4*>(Bt + (buf * TG + u) * WB + wco * PITCH + c4 * 4) = wn[u];
+  };
+  const int p = wave * 32 + li;                  // this lane's output pixel inside the tile
+  const int ph = p / TW_, pw = p % TW_;
+  const int kk0 = hh * 16;                       // lane halves split the 32 input channels
+  const float bias = d.bias ? d.bias[li] : 0.f;
+  constexpr int NG = (KH * KW + TG - 1) / TG;
+  static_assert(NG % 2 == 0, "the weight double buffer must come back to buffer 0 at a tile's end");
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  // weight pipeline: group g's tiles are requested two groups ahead (register stage g & 1), go to
+  // LDS buffer g & 1 at the end of group g - 1 and are consumed in group g -- one group of latency
+  // cover was not enough with two waves per SIMD (the barrier of every group waited for L2)
+  f32x4 ws[2][TG];
+  {
+    f32x4 pf[NCHK];
+    load_patch(tile, pf);
+    load_w(0, ws[0]);
+    store_patch(pf);
+    store_w(0, ws[0]);
+    load_w(1, ws[1]);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < ntiles;
+    // origin of the NEXT tile's patch (the last tile re-requests its own: harmless, never stored)
+    int sq2, h02, w02;
+    tile_pos(more ? nxt : tile, sq2, h02, w02);
+    const int x02 = 2 * w02 - (KW - 1) / 2;
+    const float* org2 = d.x + (long long)sq2 * d.x_seq + (long long)(h02 - 1) * d.x_line + (long long)x02 * C;
+    f32x4 pf[NCHK];
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
+    const float* Ap = At + (ph * IWv + pw) * PITCH + kk0;
+    const float* Bp = Bt + li * PITCH + kk0;
+    // one tap group, expanded 14 times with a literal index: every register-array index below is a
+    // constant the front end sees (as a loop or a generic lambda the stages went to scratch memory).
+    // Requests of a group: the weights of group G + 2 (wrapping into the next tile) and two chunks
+    // of the next tile's patch -- spread over the first groups so that no barrier ever waits for a
+    // burst of them (loads return in order).
+#define F2G_C32_PF(Q)                                                                              \
+  if ((Q) < NCHK) {                                                                                \
+    const int h_ = h02 - 1 + (rx[(Q) < NCHK ? (Q) : 0] & 255), x_ = x02 + (rx[(Q) < NCHK ? (Q) : 0] >> 8); \
+    const bool ok_ = so[(Q) < NCHK ? (Q) : 0] >= 0 && h_ >= 0 && h_ < d.H && x_ >= 0 && x_ < d.Win;  \
+    pf[(Q) < NCHK ? (Q) : 0] = *reinterpret_cast<const f32x4*>(ok_ ? org2 + go[(Q) < NCHK ? (Q) : 0] : zero4); \
+  }
+#define F2G_C32_TAP(G, U)                                                                          \
+  if ((G) * TG + (U) < KH * KW) {                                                                  \
+    constexpr int t_ = (G) * TG + (U), dh_ = t_ / KW, j_ = t_ - dh_ * KW;                          \
+    const float* Ab = Ap + (j_ & 1) * SUBv + (dh_ * IWv + (j_ >> 1)) * PITCH;                      \
+    const float* Bb = Bp + (((G) & 1) * TG + (U)) * WB;                                            \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                             \
+      const float4 a = *reinterpret_cast<const float4*>(Ab + s4 * 4);                              \
+      const float4 b = *reinterpret_cast<const float4*>(Bb + s4 * 4);                              \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);                          \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);                        \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);                          \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc2, 0, 0, 0);                        \
+    }                                                                                              \
+  }
+#define F2G_C32_GROUP(G)                                                                           \
+  {                                                                                                \
+    constexpr int gw_ = (G) + 2 < NG ? (G) + 2 : (G) + 2 - NG;                                     \
+    constexpr int t0_ = gw_ * TG < KH * KW - 1 ? gw_ * TG : KH * KW - 1;                           \
+    constexpr int t1_ = gw_ * TG + 1 < KH * KW - 1 ? gw_ * TG + 1 : KH * KW - 1;                   \
+    ws[(G) & 1][0] = *reinterpret_cast<const f32x4*>(wrow + t0_ * C);                             \
+    ws[(G) & 1][1] = *reinterpret_cast<const f32x4*>(wrow + t1_ * C);                             \
+    F2G_C32_PF(2 * (G))                                                                            \
+    F2G_C32_PF(2 * (G) + 1)                                                                        \
+    F2G_C32_TAP(G, 0)                                                                              \
+    F2G_C32_TAP(G, 1)                                                                              \
+    *reinterpret_cast<f32x4*>(wst + ((((G) & 1) ^ 1) * TG + 0) * WB) = ws[((G) & 1) ^ 1][0];      \
+    *reinterpret_cast<f32x4*>(wst + ((((G) & 1) ^ 1) * TG + 1) * WB) = ws[((G) & 1) ^ 1][1];      \
+    __syncthreads();                                                                               \
+  }
+    static_assert(TG == 2, "the group macro handles two taps");
+    float* wst = Bt + wco * PITCH + c4 * 4;
+    const float* zero4 = c32_zero;
+    F2G_C32_GROUP(0) F2G_C32_GROUP(1) F2G_C32_GROUP(2) F2G_C32_GROUP(3) F2G_C32_GROUP(4)
+    F2G_C32_GROUP(5) F2G_C32_GROUP(6) F2G_C32_GROUP(7) F2G_C32_GROUP(8) F2G_C32_GROUP(9)
+    F2G_C32_GROUP(10) F2G_C32_GROUP(11) F2G_C32_GROUP(12) F2G_C32_GROUP(13)
+#undef F2G_C32_GROUP
+#undef F2G_C32_TAP
+#undef F2G_C32_PF
+    static_assert(NG == 14, "the call list above is the tap-group loop");
+    // ---- epilogue: bias + leaky ReLU; accumulator element e = pixel (e&3) + 8 (e>>2) + 4 hh of the wave
+    int sq, h0, w0;
+    tile_pos(tile, sq, h0, w0);
+    float* ys = d.y + (long long)sq * d.y_seq;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      const int oh = h0 + q / TW_, ow = w0 + q % TW_;
+      if (oh < d.H && ow < d.Wout) {
+        float v = acc[e] + acc2[e] + bias;
+        if (d.lrelu_slope != 0.f) v = v > 0.f ? v : d.lrelu_slope * v;
+        ys[(long long)oh * d.y_line + (long long)ow * C + li] = v;
+      }
+    }
+    // (the barrier that closed the last tap group: every wave is done with this tile's patch)
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < NCHK; ++q)
+        if (so[q] >= 0) *reinterpret_cast<f32x4*>(At + so[q]) = pf[q];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- data gradient of the same layer (transposed conv) -------------------------------------
 // gx[h, x, ci] = sum_{dh, j, co} g[h + 1 - dh, (x + 4 - j) / 2, co] * w[co, ci, dh, j]   over the taps
 // with x + 4 - j even.  Input columns of one parity e = x & 1 use the taps j = e + 2u (5 taps for even
@@ -309,6 +507,169 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_dgrad_kernel(const f2g_conv3
     cs += __shfl_xor(cs, 32);
     if (hh == 0) atomicAdd(d.colsum + li, cs);
   }
+}
+
+// ---- persistent data-gradient kernel (round 3; exact fp32): the forward kernel's structure --------
+// One column parity E per block (blockIdx.y): 15 (even) / 12 (odd) taps = 8 / 6 tap groups, all run by
+// every wave on its 32 input pixels; a block walks tiles blockIdx.x, + gridDim.x, ... of its parity
+// with the next gradient patch (7 x 16 bytes per thread) in flight; the column sums of the masked
+// result (bias gradient of the layer below) are kept per lane across tiles: one atomic per block.
+template <int TH_, int TW_, int E>
+__device__ __forceinline__ void conv32_dgrad_p_body(const f2g_conv32_desc& d, float* sm, int tiles_w,
+                                                    int tiles_h, int ntiles) {
+  constexpr int IHv = TH_ + KH - 1, GWv = TW_ + 4;
+  constexpr int NCHK = (IHv * GWv * (C / 4) + 255) / 256;
+  constexpr int NU = E ? 4 : 5, NTAP = KH * NU, NG = (NTAP + TG - 1) / TG;
+  static_assert(NG % 2 == 0 && TG == 2, "weight double buffer: two taps per group, an even group count");
+  static_assert(NCHK <= 2 * NG, "patch chunks are requested one or two per tap group");
+  float* At = sm;                       // [IHv][GWv][PITCH]
+  float* Bt = sm + IHv * GWv * PITCH;   // [2 buffers][TG taps][C][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int c4 = tid & 7;
+  const int Wp = (d.Win + 1 - E) / 2;   // input columns of this parity
+  int so[NCHK], go[NCHK], rx[NCHK];
+#pragma unroll
+  for (int q = 0; q < NCHK; ++q) {
+    const int px = (tid >> 3) + 32 * q;
+    const int r = px / GWv, xc = px - r * GWv;
+    so[q] = px < IHv * GWv ? (r * GWv + xc) * PITCH + c4 * 4 : -1;
+    go[q] = (int)(r * d.x_line) + xc * C + c4 * 4;
+    rx[q] = r | (xc << 8);
+  }
+  auto tile_pos = [&](int tile, int& sq, int& h0, int& m0) {
+    const int tw = tile % tiles_w, rest = tile / tiles_w;
+    const int th = rest % tiles_h;
+    sq = rest / tiles_h;
+    h0 = th * TH_;
+    m0 = tw * TW_;
+  };
+  const int wci = tid >> 3;
+  const float* wrow = d.w + wci * C + c4 * 4;
+  float* wst = Bt + wci * PITCH + c4 * 4;
+  const float* zero4 = c32_zero;
+  const int p = wave * 32 + li;
+  const int ph = p / TW_, pw = p % TW_;
+  const int kk0 = hh * 16;
+  const bool msk = d.mask_src != nullptr, fm = d.fm_ref != nullptr;
+  const float fmw = fm ? d.fm_w * (d.fm_wdev ? d.fm_wdev[0] : 1.f) : 0.f;
+  float cs = 0.f;
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  f32x4 ws[2][TG];
+#define F2G_C32_WT(T) ((((T) < NTAP ? (T) : NTAP - 1) / NU) * KW + E + 2 * (((T) < NTAP ? (T) : NTAP - 1) % NU))
+  {
+    int sq, h0, m0;
+    tile_pos(tile, sq, h0, m0);
+    const float* org = d.x + (long long)sq * d.x_seq + (long long)(h0 - 1) * d.x_line + (long long)(m0 - 2) * C;
+#pragma unroll
+    for (int q = 0; q < NCHK; ++q) {
+      const int h = h0 - 1 + (rx[q] & 255), c = m0 - 2 + (rx[q] >> 8);
+      const bool ok = so[q] >= 0 && h >= 0 && h < d.H && c >= 0 && c < d.Wout;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? org + go[q] : zero4);
+      if (so[q] >= 0) *reinterpret_cast<f32x4*>(At + so[q]) = v;
+    }
+    *reinterpret_cast<f32x4*>(wst) = *reinterpret_cast<const f32x4*>(wrow + F2G_C32_WT(0) * (C * C));
+    *reinterpret_cast<f32x4*>(wst + WB) = *reinterpret_cast<const f32x4*>(wrow + F2G_C32_WT(1) * (C * C));
+    ws[1][0] = *reinterpret_cast<const f32x4*>(wrow + F2G_C32_WT(2) * (C * C));
+    ws[1][1] = *reinterpret_cast<const f32x4*>(wrow + F2G_C32_WT(3) * (C * C));
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < ntiles;
+    int sq2, h02, m02;
+    tile_pos(more ? nxt : tile, sq2, h02, m02);
+    const float* org2 = d.x + (long long)sq2 * d.x_seq + (long long)(h02 - 1) * d.x_line + (long long)(m02 - 2) * C;
+    f32x4 pf[NCHK];
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc2[q] = 0.f; }
+    const float* Ap = At + ((ph + 2) * GWv + pw + 4) * PITCH + kk0;
+    const float* Bp = Bt + li * PITCH + kk0;
+#define F2G_C32_PF(Q)                                                                              \
+  if ((Q) < NCHK) {                                                                                \
+    constexpr int q_ = (Q) < NCHK ? (Q) : 0;                                                       \
+    const int h_ = h02 - 1 + (rx[q_] & 255), c_ = m02 - 2 + (rx[q_] >> 8);                         \
+    const bool ok_ = so[q_] >= 0 && h_ >= 0 && h_ < d.H && c_ >= 0 && c_ < d.Wout;                 \
+    pf[q_] = *reinterpret_cast<const f32x4*>(ok_ ? org2 + go[q_] : zero4);                         \
+  }
+#define F2G_C32_TAP(G, U)                                                                          \
+  if ((G) * TG + (U) < NTAP) {                                                                     \
+    constexpr int t_ = (G) * TG + (U), dh_ = t_ / NU, u_ = t_ - dh_ * NU;                          \
+    const float* Ab = Ap - (dh_ * GWv + u_) * PITCH;                                               \
+    const float* Bb = Bp + (((G) & 1) * TG + (U)) * WB;                                            \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                             \
+      const float4 a = *reinterpret_cast<const float4*>(Ab + s4 * 4);                              \
+      const float4 b = *reinterpret_cast<const float4*>(Bb + s4 * 4);                              \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);                          \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc2, 0, 0, 0);                        \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);                          \
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc2, 0, 0, 0);                        \
+    }                                                                                              \
+  }
+#define F2G_C32_GROUP(G)                                                                           \
+  if ((G) < NG) {                                                                                  \
+    constexpr int gw_ = ((G) + 2) % NG;                                                            \
+    ws[(G) & 1][0] = *reinterpret_cast<const f32x4*>(wrow + F2G_C32_WT(gw_ * TG) * (C * C));       \
+    ws[(G) & 1][1] = *reinterpret_cast<const f32x4*>(wrow + F2G_C32_WT(gw_ * TG + 1) * (C * C));   \
+    F2G_C32_PF(G)                                                                                  \
+    F2G_C32_PF((G) + NG)                                                                           \
+    F2G_C32_TAP(G, 0)                                                                              \
+    F2G_C32_TAP(G, 1)                                                                              \
+    *reinterpret_cast<f32x4*>(wst + ((((G) & 1) ^ 1) * TG + 0) * WB) = ws[((G) & 1) ^ 1][0];       \
+    *reinterpret_cast<f32x4*>(wst + ((((G) & 1) ^ 1) * TG + 1) * WB) = ws[((G) & 1) ^ 1][1];       \
+    __syncthreads();                                                                               \
+  }
+    F2G_C32_GROUP(0) F2G_C32_GROUP(1) F2G_C32_GROUP(2) F2G_C32_GROUP(3)
+    F2G_C32_GROUP(4) F2G_C32_GROUP(5) F2G_C32_GROUP(6) F2G_C32_GROUP(7)
+    static_assert(NG <= 8, "the call list above is the tap-group loop");
+#undef F2G_C32_GROUP
+#undef F2G_C32_TAP
+#undef F2G_C32_PF
+    // ---- epilogue: optional leaky-ReLU backward of the layer below (+ feature-matching term)
+    int sq, h0, m0;
+    tile_pos(tile, sq, h0, m0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int px = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+      const int oh = h0 + px / TW_, om = m0 + px % TW_;
+      if (oh < d.H && om < Wp) {
+        const long long off = (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + li;
+        float v = acc[q] + acc2[q];
+        if (msk) {
+          const float y = d.mask_src[off];
+          if (fm) {
+            const float dl = y - d.fm_ref[off];
+            v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+          }
+          v *= y > 0.f ? 1.f : d.mask_slope;
+        }
+        cs += v;
+        d.y[off] = v;
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < NCHK; ++q)
+        if (so[q] >= 0) *reinterpret_cast<f32x4*>(At + so[q]) = pf[q];
+    }
+    __syncthreads();
+  }
+#undef F2G_C32_WT
+  if (d.colsum) {
+    cs += __shfl_xor(cs, 32);
+    if (hh == 0) atomicAdd(d.colsum + li, cs);
+  }
+}
+
+template <int TH_, int TW_>
+__global__ __launch_bounds__(256, 2) void conv32_s2_dgrad_p_kernel(const f2g_conv32_desc d, int tiles_w0,
+                                                                  int tiles_w1, int tiles_h) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  if (blockIdx.y == 0) conv32_dgrad_p_body<TH_, TW_, 0>(d, sm, tiles_w0, tiles_h, tiles_w0 * tiles_h * d.S);
+  else conv32_dgrad_p_body<TH_, TW_, 1>(d, sm, tiles_w1, tiles_h, tiles_w1 * tiles_h * d.S);
 }
 
 // ---- weight gradient of the same layer ---------------------------------------------------------
@@ -611,6 +972,37 @@ extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) 
     attr_done = true;
   }
   const int tiles = ((d->H + TH - 1) / TH) * ((d->Wout + TW - 1) / TW);
+  static const bool persistent = !(getenv("F2G_CONV32_V2") && atoi(getenv("F2G_CONV32_V2")) == 0);
+  if (d->precision == 0 && persistent && d->x_line < (1ll << 24)) {
+    // tile shape: fewer wasted output pixels wins (8 x 16 on a tie)
+    auto waste = [&](int th, int tw) {
+      return (long long)((d->H + th - 1) / th * th) * ((d->Wout + tw - 1) / tw * tw);
+    };
+    const bool tall = waste(16, 8) < waste(8, 16);
+    const int th = tall ? 16 : 8, tw = tall ? 8 : 16;
+    const int tiles_h = (d->H + th - 1) / th, tiles_w = (d->Wout + tw - 1) / tw;
+    const long long nt = (long long)tiles_h * tiles_w * d->S;
+    if (nt < (1ll << 30)) {
+      const size_t sm8 = (size_t)(2 * ((8 + 2) * (16 + 4) * PITCH + 16) + 2 * TG * WB) * sizeof(float);
+      const size_t sm16 = (size_t)(2 * ((16 + 2) * (8 + 4) * PITCH + 16) + 2 * TG * WB) * sizeof(float);
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_fwd_p_kernel<8, 16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_fwd_p_kernel<16, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm16);
+        attr2 = true;
+      }
+      const int grid = (int)(nt < 512 ? nt : 512);     // 256 CUs x 2 resident blocks
+      if (tall)
+        hipLaunchKernelGGL((conv32_s2_fwd_p_kernel<16, 8>), dim3(grid), dim3(256), sm16,
+                           (hipStream_t)stream, *d, tiles_w, tiles_h, (int)nt);
+      else
+        hipLaunchKernelGGL((conv32_s2_fwd_p_kernel<8, 16>), dim3(grid), dim3(256), sm8,
+                           (hipStream_t)stream, *d, tiles_w, tiles_h, (int)nt);
+      return f2g_check_launch();
+    }
+  }
   if (d->precision == 1)   // w = the f2g_split_bf16 image of the packed weights
     hipLaunchKernelGGL(conv32_s2_fwd_kernel<true>, dim3(tiles, d->S), dim3(512), smem,
                        (hipStream_t)stream, *d);
@@ -637,6 +1029,37 @@ extern "C" int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream
     attr_done = true;
   }
   const int tiles = ((d->H + TH - 1) / TH) * (((d->Win + 1) / 2 + TW - 1) / TW);
+  static const bool persistent = !(getenv("F2G_CONV32_V2") && atoi(getenv("F2G_CONV32_V2")) == 0);
+  if (d->precision == 0 && persistent && d->x_line < (1ll << 24)) {
+    const int Wp0 = (d->Win + 1) / 2, Wp1 = d->Win / 2;
+    auto waste = [&](int th, int tw) {
+      return (long long)((d->H + th - 1) / th * th) * ((Wp0 + tw - 1) / tw * tw + (Wp1 + tw - 1) / tw * tw);
+    };
+    const bool tall = waste(16, 8) < waste(8, 16);
+    const int th = tall ? 16 : 8, tw = tall ? 8 : 16;
+    const int tiles_h = (d->H + th - 1) / th, tw0 = (Wp0 + tw - 1) / tw, tw1 = (Wp1 + tw - 1) / tw;
+    const long long nt0 = (long long)tiles_h * tw0 * d->S;
+    if (nt0 < (1ll << 30)) {
+      const size_t sm8 = (size_t)((8 + 2) * (16 + 4) * PITCH + 2 * TG * WB) * sizeof(float);
+      const size_t sm16 = (size_t)((16 + 2) * (8 + 4) * PITCH + 2 * TG * WB) * sizeof(float);
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad_p_kernel<8, 16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad_p_kernel<16, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm16);
+        attr2 = true;
+      }
+      const int grid = (int)(nt0 < 256 ? nt0 : 256);   // per parity: 256 CUs x 2 resident blocks in all
+      if (tall)
+        hipLaunchKernelGGL((conv32_s2_dgrad_p_kernel<16, 8>), dim3(grid, 2), dim3(256), sm16,
+                           (hipStream_t)stream, *d, tw0, tw1, tiles_h);
+      else
+        hipLaunchKernelGGL((conv32_s2_dgrad_p_kernel<8, 16>), dim3(grid, 2), dim3(256), sm8,
+                           (hipStream_t)stream, *d, tw0, tw1, tiles_h);
+      return f2g_check_launch();
+    }
+  }
   if (d->precision == 1)   // w = the f2g_split_bf16 image of the transposed tiles
     hipLaunchKernelGGL(conv32_s2_dgrad_kernel<true>, dim3(tiles, d->S, 2), dim3(512), smem,
                        (hipStream_t)stream, *d);

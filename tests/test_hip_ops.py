@@ -741,10 +741,13 @@ def test_spec_power_and_fm_loss(ops):
     close(w, sc * mask * inv, rtol=1e-4, name="fm loss weights")
 
 
-@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (4, 17, 26)])
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (4, 17, 26),
+                                     (40, 47, 39), (24, 94, 77), (48, 47, 51)])
 def test_direct_conv32_matches_implicit_gemm(ops, S, H, Win):
     """conv32.hip (LDS-tiled direct conv of the MRD band layers) against the implicit-GEMM path and
-    torch.conv2d, incl. partial tiles on every edge."""
+    torch.conv2d, incl. partial tiles on every edge; the last two cases have more tiles than the
+    persistent kernel has blocks (every block walks over several tiles, prefetched patches, the
+    weight double buffer wrapping across tiles), one per tile shape (widths 20 and 39)."""
     Wout = (Win - 1) // 2 + 1
     x = rnd(S * H * Win, 32, seed=1)
     w = rnd(32, 32, 3, 9, seed=2, scale=0.05)
@@ -761,7 +764,8 @@ def test_direct_conv32_matches_implicit_gemm(ops, S, H, Win):
     close(y, y2.cpu().double(), name="conv32-vs-gemm")
 
 
-@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (4, 17, 26), (1, 9, 33)])
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (4, 17, 26), (1, 9, 33),
+                                     (24, 94, 77), (48, 47, 51), (2, 9, 1)])
 def test_direct_conv32_dgrad_matches_autograd(ops, S, H, Win):
     """conv32.hip data gradient (direct transposed conv per column parity) against torch's conv2d
     backward in fp64, incl. odd widths and partial tiles."""
@@ -776,6 +780,36 @@ def test_direct_conv32_dgrad_matches_autograd(ops, S, H, Win):
     y.backward(gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
     ref = x.grad.permute(0, 2, 3, 1).reshape(S * H * Win, 32)
     close(gx, ref, name="conv32 dgrad")
+
+
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (24, 94, 77), (2, 8, 64)])
+def test_direct_conv32_dgrad_fused_lrelu_backward(ops, S, H, Win):
+    """The data gradient's optional epilogue: leaky-ReLU backward of the layer below (mask by that
+    layer's activation y), the feature-matching term w * sign(y - y_real) added in front of it, and
+    the column sums of the result (= the bias gradient of the layer below), against torch fp64."""
+    Wout = (Win - 1) // 2 + 1
+    w = rnd(32, 32, 3, 9, seed=2, scale=0.05)
+    gy = rnd(S * H * Wout, 32, seed=4)
+    yact = rnd(S * H * Win, 32, seed=5)
+    yact = torch.where(yact > 0, yact, 0.1 * yact)          # an activation map: leaky_relu(pre)
+    yreal = rnd(S * H * Win, 32, seed=6)
+    wdev = torch.tensor([0.7])
+    wT = w.permute(2, 3, 1, 0).reshape(27, 32, 32).contiguous()
+    x = torch.zeros(S, 32, H, Win, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w.double(), None, stride=(1, 2), padding=(1, 4))
+    y.backward(gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
+    base = x.grad.permute(0, 2, 3, 1).reshape(S * H * Win, 32)
+    for use_fm in (False, True):
+        want = base.clone()
+        if use_fm:
+            want = want + 0.25 * 0.7 * torch.sign(yact.double() - yreal.double())
+        want = want * torch.where(yact > 0, 1.0, 0.1).double()
+        gx = torch.full((S * H * Win, 32), 7.0, device=DEV)
+        cs = torch.zeros(32, device=DEV)
+        ops.conv32_s2_dgrad(g(gy), S, H, Win, Wout, g(wT), gx, mask=(g(yact), 0, 0.1),
+                            fm=(g(yreal), 0, 0.25, g(wdev)) if use_fm else None, colsum=cs)
+        close(gx, want, name=f"conv32 dgrad + lrelu bwd (fm={use_fm})")
+        close(cs, want.sum(0), rtol=1e-4, name="column sums")
 
 
 @pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 21, 51), (1, 5, 2), (2, 8, 64), (5, 17, 26)])
