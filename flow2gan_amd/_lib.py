@@ -205,6 +205,7 @@ _SIGS = {
     "f2g_sadam_update": [_P, _P, _I, _P],
     "f2g_mlp_pack": [_P, _P, _L, _P, _L, _I, _I],
     "f2g_fused_mlp": [C.POINTER(FusedMlpDesc)],
+    "f2g_fused_block": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc)],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
                                  "f2g_gemm_lean_ok", "f2g_fused_mlp_ok",

@@ -49,9 +49,15 @@ __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) {
 // (a tile count well below the 256 CUs -- 94 tiles at C = 768, B = 64 -- would leave most of the chip
 // idle, and more rows per block are not to be had: the output tile fills the registers): every
 // part adds its partial output tile atomically onto a zeroed `out`, part 0 carries b2 and the residual.
-template <int RT, int NT>
+// DW: the block computes its z tile ITSELF from the residual stream (f2g_fused_block): depthwise
+// conv (7 taps) + BiasNorm + condition add + time scale of modules.py:473-485 as the prologue, with
+// the arithmetic and the lane -> channel mapping of dwnorm4_kernel (convnext.hip: a wave owns 4
+// consecutive frames, a lane 4 consecutive channels per 256-channel chunk, all 10 input rows of a
+// frame group requested before anything is consumed) -- z never exists in HBM, and the launch,
+// the z store and the z re-read of the separate kernel are gone.
+template <int RT, int NT, bool DW>
 __global__ __launch_bounds__(256, 1)
-void fused_mlp_kernel(const f2g_fused_mlp_desc d, int spb) {
+void fused_mlp_kernel(const f2g_fused_mlp_desc d, const f2g_dwnorm_fwd_desc P, int spb) {
   constexpr int BM = 32 * RT, C = 128 * NT;
   constexpr int ZP = C * 2 + 16;               // LDS pitch of a z row (bytes)
   constexpr int KA = C / 16;                   // k steps (= weight fragments) of phase A
@@ -84,6 +90,140 @@ void fused_mlp_kernel(const f2g_fused_mlp_desc d, int spb) {
     wso += 1024;
   }
 
+  if constexpr (DW) {
+    constexpr int NCQ = (C + 255) / 256, FW = 4, RW = BM / 4;
+    const int F = P.F;
+    const float escale = expf(P.log_scale[0]);
+    constexpr float invC = 1.f / (float)C;
+    int c4[NCQ];
+    bool cok[NCQ];
+#pragma unroll
+    for (int k = 0; k < NCQ; ++k) {
+      const int c = 256 * k + 4 * lane;
+      cok[k] = c < C;
+      c4[k] = cok[k] ? c : 0;
+    }
+    auto ld4 = [](float (&o)[4], const float* p) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    };
+    // this lane's taps (channel e, tap j = tw[k][7 e + j]: 28 consecutive floats of the (C, 1, 7)
+    // checkpoint layout), depthwise bias and BiasNorm bias
+    float tw[NCQ][28], bdw[NCQ][4], bet[NCQ][4];
+#pragma unroll
+    for (int k = 0; k < NCQ; ++k) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        float t4[4];
+        ld4(t4, P.w_dw + (long long)c4[k] * 7 + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tw[k][4 * i + e] = t4[e];
+      }
+      if (P.b_dw) ld4(bdw[k], P.b_dw + c4[k]);
+      else bdw[k][0] = bdw[k][1] = bdw[k][2] = bdw[k][3] = 0.f;
+      ld4(bet[k], P.beta + c4[k]);
+    }
+    const long long last = (long long)d.rows - 1;
+    for (int g = 0; g < RW / FW; ++g) {
+      const int lr0 = w * RW + g * FW;              // first frame of the group inside the tile
+      const long long r0 = (long long)m0 + lr0;     // ... in the flattened (item, frame) rows
+      float xr[NCQ][FW + 6][4];
+#pragma unroll
+      for (int r = 0; r < FW + 6; ++r) {
+        long long rr = r0 - 3 + r;
+        rr = rr < 0 ? 0 : (rr > last ? last : rr);
+        const float* xrow = P.x + rr * P.ldx;
+#pragma unroll
+        for (int k = 0; k < NCQ; ++k) ld4(xr[k][r], xrow + c4[k]);
+      }
+      // item / frame of every output row of the group; condition and time rows
+      int fi[FW], li_[FW];
+      bool lv[FW];
+      float cp[FW][NCQ][4], te1[FW][NCQ][4];
+#pragma unroll
+      for (int i = 0; i < FW; ++i) {
+        const long long r = r0 + i;
+        lv[i] = r <= last;
+        const int rc = (int)(lv[i] ? r : last);
+        const int b = rc / F, f = rc - b * F;
+        fi[i] = f;
+        const int len_b = P.lens ? P.lens[b] : F;
+        li_[i] = len_b < F ? len_b : F;
+        const int fc = P.cproj ? f / P.up : 0;
+        const bool has = P.cproj && fc < P.Fc;
+        const float* cprow = has ? P.cproj + ((long long)b * P.Fc + fc) * P.ldcp : P.x;
+        const float* terow = P.te ? P.te + (long long)b * P.ldte : P.x;
+#pragma unroll
+        for (int k = 0; k < NCQ; ++k) {
+          ld4(cp[i][k], cprow + c4[k]);
+          ld4(te1[i][k], terow + c4[k]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (!has) cp[i][k][e] = 0.f;
+            te1[i][k][e] = P.te ? te1[i][k][e] + 1.f : 1.f;
+          }
+        }
+      }
+      // (wave-uniform) does any tap of the group leave its item or its valid length?
+      const bool interior = lv[FW - 1] && fi[FW - 1] == fi[0] + FW - 1 && fi[0] >= 3 &&
+                            fi[FW - 1] + 3 < li_[0];
+      float u[FW][NCQ][4], ssq[FW];
+#pragma unroll
+      for (int i = 0; i < FW; ++i) ssq[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCQ; ++k) {
+#pragma unroll
+        for (int i = 0; i < FW; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[i][k][e] = bdw[k][e];
+        if (interior) {
+#pragma unroll
+          for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int i = 0; i < FW; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[i][k][e] += tw[k][7 * e + j] * xr[k][i + j][e];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int i = 0; i < FW; ++i) {
+              const int fj = fi[i] + j - 3;
+              const bool ok = fj >= 0 && fj < li_[i];      // (the masked input of modules.py:473)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) u[i][k][e] += tw[k][7 * e + j] * (ok ? xr[k][i + j][e] : 0.f);
+            }
+        }
+        if (cok[k]) {
+#pragma unroll
+          for (int i = 0; i < FW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float dlt = u[i][k][e] - bet[k][e];
+              ssq[i] += dlt * dlt;
+            }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FW; ++i) {
+        const float rms2 = wave_sum(ssq[i]) * invC;
+        const float sc = escale / sqrtf(rms2);
+#pragma unroll
+        for (int k = 0; k < NCQ; ++k) {
+          if (cok[k]) {
+            unsigned short hb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float zv = lv[i] ? (u[i][k][e] * sc + cp[i][k][e]) * te1[i][k][e] : 0.f;
+              hb[e] = __builtin_bit_cast(unsigned short, (__bf16)zv);
+            }
+            *reinterpret_cast<uint2*>(zs + (lr0 + i) * ZP + c4[k] * 2) =
+                make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+          }
+        }
+      }
+    }
+  } else
   // ---- z tile -> LDS (rows past the end read as zeros: out of the buffer's range)
   if (!(F2G_MLPVAR & 4)) {
     __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
@@ -319,13 +459,13 @@ void mlp_pack_kernel(uint4* __restrict__ dst, const float* __restrict__ w1, long
   }
 }
 
-template <int RT, int NT>
-int launch_fused(const f2g_fused_mlp_desc& d, hipStream_t st) {
+template <int RT, int NT, bool DW = false>
+int launch_fused(const f2g_fused_mlp_desc& d, hipStream_t st, const f2g_dwnorm_fwd_desc* dw = nullptr) {
   constexpr int BM = 32 * RT, C = 128 * NT;
   constexpr size_t smem = (size_t)BM * (C * 2 + 16) + (size_t)BM * PP;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<RT, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_mlp_kernel<RT, NT, DW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
@@ -350,7 +490,9 @@ int launch_fused(const f2g_fused_mlp_desc& d, hipStream_t st) {
       return F2G_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL((fused_mlp_kernel<RT, NT>), dim3(tiles, J), dim3(256), smem, st, d, spb);
+  f2g_dwnorm_fwd_desc P{};
+  if (dw) P = *dw;
+  hipLaunchKernelGGL((fused_mlp_kernel<RT, NT, DW>), dim3(tiles, J), dim3(256), smem, st, d, P, spb);
   return f2g_check_launch();
 }
 
@@ -393,4 +535,29 @@ extern "C" int f2g_fused_mlp(const f2g_fused_mlp_desc* dp, f2g_stream_t stream) 
   if (d.C == 768) return launch_fused<2, 6>(d, st);
   if (d.C == 512) return launch_fused<3, 4>(d, st);
   return launch_fused<4, 3>(d, st);
+}
+
+extern "C" int f2g_fused_block(const f2g_dwnorm_fwd_desc* wp, const f2g_fused_mlp_desc* mp,
+                               f2g_stream_t stream) {
+  if (!wp || !mp) return F2G_EINVAL;
+  const f2g_dwnorm_fwd_desc& w = *wp;
+  f2g_fused_mlp_desc d = *mp;
+  auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (!w.x || !w.w_dw || !w.beta || !w.log_scale || !d.wp || !d.alpha || !d.out) return F2G_EINVAL;
+  if (!f2g_fused_mlp_ok(d.C, d.H) || w.C != d.C || w.K != 7 || w.B <= 0 || w.F <= 0 ||
+      (long long)w.B * w.F != d.rows || (w.ldx & 3) || w.ldx < d.C || !al16(w.x) || !al16(w.w_dw) ||
+      !al16(w.beta) || (w.b_dw && !al16(w.b_dw)) || (w.cproj && (!al16(w.cproj) || (w.ldcp & 3) || w.up < 1)) ||
+      (w.te && (!al16(w.te) || (w.ldte & 3))) || (d.res && (d.ldres < d.C || (d.ldres & 3) || !al16(d.res))) ||
+      d.ldo < d.C || (d.ldo & 3) || !al16(d.out) || !al16(d.wp) || (d.gamma && !al16(d.gamma)) ||
+      (long long)d.rows * d.ldo * 4 >= 0x7ff00000ll || (d.res && (long long)d.rows * d.ldres * 4 >= 0x7ff00000ll)) {
+    f2g_set_error("f2g_fused_block: unsupported shape (C in {384, 512, 768}, 7 taps, rows = B * F, "
+                  "16-byte aligned tensors with row strides in whole float4s)");
+    return F2G_EINVAL;
+  }
+  d.z = w.x;       // (unused by the DW instances; keeps the descriptor valid)
+  d.ldz = 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (d.C == 768) return launch_fused<2, 6, true>(d, st, wp);
+  if (d.C == 512) return launch_fused<3, 4, true>(d, st, wp);
+  return launch_fused<4, 3, true>(d, st, wp);
 }

@@ -119,9 +119,18 @@ def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0,
     dev = x.device
     rows, Cc, Hh = B * F, bp.C, bp.H
     fmt = ops.operand_formats_ok(Cc, Hh)
+    if fmt == 2 and not keep and ops.FUSED_BLOCK and bp.K == 7 and ops.fused_mlp_applies(Cc, Hh) \
+            and x.stride(0) % 4 == 0:
+        # plain-bf16 inference (BASELINE config 2): the whole block in one launch -- z is computed in
+        # the fused kernel's prologue and lives in LDS only, the hidden activation on chip
+        out = ops.empty(rows, Cc, device=dev)
+        ops.fused_block(x, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta, bp.log_scale.reshape(1),
+                        ops.mlp_pack(bp.w1, bp.w2), bp.b1, bp.alpha, bp.b2, bp.gamma.reshape(Cc), out,
+                        Hh, cproj, ldcp, Fc, up, cp_off, te, ldte, te_off)
+        return out, None, (None, None, None, 0)
     if fmt == 2 and not keep:
-        # plain-bf16 inference (BASELINE config 2): z and the hidden activation live in HBM as
-        # bf16, written by their producers in the layout the lean GEMM kernel reads
+        # (two launches: z and the hidden activation live in HBM as bf16, written by their producers
+        # in the layout the lean GEMM kernel reads)
         z = torch.empty(rows, Cc, device=dev, dtype=torch.bfloat16)
         ops.dwnorm_fwd(x, z, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta, bp.log_scale.reshape(1),
                        cproj, ldcp, Fc, up, cp_off, te, ldte, te_off, z_format=2)

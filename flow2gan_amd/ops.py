@@ -833,6 +833,31 @@ def fused_mlp(z, wp, b1, alpha, b2, res, gamma, out, rows: int, Cc: int, Hh: int
     return out
 
 
+def fused_block(x, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, wp, b1, alpha, b2, gamma, out,
+                Hh: int, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0, te=None, ldte=0, te_off=0,
+                parts: int = 0):
+    """out = x-block of ConvNeXtBlock.forward (modules.py:473-495) in one launch (plain-bf16
+    inference): dwconv7 + BiasNorm + cond + time scale -> z (bf16, LDS only) -> fused MLP ->
+    + gamma * x.  Arguments as dwnorm_fwd / fused_mlp."""
+    f = _dw_desc(x, x.stride(0), None, 0, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj, ldcp,
+                 Fc, up, cp_off, te, ldte, te_off, None)
+    d = L.FusedMlpDesc()
+    d.parts = parts
+    d.wp, d.b1, d.alpha, d.b2 = ptr(wp), ptr(b1), ptr(alpha), ptr(b2)
+    d.res, d.ldres, d.gamma = ptr(x), x.stride(0), ptr(gamma)
+    d.out, d.ldo = ptr(out), out.stride(0)
+    d.rows, d.C, d.H = B * F, Cc, Hh
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_fused_block", C.byref(f), C.byref(d)), 4.0 * B * F * Cc * Hh,
+                        (0, B * F, Cc, 2 * Hh), path="fused-mlp")
+    else:
+        call("f2g_fused_block", C.byref(f), C.byref(d))
+    return out
+
+
+FUSED_BLOCK = _os.environ.get("F2G_FUSED_BLOCK", "1") != "0"
+
+
 # ------------------------------------------------------------------ fused block kernels
 def _dw_desc(x, ldx, z, ldz, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj, ldcp, Fc, up,
              cp_off, te, ldte, te_off, rstd) -> DwnormFwd:

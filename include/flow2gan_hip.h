@@ -607,6 +607,13 @@ int f2g_fused_mlp_ok(int32_t C, int32_t H);
 int f2g_mlp_pack(void* dst, const float* w1, int64_t ld1, const float* w2, int64_t ld2, int32_t C,
                  int32_t H, f2g_stream_t stream);
 int f2g_fused_mlp(const f2g_fused_mlp_desc* d, f2g_stream_t stream);
+/* The whole ConvNeXt block of modules.py:473-495 in ONE launch (plain-bf16 inference): the z tile of
+ * a row block is computed in the kernel's prologue from the residual stream x -- depthwise conv (K = 7),
+ * BiasNorm, condition add, time scale, exactly f2g_dwnorm_fwd's arithmetic, rounded to bf16 into LDS --
+ * and feeds the fused MLP above; neither z nor the hidden activation exists in HBM.  `dw` names x,
+ * the masks and the dwnorm parameters (its z / rstd / z_format fields are ignored), `mlp` the rest
+ * (its z / ldz are ignored; mlp->rows must equal dw->B * dw->F, mlp->res is normally dw->x). */
+int f2g_fused_block(const f2g_dwnorm_fwd_desc* dw, const f2g_fused_mlp_desc* mlp, f2g_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -966,3 +966,48 @@ def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
     p0 = (a0.clamp(min=0) + al.double() * a0.clamp(max=0)).float().to(torch.bfloat16)
     want2 = p0.double() @ w2b.double().t()
     assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())
+
+
+@pytest.mark.parametrize("C,B,Fr,up", [(768, 3, 47, 1), (512, 5, 94, 2), (384, 3, 94, 4), (512, 2, 9, 1)])
+def test_fused_block_matches_dwnorm_plus_fused_mlp(ops, C, B, Fr, up):
+    """f2g_fused_block (dwconv7 + BiasNorm + cond + time scale in the fused kernel's prologue, z in
+    LDS only) against the two kernels it replaces -- f2g_dwnorm_fwd writing z as bf16, then
+    f2g_fused_mlp: the same arithmetic in the same order, so the outputs agree to fp32 rounding --
+    with ragged lengths, items shorter than a tile (tiles straddle item boundaries), a condition
+    shorter than the frames and a stacked cond / time buffer read at an offset."""
+    H, K = 3 * C, 7
+    Fc = (Fr + up - 1) // up - (1 if up > 1 else 0)      # the last condition row is missing: zeros
+    gen = torch.Generator().manual_seed(C + Fr)
+    x = torch.randn(B * Fr, C, generator=gen)
+    lens = torch.tensor([Fr, max(1, Fr - 5), max(1, Fr // 2), Fr, 3][:B])
+    w_dw = torch.randn(C, 1, K, generator=gen) * 0.3
+    b_dw = torch.randn(C, generator=gen) * 0.1
+    beta = torch.randn(C, generator=gen) * 0.1
+    ls = torch.tensor([0.7])
+    NC = 2 * C
+    cp_all = torch.randn(B * Fc, NC, generator=gen)
+    te_all = torch.randn(B, NC, generator=gen) * 0.3
+    w1 = torch.randn(H, C, generator=gen) * 0.05
+    w2 = torch.randn(C, H, generator=gen) * 0.03
+    b1 = torch.randn(H, generator=gen) * 0.1
+    al = 0.25 + 0.2 * torch.randn(H, generator=gen)
+    b2 = torch.randn(C, generator=gen) * 0.1
+    gam = 0.5 + torch.rand(C, generator=gen)
+    xd, lens_d = g(x), g(lens.int())
+    wp = ops.mlp_pack(g(w1), g(w2))
+    args = (B, Fr, C, K, lens_d, g(w_dw), g(b_dw), g(beta), g(ls))
+    for use_cond in (True, False):
+        cpa = (g(cp_all), NC, Fc, up, C // 2, g(te_all), NC, C // 2) if use_cond else (None, 0, 0, 1, 0, None, 0, 0)
+        z = torch.empty(B * Fr, C, device=DEV, dtype=torch.bfloat16)
+        ops.dwnorm_fwd(xd, z, *args, *cpa, z_format=2)
+        want = torch.empty(B * Fr, C, device=DEV)
+        ops.fused_mlp(z, wp, g(b1), g(al), g(b2), xd, g(gam), want, B * Fr, C, H)
+        got = torch.full((B * Fr, C), float("nan"), device=DEV)
+        ops.fused_block(xd, *args, wp, g(b1), g(al), g(b2), g(gam), got, H, *cpa)
+        assert torch.isfinite(got).all()
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        # identical z (same lane -> channel mapping, same order of operations); what may differ is
+        # nothing but the compiler's contraction choices inside the prologue
+        assert err < 2e-3 * scale, (use_cond, err, scale)
+        assert float((got - want).pow(2).mean().sqrt()) < 2e-5 * scale
