@@ -101,7 +101,7 @@ class FftDesc(C.Structure):  # == f2g_fft_desc
     _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("hop", C.c_int32), ("n_fft", C.c_int32),
                 ("F", C.c_int32), ("rows", C.c_int32), ("window", C.c_void_p), ("twiddle", C.c_void_p),
                 ("spec", C.c_void_p), ("ld_spec", C.c_int64), ("interleaved", C.c_int32),
-                ("_pad", C.c_int32), ("frames", C.c_void_p), ("ld_frames", C.c_int64)]
+                ("spec_cols", C.c_int32), ("frames", C.c_void_p), ("ld_frames", C.c_int64)]
 
 
 class Mpd0Desc(C.Structure):  # == f2g_mpd0_desc

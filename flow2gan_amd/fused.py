@@ -500,9 +500,12 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     bf16_chain = (not keep) and ops.GEMM_PRECISION == 2 and SPEC_PAD and ops.BF16_IMAGES \
         and ops.LEAN_SPLIT and Kc % 64 == 0 and N % 64 == 0
     if ops.fft_applies(N):
-        packed = ops.zeros(rows, ldp, device=dev) if SPEC_PAD else ops.empty(rows, ldp, device=dev)
-        ops.stft_fft(x, N, hop, F, packed)
-        pk = mat(packed, rows, Kc)
+        # LDS-butterfly FFT; the kernel writes the zero padding of the rows itself, and in the
+        # plain-bf16 inference chain the spectrum as the bf16 tensor in_proj's GEMM reads
+        packed = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16) if bf16_chain \
+            else ops.empty(rows, ldp, device=dev)
+        ops.stft_fft(x, N, hop, F, packed, zero_pad=True)
+        pk = mat(packed, rows, Kc, split=2 if bf16_chain else 0)
     elif bf16_chain:
         packed = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16)
         gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1)
@@ -542,14 +545,18 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
         if keep:
             saved_blocks.append((xcur, z, a))
         xcur = y
-    ybf = bf16_chain and lens_f is None
+    ifft = ops.fft_applies(N)       # inverse transform through the LDS FFT instead of the DFT GEMM
+    ybf = bf16_chain and lens_f is None       # (the inverse FFT reads bf16 spectra as well)
     yspec = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16) if ybf else ops.empty(rows, ldp, device=dev)
     gemm(mat(xcur, rows, Cc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), yspec,
          bias=_pad_vec(bv.b_out, Kc), split_k=1)
     if lens_f is not None:
         ops.mask_rows(yspec, B, F, Cin, lens_f)
     frames = ops.empty(rows, N, device=dev)
-    gemm(mat(yspec, rows, Kc, split=2 if ybf else 0), mat(_pad_cols(Wi, Kc)), frames, split_k=1)
+    if ifft:
+        ops.istft_fft(yspec, N, F, frames)
+    else:
+        gemm(mat(yspec, rows, Kc, split=2 if ybf else 0), mat(_pad_cols(Wi, Kc)), frames, split_k=1)
     if lanes is not None:
         lanes.chain_enter()  # pred is accumulated branch after branch
     ops.istft_ola(frames, pred, B, F, N, hop, T, window, wbranch_row, wscale, accumulate)
@@ -577,8 +584,12 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
     Fce = cproj.shape[0] // B
     gfr = ops.empty(rows, N, device=dev)
     ops.istft_ola_bwd(g_pred, gfr, B, F, N, hop, T, window, wbranch_row, wscale)
-    gy = ops.empty(rows, ldp, device=dev)
-    gemm(mat(gfr, rows, N), mat(_pad_cols(Wi, Kc)), gy, form=1)      # pad columns come out zero
+    if ops.fft_applies(N):
+        gy = ops.empty(rows, ldp, device=dev)
+        ops.istft_fft_adjoint(gfr, N, F, gy, zero_pad=True)             # (pad columns written as zeros)
+    else:
+        gy = ops.empty(rows, ldp, device=dev)
+        gemm(mat(gfr, rows, N), mat(_pad_cols(Wi, Kc)), gy, form=1)      # pad columns come out zero
     if lens_f is not None:
         ops.mask_rows(gy, B, F, Cin, lens_f)
     g_wout = ops.zeros(Cin, Cc, device=dev)

@@ -1187,7 +1187,9 @@ def mpdpost_wgrad(y, S, H, halo, g, gw):
 
 # ------------------------------------------------------------------ LDS-butterfly FFT (n_fft >= 1024)
 USE_FFT = _os.environ.get("F2G_FFT", "1") != "0"
-FFT_MIN = 1024          # smaller transforms stay on the DFT GEMM (K <= 512: a short, full-rate GEMM)
+# transforms below FFT_MIN stay on the DFT GEMM (the 32- / 64-point mel-reconstruction scales: a
+# handful of MFMAs per frame).  F2G_FFT_MIN=1024 restores round 2's split (LDS FFT for n_fft >= 1024 only).
+FFT_MIN = int(_os.environ.get("F2G_FFT_MIN", "128"))
 _FFT_TABLES = {}
 
 
@@ -1208,8 +1210,13 @@ def _fft_tables(n_fft: int, device):
     return _FFT_TABLES[key]
 
 
-def stft_fft(x, n_fft: int, hop: int, F: int, spec, interleaved: bool = False):
-    """spec (B*F, ld) = STFT of x (B, T) (center, reflect, periodic hann) through the LDS FFT."""
+def _spec_flags(spec, interleaved: bool) -> int:
+    return (1 if interleaved else 0) | (2 if spec.dtype == torch.bfloat16 else 0)
+
+
+def stft_fft(x, n_fft: int, hop: int, F: int, spec, interleaved: bool = False, zero_pad: bool = False):
+    """spec (B*F, ld) = STFT of x (B, T) (center, reflect, periodic hann) through the LDS FFT.  spec
+    may be a bf16 tensor (planar rows); zero_pad: the kernel also zeroes columns [n_fft + 2, ld)."""
     B, T = x.shape
     pad = n_fft // 2
     Tp = pad4(T + 2 * pad)
@@ -1219,7 +1226,8 @@ def stft_fft(x, n_fft: int, hop: int, F: int, spec, interleaved: bool = False):
     d = L.FftDesc()
     d.x, d.x_stride, d.hop, d.n_fft, d.F, d.rows = ptr(xp), Tp, hop, n_fft, F, B * F
     d.window, d.twiddle = ptr(win), ptr(tw)
-    d.spec, d.ld_spec, d.interleaved = ptr(spec), spec.stride(0), 1 if interleaved else 0
+    d.spec, d.ld_spec, d.interleaved = ptr(spec), spec.stride(0), _spec_flags(spec, interleaved)
+    d.spec_cols = spec.shape[1] if zero_pad else 0
     call("f2g_fft_frames", C.byref(d), 0)
     d._keep = (xp, win, tw)
     return spec
@@ -1237,6 +1245,34 @@ def stft_fft_adjoint(gspec, n_fft: int, F: int, gframes, interleaved: bool = Fal
     d.frames, d.ld_frames = ptr(gframes), gframes.stride(0)
     call("f2g_fft_frames", C.byref(d), 1)
     return gframes
+
+
+def istft_fft(spec, n_fft: int, F: int, frames):
+    """frames (rows, n_fft) = the iSTFT's windowed inverse real transform of the planar half spectra
+    spec (rows, ld) (f2g_fft_frames mode 2: 1/N, doubled interior bins, Im of DC / Nyquist ignored,
+    hann window): what istft_ola overlap-adds (the inverse-DFT GEMM's output)."""
+    win, tw = _fft_tables(n_fft, spec.device)
+    d = L.FftDesc()
+    d.hop, d.n_fft, d.F, d.rows = 0, n_fft, F, frames.shape[0]
+    d.window, d.twiddle = ptr(win), ptr(tw)
+    d.spec, d.ld_spec, d.interleaved = ptr(spec), spec.stride(0), _spec_flags(spec, False)
+    d.frames, d.ld_frames = ptr(frames), frames.stride(0)
+    call("f2g_fft_frames", C.byref(d), 2)
+    return frames
+
+
+def istft_fft_adjoint(gframes, n_fft: int, F: int, gspec, zero_pad: bool = False):
+    """gspec (rows, ld) columns [0, n_fft + 2) = gradient of the bins given the gradient of the
+    windowed inverse-transformed frames (mode 3); columns beyond are zeroed (zero_pad) or left alone."""
+    win, tw = _fft_tables(n_fft, gframes.device)
+    d = L.FftDesc()
+    d.hop, d.n_fft, d.F, d.rows = 0, n_fft, F, gframes.shape[0]
+    d.window, d.twiddle = ptr(win), ptr(tw)
+    d.spec, d.ld_spec, d.interleaved = ptr(gspec), gspec.stride(0), 0
+    d.spec_cols = gspec.shape[1] if zero_pad else 0
+    d.frames, d.ld_frames = ptr(gframes), gframes.stride(0)
+    call("f2g_fft_frames", C.byref(d), 3)
+    return gspec
 
 
 def stft_frames(x, n_fft: int, hop: int, F: int) -> Operand:

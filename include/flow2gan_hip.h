@@ -366,13 +366,20 @@ int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, float w, co
 int f2g_lrelu_bwd_colsum(float* g, const float* y_act, const float* f_real, float w,
                          const float* wdev, float slope, int32_t rows, int32_t C, int64_t ld,
                          float* colsum, f2g_stream_t stream);
-/* Batched real FFT of STFT frames through LDS butterflies (fft.hip; modules.py:69-78)
- * for n_fft = 256..4096 (power of two).  rows = items * F frames; frame m of an item is the n_fft
- * samples x[item*x_stride + m*hop + n] of the REFLECT-PADDED signal (f2g_reflect_pad), multiplied by
- * `window`.  spec rows are planar [Re(0..N/2) | Im(0..N/2)] or interleaved [Re0, Im0, ...].
- *   adjoint = 0: spec = FFT(window * frame)                     (replaces the windowed-DFT GEMM)
- *   adjoint = 1: frames[row, n] = window[n] * Re sum_{k<=N/2} (spec_r[k] + i spec_i[k]) e^{+i theta}
- *                (the gradient of the frames given the gradient of the stored bins)
+/* Batched real FFT of STFT frames through LDS butterflies (fft.hip; modules.py:69-78 torch.stft,
+ * modules.py:106-115 torch.istft) for n_fft = 64..4096 (power of two).  rows =
+ * items * F frames; frame m of an item is the n_fft samples x[item*x_stride + m*hop + n] of the
+ * REFLECT-PADDED signal (f2g_reflect_pad).  spec rows are planar [Re(0..N/2) | Im(0..N/2)] or
+ * interleaved [Re0, Im0, ...].
+ *   mode 0: spec = FFT(window * frame)                          (replaces the windowed-DFT GEMM)
+ *   mode 1: frames[row, n] = window[n] * Re sum_{k<=N/2} (spec_r[k] + i spec_i[k]) e^{+i theta}
+ *           (the gradient of the frames given the gradient of the stored bins)
+ *   mode 2: the iSTFT's windowed inverse transform (what f2g_istft_ola overlap-adds):
+ *           frames[row, n] = window[n] (1/N) Re sum_{k<=N/2} c_k (spec_r[k] + i spec_i[k]) e^{+i theta},
+ *           c_0 = c_{N/2} = 1, else 2; spec_i[0] and spec_i[N/2] are ignored, as torch.istft does
+ *   mode 3: its adjoint (gradient of the bins given the gradient g of those frames, read from
+ *           `frames`): spec_r[k] = (c_k/N) sum_n window[n] g[n] cos, spec_i[k] = -(c_k/N) sum_n
+ *           window[n] g[n] sin, spec_i[0] = spec_i[N/2] = 0
  * twiddle: n_fft/2 pairs (cos, -sin)(2 pi j / n_fft). */
 typedef struct {
   const float* x;
@@ -382,11 +389,14 @@ typedef struct {
   const float* twiddle;
   float* spec;
   int64_t ld_spec;
-  int32_t interleaved, _pad;
+  int32_t interleaved; /* bit 0: interleaved rows (else planar); bit 1: spec is a bf16 tensor (planar
+                        * rows only, ld_spec in elements): the operand format of the bf16 GEMMs */
+  int32_t spec_cols;   /* modes 0 / 3: columns [n_fft + 2, spec_cols) of every row are written as
+                        * zeros (0: leave them alone) */
   float* frames;
   int64_t ld_frames;
 } f2g_fft_desc;
-int f2g_fft_frames(const f2g_fft_desc* d, int32_t adjoint, f2g_stream_t stream);
+int f2g_fft_frames(const f2g_fft_desc* d, int32_t mode, f2g_stream_t stream);
 
 /* out (B, Tp) = reflect padding of x (B, T) by `pad` samples on both sides (torch.stft center=True,
  * modules.py:69-78), zeros from T + 2*pad to Tp (row length, a multiple of 4): the STFT framing

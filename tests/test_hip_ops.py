@@ -313,7 +313,9 @@ def test_stft_as_windowed_gemm(ops, n_fft, hop, T):
 
 
 @pytest.mark.parametrize("n_fft,hop,T,inter", [(1024, 256, 6000, False), (2048, 512, 24000, True),
-                                               (4096, 1024, 9000, False), (1024, 256, 5003, True)])
+                                               (4096, 1024, 9000, False), (1024, 256, 5003, True),
+                                               (512, 256, 6000, False), (256, 128, 5003, False),
+                                               (128, 64, 6001, False), (512, 128, 4000, True)])
 def test_stft_lds_fft_forward_and_adjoint(ops, n_fft, hop, T, inter):
     """LDS-butterfly FFT (fft.hip) against torch.stft in float64 (modules.py:69-78): spectrum in the
     planar and the interleaved row layout, and its adjoint against autograd."""
@@ -342,6 +344,50 @@ def test_stft_lds_fft_forward_and_adjoint(ops, n_fft, hop, T, inter):
     ops.frames_fold(gfr, gx, B, Fr, n_fft, hop, T, False)
     (want * gs[:, :2 * nb].double()).sum().backward()
     close(gx, xd.grad, rtol=5e-6, name="fft-stft-adjoint")
+
+
+@pytest.mark.parametrize("n_fft,hop,T", [(512, 256, 6000), (256, 128, 5003), (128, 64, 6001), (1024, 256, 24000)])
+def test_istft_lds_fft_against_torch_istft(ops, n_fft, hop, T):
+    """The windowed inverse real transform of the iSTFT through the LDS FFT (f2g_fft_frames mode 2)
+    + the overlap-add kernel against torch.istft in float64 (modules.py:106-115), with junk in Im(DC) /
+    Im(Nyquist) (torch ignores them) and ragged row counts (frames not a multiple of 4); and its
+    adjoint (mode 3) against autograd through torch.istft."""
+    B = 3
+    assert ops.fft_applies(n_fft)
+    Fr = 1 + T // hop
+    nb = n_fft // 2 + 1
+    ld = (2 * nb + 63) // 64 * 64
+    spec = rnd(B * Fr, ld, seed=21, scale=0.3)
+    win = torch.hann_window(n_fft)
+    frames = torch.full((B * Fr, n_fft), 7.0, device=DEV)
+    ops.istft_fft(g(spec), n_fft, Fr, frames)
+    out = torch.empty(B, T, device=DEV)
+    ops.istft_ola(frames, out, B, Fr, n_fft, hop, T, g(win), None, 1.0, False)
+    sr = spec[:, :nb].reshape(B, Fr, nb).permute(0, 2, 1).double().requires_grad_(True)
+    si = spec[:, nb:2 * nb].reshape(B, Fr, nb).permute(0, 2, 1).double().requires_grad_(True)
+    y = torch.istft(torch.complex(sr, si), n_fft, hop, n_fft, win.double(), center=True)
+    Ty = y.shape[1]
+    n = min(T, Ty)
+    close(out[:, :n], y[:, :n].detach(), rtol=2e-5, name="ifft + ola")
+    if T > Ty:
+        assert float(out[:, Ty:].abs().max()) == 0.0       # convert_length pads with zeros
+    # adjoint of the inverse transform alone: <gf, frames(spec)> differentiated w.r.t. the bins
+    gf = rnd(B * Fr, n_fft, seed=22)
+    gsp = torch.zeros(B * Fr, ld, device=DEV)
+    ops.istft_fft_adjoint(g(gf), n_fft, Fr, gsp)
+    k = torch.arange(nb).double()
+    nn = torch.arange(n_fft).double()
+    ang = 2 * torch.pi * k[:, None] * nn[None] / n_fft
+    c = torch.full((nb,), 2.0, dtype=torch.double)
+    c[0] = c[-1] = 1.0
+    gw = gf.double() * win.double()[None]
+    want_r = (gw @ torch.cos(ang).t()) * c / n_fft
+    want_i = -(gw @ torch.sin(ang).t()) * c / n_fft
+    want_i[:, 0] = 0.0
+    want_i[:, -1] = 0.0
+    close(gsp[:, :nb], want_r, rtol=2e-5, name="ifft adjoint re")
+    close(gsp[:, nb:2 * nb], want_i, rtol=2e-5, name="ifft adjoint im")
+    assert float(gsp[:, 2 * nb:].abs().max()) == 0.0
 
 
 def test_stft_fft_agrees_with_dft_gemm(ops):
