@@ -768,18 +768,31 @@ class Lanes:
 
 
 def split_for(reduction_rows: int, out_tiles: int) -> int:
-    """Split-K factor for weight-gradient GEMMs: fill ~2 waves of the 256 CUs."""
-    slots = 512  # 256 CUs x 2 resident blocks
-    smax = max(1, min(1024, reduction_rows // 256))
-    cands = set(range(1, 17)) | {(slots * m + out_tiles - 1) // out_tiles for m in (1, 2)}
-    best, best_eff = 1, 0.0
-    for s in sorted(c for c in cands if 1 <= c <= smax):
-        blocks = out_tiles * s
-        eff = blocks / (((blocks + slots - 1) // slots) * slots)
-        # prefer fewer splits (fewer atomics) unless occupancy improves by > 3 % (relative)
-        if eff > best_eff * 1.03:
-            best, best_eff = s, eff
-    return best
+    """Split-K factor for weight-gradient GEMMs (form 2; 128 x 128 output tiles, atomic accumulation).
+
+    Measured (tools/wgrad_probe.py, 14 shapes x 15 factors): what matters is how the blocks =
+    tiles * s fill ROUNDS OF 256 (one block per CU) -- a count just above a multiple of 256 is the
+    worst case (27 tiles: s = 9 -> 243 blocks 214 us, s = 10 -> 270 blocks 319 us), just below the
+    best; among well-filled counts, "all blocks co-resident as two per CU" (<= 512) wins when it
+    fills its rounds within 5 % of the best candidate, otherwise the fewest splits among the best
+    fills (fewer atomics); a chunk keeps >= 16 K slabs."""
+    slabs = max(1, reduction_rows // 32)
+    smax = max(1, min(512, slabs // 16))
+    cands = set(range(1, min(smax, 64) + 1))
+    for m in range(1, 9):
+        s = (256 * m) // out_tiles
+        if 1 <= s <= smax:
+            cands.add(s)
+
+    def fill(s):
+        b = out_tiles * s
+        return b / (((b + 255) // 256) * 256)
+
+    best = max(fill(s) for s in cands)
+    pair = [s for s in cands if out_tiles * s <= 512 and fill(s) >= best - 0.05]
+    if pair:
+        return max(pair)
+    return min(s for s in cands if fill(s) >= best - 0.02)
 
 
 def wgrad(dY, M: int, ldy: int, X: Operand, g_out, ldg: Optional[int] = None, out_offset: int = 0,
