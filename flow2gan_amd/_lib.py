@@ -66,6 +66,7 @@ class DwnormBwd(C.Structure):
         ("f", DwnormFwd), ("gz", C.c_void_p), ("ldgz", C.c_int64), ("du", C.c_void_p),
         ("lddu", C.c_int64), ("g_cproj", C.c_void_p), ("g_te", C.c_void_p),
         ("g_beta", C.c_void_p), ("g_log_scale", C.c_void_p), ("partials", C.c_void_p),
+        ("g_cproj_store", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 
@@ -206,6 +207,7 @@ _SIGS = {
     "f2g_mlp_pack": [_P, _P, _L, _P, _L, _I, _I],
     "f2g_fused_mlp": [C.POINTER(FusedMlpDesc)],
     "f2g_fused_block": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc)],
+    "f2g_fused_block_multi": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc), C.c_int32],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
                                  "f2g_gemm_lean_ok", "f2g_fused_mlp_ok",

@@ -259,17 +259,55 @@ __global__ __launch_bounds__(256, (BWD || (FW == 4 && NCH == 3)) ? 2 : 3) void d
     ld4(te1[k], (P.te ? P.te + (long long)b * P.ldte : P.x) + c4[k]);
   }
   // 2. taps -> LDS, transposed, while the rows are on their way
-  if (K < 7)
+  if (K == 7) {
+    // the model's case: the (C, 1, 7) block is read as 7C/4 float4s, all of a thread's loads in
+    // flight together (one memory round trip instead of one per loop trip), divisions by the
+    // constant 7 (the runtime-K loop below costs ~35 VALU instructions per element)
+    constexpr int NQ = (7 * NCH * 256 / 4 + 255) / 256;
+    const int nq = 7 * C / 4;       // C % 4 == 0
+    float4 q[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int i4 = threadIdx.x + 256 * n;
+      q[n] = reinterpret_cast<const float4*>(P.w_dw)[i4 < nq ? i4 : 0];
+    }
+    float bq[NCH], tq[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int ic = i < C ? i : 0;
+      bq[k] = P.b_dw ? P.b_dw[ic] : 0.f;
+      tq[k] = P.beta[ic];
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int i4 = threadIdx.x + 256 * n;
+      if (i4 < nq) {
+        const float v[4] = {q[n].x, q[n].y, q[n].z, q[n].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned i = 4u * i4 + e, c = i / 7u, j = i - 7u * c;
+          wl[j * C + c] = v[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < C) { bl[i] = bq[k]; tl[i] = tq[k]; }
+    }
+  } else {
     for (int i = threadIdx.x; i < 7 * C; i += 256) wl[i] = 0.f;
-  const int koff = (7 - K) / 2;
-  if (K < 7) __syncthreads();
-  for (int i = threadIdx.x; i < C * K; i += 256) {
-    const int c = i / K, j = i - c * K;
-    wl[(j + koff) * C + c] = P.w_dw[i];
-  }
-  for (int i = threadIdx.x; i < C; i += 256) {
-    bl[i] = P.b_dw ? P.b_dw[i] : 0.f;
-    tl[i] = P.beta[i];
+    const int koff = (7 - K) / 2;
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * K; i += 256) {
+      const int c = i / K, j = i - c * K;
+      wl[(j + koff) * C + c] = P.w_dw[i];
+    }
+    for (int i = threadIdx.x; i < C; i += 256) {
+      bl[i] = P.b_dw ? P.b_dw[i] : 0.f;
+      tl[i] = P.beta[i];
+    }
   }
   __syncthreads();
 
@@ -408,8 +446,8 @@ __global__ __launch_bounds__(256, (BWD || (FW == 4 && NCH == 3)) ? 2 : 3) void d
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
           if (cok[k] && has_cp) {
-            float o[4];
-            ld4(o, grow + c4[k]);
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!D.g_cproj_store) ld4(o, grow + c4[k]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += gcp[k][e];
             st4(grow + c4[k], o);
@@ -558,13 +596,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const f2g_dwconv_bwd_de
 
 
 // Vectorised variant (K == 7, C % 4 == 0, aligned rows).  Work unit of a WAVE: 256 channels (4 per
-// lane) x a strip of DWS_ROUNDS x 4 frames; per round all 10 + 10 + 4 rows (du and x with the
+// lane) x a strip of DWS_ROUNDS x DWS_FR frames; per round all 14 + 14 + 8 rows (du and x with the
 // +-3 halo, the residual gradient) are requested back to back as dwordx4 loads, the halo re-reads
 // are cache hits.  Tap / bias / scale gradients stay in registers over the strip, the 4 waves of
 // a block (4 consecutive strips of the same channels) are combined through LDS, and one partial
 // row per block goes to the workspace (reduced by f2g_colsum: no atomics on the hot rows).
-constexpr int DWS_ROUNDS = 4;
-constexpr int DWS_STRIP = 4 * DWS_ROUNDS;
+constexpr int DWS_FR = 8;        // frames per round: 8 + 6 rows of du and x, 8 of the residual gradient in flight
+constexpr int DWS_ROUNDS = 2;    // (two memory round trips per wave; four rounds of 4 frames measured 23-48 us)
+constexpr int DWS_STRIP = DWS_FR * DWS_ROUNDS;
 
 __global__ __launch_bounds__(256) void dwconv4_bwd_kernel(const f2g_dwconv_bwd_desc P) {
   __shared__ float red[4][9][256];
@@ -606,25 +645,25 @@ __global__ __launch_bounds__(256) void dwconv4_bwd_kernel(const f2g_dwconv_bwd_d
   }
 
   for (int rd = 0; rd < DWS_ROUNDS; ++rd) {
-    const int fs = fs0 + 4 * rd;
+    const int fs = fs0 + DWS_FR * rd;
     if (fs >= F || !live) break;
-    float du[10][4], xr[10][4], gr[4][4];
+    float du[DWS_FR + 6][4], xr[DWS_FR + 6][4], gr[DWS_FR][4];
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < DWS_FR + 6; ++r) {
       int f = fs - 3 + r;
       f = f < 0 ? 0 : (f > F - 1 ? F - 1 : f);
       ld4(du[r], P.du + (rb + f) * P.lddu + c4);
       ld4(xr[r], P.x + (rb + f) * P.ldx + c4);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < DWS_FR; ++i) {
       int f = fs + i;
       f = f > F - 1 ? F - 1 : f;
       ld4(gr[i], (P.gres ? P.gres + (rb + f) * P.ldgres : P.x + (rb + f) * P.ldx) + c4);
     }
     // residual-scale gradient uses the UNMASKED input row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < DWS_FR; ++i) {
       const bool in = fs + i < F && P.gres;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -633,13 +672,13 @@ __global__ __launch_bounds__(256) void dwconv4_bwd_kernel(const f2g_dwconv_bwd_d
       }
     }
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < DWS_FR + 6; ++r) {
       const int f = fs - 3 + r;
       if (f < 0 || f >= F) { du[r][0] = du[r][1] = du[r][2] = du[r][3] = 0.f; }
       if (f < 0 || f >= lim) { xr[r][0] = xr[r][1] = xr[r][2] = xr[r][3] = 0.f; }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < DWS_FR; ++i) {
       const int f = fs + i;
       float dx[4];
 #pragma unroll
@@ -779,7 +818,7 @@ int check_dw(const f2g_dwnorm_fwd_desc& f) {
 bool vec4_ok(const f2g_dwnorm_bwd_desc& d, bool bwd) {
   const f2g_dwnorm_fwd_desc& f = d.f;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  bool ok = (f.C % 4) == 0 && (f.ldx % 4) == 0 && al(f.x);
+  bool ok = (f.C % 4) == 0 && (f.ldx % 4) == 0 && al(f.x) && (f.K != 7 || al(f.w_dw));
   if (f.cproj) ok = ok && (f.ldcp % 4) == 0 && al(f.cproj);
   if (f.te) ok = ok && (f.ldte % 4) == 0 && al(f.te);
   if (!bwd) return ok && (f.ldz % 4) == 0 && al(f.z);
@@ -795,6 +834,7 @@ int launch_dwnorm(const f2g_dwnorm_bwd_desc& d, hipStream_t st) {
   if (!BWD && f.z_format != 0) {   // operand-format outputs: vector kernel only
     const bool okf = (f.z_format == 1 || f.z_format == 2) && (f.C % 4) == 0 && (f.ldx % 4) == 0 &&
                      (((uintptr_t)f.x) & 15) == 0 && (((uintptr_t)f.z) & 15) == 0 &&
+                     (f.K != 7 || (((uintptr_t)f.w_dw) & 15) == 0) &&
                      (f.ldz % (f.z_format == 1 ? 4 : 8)) == 0 &&
                      (!f.cproj || ((f.ldcp % 4) == 0 && (((uintptr_t)f.cproj) & 15) == 0)) &&
                      (!f.te || ((f.ldte % 4) == 0 && (((uintptr_t)f.te) & 15) == 0));

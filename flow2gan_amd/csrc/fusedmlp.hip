@@ -55,9 +55,12 @@ __device__ __forceinline__ bf16x8 as_frag(const u32x4& v) {
 // consecutive frames, a lane 4 consecutive channels per 256-channel chunk, all 10 input rows of a
 // frame group requested before anything is consumed) -- z never exists in HBM, and the launch,
 // the z store and the z re-read of the separate kernel are gone.
+// (the body is a device function of (row tile bx, hidden part by of ny) so that one launch can serve
+// several problems: fused_block_multi_kernel below)
 template <int RT, int NT, bool DW>
-__global__ __launch_bounds__(256, 1)
-void fused_mlp_kernel(const f2g_fused_mlp_desc d, const f2g_dwnorm_fwd_desc P, int spb) {
+__device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, const f2g_dwnorm_fwd_desc& P,
+                                               const int spb, const int bx, const int by, const int ny,
+                                               unsigned char* const smem) {
   constexpr int BM = 32 * RT, C = 128 * NT;
   constexpr int ZP = C * 2 + 16;               // LDS pitch of a z row (bytes)
   constexpr int KA = C / 16;                   // k steps (= weight fragments) of phase A
@@ -65,18 +68,17 @@ void fused_mlp_kernel(const f2g_fused_mlp_desc d, const f2g_dwnorm_fwd_desc P, i
   constexpr int PER_SLAB = KA + KB * NT;       // fragments per slab and wave (a multiple of RING)
   constexpr int RING = PER_SLAB % RING_WANTED == 0 ? RING_WANTED : 16;
   static_assert(PER_SLAB % RING == 0, "ring indices must be static across slabs");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* zs = smem;
   unsigned char* ps = smem + BM * ZP;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
   // (wave-uniform by construction; said explicitly so that everything derived from it -- the scalar
   // offset of the weight stream above all -- lives in SGPRs instead of behind waterfall loops)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * BM;
+  const int m0 = bx * BM;
   const int S = d.H / HS;
-  const int s_beg = blockIdx.y * spb;
+  const int s_beg = by * spb;
   const int s_end = s_beg + spb < S ? s_beg + spb : S;
-  const bool lead = blockIdx.y == 0, split = gridDim.y > 1;
+  const bool lead = by == 0, split = ny > 1;
 
   // ---- weight stream of this wave: fragments [slab][KA of W1 | KB x NT of W2], 1 KiB each
   __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
@@ -279,20 +281,28 @@ void fused_mlp_kernel(const f2g_fused_mlp_desc d, const f2g_dwnorm_fwd_desc P, i
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) a[rt][e] = 0.f;
-    bf16x8 fz[2][RT];
+    // A fragments ZD - 1 k-steps ahead of their MFMAs: a k-step is only RT MFMAs = 64-128 cycles long,
+    // about one LDS round trip with four waves reading (one step ahead, the wait in front of every
+    // step's first MFMA stalled the pipe)
+    constexpr int ZD = 4;
+    bf16x8 fz[ZD][RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) fz[0][rt] = *reinterpret_cast<const bf16x8*>(za + rt * 32 * ZP);
+    for (int q = 0; q < ZD - 1; ++q)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        fz[q][rt] = *reinterpret_cast<const bf16x8*>(za + rt * 32 * ZP + q * 32);
 #pragma unroll
     for (int ks = 0; ks < KA; ++ks) {
-      if (ks + 1 < KA) {
+      if (ks + ZD - 1 < KA) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
-          fz[(ks + 1) & 1][rt] = *reinterpret_cast<const bf16x8*>(za + rt * 32 * ZP + (ks + 1) * 32);
+          fz[(ks + ZD - 1) % ZD][rt] =
+              *reinterpret_cast<const bf16x8*>(za + rt * 32 * ZP + (ks + ZD - 1) * 32);
       }
       const bf16x8 fb = as_frag(ring[ks % RING]);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        a[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz[ks & 1][rt], fb, a[rt], 0, 0, 0);
+        a[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz[ks % ZD][rt], fb, a[rt], 0, 0, 0);
       if (!(F2G_MLPVAR & 1)) ring[ks % RING] = __builtin_amdgcn_raw_buffer_load_b128(rw, wlane, wso, 0);
       wso += 1024;
       // keep the written order: left alone, the scheduler sinks the refills to just before their
@@ -432,6 +442,57 @@ void fused_mlp_kernel(const f2g_fused_mlp_desc d, const f2g_dwnorm_fwd_desc P, i
   }
 }
 
+template <int RT, int NT, bool DW>
+__global__ __launch_bounds__(256, 1)
+void fused_mlp_kernel(const f2g_fused_mlp_desc d, const f2g_dwnorm_fwd_desc P, int spb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  fused_mlp_body<RT, NT, DW>(d, P, spb, blockIdx.x, blockIdx.y, gridDim.y, smem);
+}
+
+// Several ConvNeXt blocks in ONE launch (f2g_fused_block_multi): the three Fourier branches of a
+// decoder run the same layer at the same time on tiles of very different cost (94 tiles of ~90 us at
+// 768 channels, 126 of ~63 us at 512, 188 of ~60 us at 384, one block per CU) -- as three launches
+// on three streams they need two rounds of the chip for 1.6 rounds of work, and the 768-channel
+// branch, the critical path of every Euler step, waits for CUs.  Here the tiles of all entries form
+// one grid in order of decreasing cost, so the hardware's in-order workgroup dispatch IS
+// longest-processing-time-first list scheduling: the long tiles start first and the short ones
+// fill the CUs as they free up.
+constexpr int MULTI_MAX = 4;
+struct fused_multi_args {
+  f2g_fused_mlp_desc d[MULTI_MAX];
+  f2g_dwnorm_fwd_desc P[MULTI_MAX];
+  int cum[MULTI_MAX + 1];    // first block of entry i (entries sorted by decreasing cost per tile)
+  int rt[MULTI_MAX];         // rows per tile / 32 of entry i
+  int n;
+};
+
+__global__ __launch_bounds__(256, 1)
+void fused_block_multi_kernel(const fused_multi_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int bid = blockIdx.x;
+  int i = 0, base = 0, rt = a.rt[0];
+#pragma unroll
+  for (int k = 1; k < MULTI_MAX; ++k)
+    if (k < a.n && bid >= a.cum[k]) { i = k; base = a.cum[k]; rt = a.rt[k]; }
+  // the entry's descriptors straight from the kernel-argument segment (a uniform index: scalar loads;
+  // indexing the by-value copy would put the whole struct into scratch memory)
+  const unsigned char* ka = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
+  f2g_fused_mlp_desc d;
+  f2g_dwnorm_fwd_desc P;
+  __builtin_memcpy(&d, ka + offsetof(fused_multi_args, d) + (size_t)i * sizeof(f2g_fused_mlp_desc), sizeof d);
+  __builtin_memcpy(&P, ka + offsetof(fused_multi_args, P) + (size_t)i * sizeof(f2g_dwnorm_fwd_desc), sizeof P);
+  const int bx = bid - base;
+  const int S = d.H / HS;
+  if (d.C == 768) fused_mlp_body<2, 6, true>(d, P, S, bx, 0, 1, smem);
+  else if (d.C == 512) {
+    if (rt == 3) fused_mlp_body<3, 4, true>(d, P, S, bx, 0, 1, smem);
+    else fused_mlp_body<2, 4, true>(d, P, S, bx, 0, 1, smem);
+  } else {
+    if (rt == 4) fused_mlp_body<4, 3, true>(d, P, S, bx, 0, 1, smem);
+    else fused_mlp_body<2, 3, true>(d, P, S, bx, 0, 1, smem);
+  }
+}
+
 // W1 (H, C) and W2 (C, H), fp32 row-major -> the per-wave bf16 fragment stream (see the kernel).
 __global__ __launch_bounds__(256)
 void mlp_pack_kernel(uint4* __restrict__ dst, const float* __restrict__ w1, long long ld1,
@@ -496,6 +557,37 @@ int launch_fused(const f2g_fused_mlp_desc& d, hipStream_t st, const f2g_dwnorm_f
   return f2g_check_launch();
 }
 
+// Rows per tile.  The default tiles (64 / 96 / 128 rows at 768 / 512 / 384 channels: what the 192
+// accumulator registers hold) amortise the weight stream best, but a launch with few rows then has
+// far fewer tiles than the chip has CUs (the condition encoder: 6016 rows x 512 channels = 63 tiles):
+// smaller tiles trade weight traffic for parallelism.  F2G_MLP_RT forces rows / 32.
+int pick_rt(int C, int rows) {
+  static const int env_rt = getenv("F2G_MLP_RT") ? atoi(getenv("F2G_MLP_RT")) : 0;
+  const int rt_max = C == 768 ? 2 : (C == 512 ? 3 : 4);
+  if (env_rt > 0) {
+    int r = env_rt > rt_max ? rt_max : env_rt;
+    if (C == 384 && r == 3) r = 2;
+    return r;
+  }
+  // the largest tile that still gives every CU of HALF the chip a tile
+  for (int r = rt_max; r > 1; --r) {
+    if (C == 384 && r == 3) continue;
+    if ((rows + 32 * r - 1) / (32 * r) >= 128) return r;
+  }
+  return 1;
+}
+
+template <bool DW>
+int dispatch_fused(const f2g_fused_mlp_desc& d, hipStream_t st, const f2g_dwnorm_fwd_desc* dw) {
+  const int rt = pick_rt(d.C, d.rows);
+  if (d.C == 768) return rt == 2 ? launch_fused<2, 6, DW>(d, st, dw) : launch_fused<1, 6, DW>(d, st, dw);
+  if (d.C == 512)
+    return rt == 3 ? launch_fused<3, 4, DW>(d, st, dw)
+                   : (rt == 2 ? launch_fused<2, 4, DW>(d, st, dw) : launch_fused<1, 4, DW>(d, st, dw));
+  return rt == 4 ? launch_fused<4, 3, DW>(d, st, dw)
+                 : (rt == 2 ? launch_fused<2, 3, DW>(d, st, dw) : launch_fused<1, 3, DW>(d, st, dw));
+}
+
 }  // namespace
 
 extern "C" int f2g_fused_mlp_ok(int32_t C, int32_t H) {
@@ -531,17 +623,10 @@ extern "C" int f2g_fused_mlp(const f2g_fused_mlp_desc* dp, f2g_stream_t stream) 
     return F2G_EINVAL;
   }
   if (d.rows == 0) return F2G_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (d.C == 768) return launch_fused<2, 6>(d, st);
-  if (d.C == 512) return launch_fused<3, 4>(d, st);
-  return launch_fused<4, 3>(d, st);
+  return dispatch_fused<false>(d, (hipStream_t)stream, nullptr);
 }
 
-extern "C" int f2g_fused_block(const f2g_dwnorm_fwd_desc* wp, const f2g_fused_mlp_desc* mp,
-                               f2g_stream_t stream) {
-  if (!wp || !mp) return F2G_EINVAL;
-  const f2g_dwnorm_fwd_desc& w = *wp;
-  f2g_fused_mlp_desc d = *mp;
+static int check_block(const f2g_dwnorm_fwd_desc& w, const f2g_fused_mlp_desc& d) {
   auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!w.x || !w.w_dw || !w.beta || !w.log_scale || !d.wp || !d.alpha || !d.out) return F2G_EINVAL;
   if (!f2g_fused_mlp_ok(d.C, d.H) || w.C != d.C || w.K != 7 || w.B <= 0 || w.F <= 0 ||
@@ -554,10 +639,66 @@ extern "C" int f2g_fused_block(const f2g_dwnorm_fwd_desc* wp, const f2g_fused_ml
                   "16-byte aligned tensors with row strides in whole float4s)");
     return F2G_EINVAL;
   }
-  d.z = w.x;       // (unused by the DW instances; keeps the descriptor valid)
+  return F2G_OK;
+}
+
+extern "C" int f2g_fused_block(const f2g_dwnorm_fwd_desc* wp, const f2g_fused_mlp_desc* mp,
+                               f2g_stream_t stream) {
+  if (!wp || !mp) return F2G_EINVAL;
+  f2g_fused_mlp_desc d = *mp;
+  const int rc = check_block(*wp, d);
+  if (rc) return rc;
+  d.z = wp->x;       // (unused by the DW instances; keeps the descriptor valid)
   d.ldz = 8;
-  hipStream_t st = (hipStream_t)stream;
-  if (d.C == 768) return launch_fused<2, 6, true>(d, st, wp);
-  if (d.C == 512) return launch_fused<3, 4, true>(d, st, wp);
-  return launch_fused<4, 3, true>(d, st, wp);
+  return dispatch_fused<true>(d, (hipStream_t)stream, wp);
+}
+
+extern "C" int f2g_fused_block_multi(const f2g_dwnorm_fwd_desc* wp, const f2g_fused_mlp_desc* mp,
+                                     int32_t n, f2g_stream_t stream) {
+  if (!wp || !mp || n < 1 || n > MULTI_MAX) return F2G_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    const int rc = check_block(wp[i], mp[i]);
+    if (rc) return rc;
+  }
+  // entries in order of decreasing cost per tile (12 C^2 FLOPs per row x 32 RT rows)
+  // rows per tile of an entry: the default tiles, or (F2G_MULTI_RT512 / F2G_MULTI_RT384 = 2) 64-row
+  // tiles for the cheaper branches -- finer granularity at the tail of the list schedule
+  static const int rt512 = getenv("F2G_MULTI_RT512") ? atoi(getenv("F2G_MULTI_RT512")) : 3;
+  static const int rt384 = getenv("F2G_MULTI_RT384") ? atoi(getenv("F2G_MULTI_RT384")) : 4;
+  auto bm_of = [&](int C) { return C == 768 ? 64 : (C == 512 ? (rt512 == 2 ? 64 : 96) : (rt384 == 2 ? 64 : 128)); };
+  int order[MULTI_MAX];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0; --j) {
+      const long long cj = (long long)mp[order[j]].C * mp[order[j]].C * bm_of(mp[order[j]].C);
+      const long long cp = (long long)mp[order[j - 1]].C * mp[order[j - 1]].C * bm_of(mp[order[j - 1]].C);
+      if (cj > cp) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    }
+  fused_multi_args a{};
+  int total = 0;
+  size_t smem = 0;
+  for (int k = 0; k < n; ++k) {
+    const int i = order[k];
+    a.d[k] = mp[i];
+    a.d[k].z = wp[i].x;
+    a.d[k].ldz = 8;
+    a.P[k] = wp[i];
+    a.cum[k] = total;
+    const int BM = bm_of(mp[i].C);
+    a.rt[k] = BM / 32;
+    total += (mp[i].rows + BM - 1) / BM;
+    const size_t sm = (size_t)BM * (mp[i].C * 2 + 16) + (size_t)BM * PP;
+    smem = sm > smem ? sm : smem;
+  }
+  for (int k = n; k <= MULTI_MAX; ++k) a.cum[k] = total;
+  a.n = n;
+  if (total == 0) return F2G_OK;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_block_multi_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (384 * 2 + 16) + 128 * PP);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fused_block_multi_kernel, dim3(total), dim3(256), smem, (hipStream_t)stream, a);
+  return f2g_check_launch();
 }

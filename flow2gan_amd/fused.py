@@ -174,9 +174,10 @@ def block_fwd(bp: _Blk, x, B, F, lens, cproj=None, ldcp=0, Fc=0, up=1, cp_off=0,
 
 def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale: bool,
               cproj=None, ldcp=0, Fc=0, up=1, cp_off=0, te=None, ldte=0, te_off=0, g_cproj=None,
-              g_te=None):
+              g_te=None, g_cproj_store=False):
     """Backward of block_fwd.  Destroys z and a (reused as gradient buffers).
-    Returns (gx, grads) with grads ordered like BLOCK_KEYS."""
+    Returns (gx, grads) with grads ordered like BLOCK_KEYS.  g_cproj_store: this block owns the
+    zero-filled columns [cp_off, cp_off + C) of g_cproj (ops.dwnorm_bwd)."""
     a, p_act, share, zsplit = a
     if share is None:
         share = ops.split_sharing()
@@ -199,7 +200,8 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
     du = ops.empty(rows, Cc, device=dev)
     ops.dwnorm_bwd(x, z, du, B, F, Cc, bp.K, lens, bp.w_dw, bp.b_dw, bp.beta,
                    bp.log_scale.reshape(1), cproj, ldcp, Fc, up, cp_off, te, ldte, te_off,
-                   g_cproj=g_cproj, g_te=g_te, g_beta=g_beta, g_log_scale=g_ls)
+                   g_cproj=g_cproj, g_te=g_te, g_beta=g_beta, g_log_scale=g_ls,
+                   g_cproj_store=g_cproj_store)
     gx = ops.empty(rows, Cc, device=dev)
     ops.dwconv_bwd(du, x, gx, B, F, Cc, bp.K, lens, bp.w_dw, gres=gout, gamma=bp.gamma.reshape(Cc),
                    g_w=g_wdw, g_b=g_bdw, g_gamma=g_gamma)
@@ -345,16 +347,26 @@ class CondPathFn(GradAwareFunction):
             n = min(Fc, Fce)
             ops.copy3(cext, Fce * Dc, Dc, cond, Fc * Dc, Dc, B, n, Dc)
         rows = B * Fce
-        a = ops.empty(rows, Hc, device=dev)
         keep = _keep(ctx)
+        wstack = _stack_rows(wcs, Dc, dev)
+        bstack = _stack_vecs(bcs, dev)
+        cproj = ops.empty(rows, nblk * Cc, device=dev)
+        if (not keep) and ops.GEMM_PRECISION == 2 and ops.BF16_IMAGES and ops.LEAN_SPLIT \
+                and Dc % 64 == 0 and Hc % 64 == 0:
+            # plain-bf16 inference: the two intermediate results leave their GEMMs as the bf16
+            # tensors the next GEMM reads (no conversion launches in between)
+            a = torch.empty(rows, Hc, device=dev, dtype=torch.bfloat16)
+            gemm(mat(cext, rows, Dc), mat(w0.reshape(Hc, Dc)), a, bias=b0, prelu=alpha, split_k=1)
+            cm = torch.empty(rows, Dc, device=dev, dtype=torch.bfloat16)
+            gemm(mat(a, rows, Hc, split=2), mat(w2.reshape(Dc, Hc)), cm, bias=b2, split_k=1)
+            gemm(mat(cm, rows, Dc, split=2), mat(wstack), cproj, bias=bstack)
+            return cproj
+        a = ops.empty(rows, Hc, device=dev)
         pact = ops.empty(rows, Hc, device=dev) if keep else a
         gemm(mat(cext, rows, Dc), mat(w0.reshape(Hc, Dc)), a, bias=b0, prelu=alpha,
              prelu_out=pact if keep else None)
         cm = ops.empty(rows, Dc, device=dev)
         gemm(mat(pact, rows, Hc), mat(w2.reshape(Dc, Hc)), cm, bias=b2)
-        wstack = _stack_rows(wcs, Dc, dev)
-        bstack = _stack_vecs(bcs, dev)
-        cproj = ops.empty(rows, nblk * Cc, device=dev)
         gemm(mat(cm, rows, Dc), mat(wstack), cproj, bias=bstack)
         if keep:
             ctx.saved = (cext, (a, pact), cm, wstack)
@@ -483,8 +495,52 @@ def _pad_vec(b, Np: int):
     return b if b.shape[0] == Np else ops.derived(b, ("padv", Np), build)
 
 
-def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pred, accumulate,
-                    lens_f, training, keep, lanes=None):
+def _time_path(bv: _BranchView, t):
+    """t (n,) -> the time scale rows of all blocks of a decoder, (n, nblk * C) (modules.py:569-573,
+    451, 485): sinusoidal embedding -> Linear -> SiLU -> Linear, then every block's time_emb
+    Linear as one stacked GEMM."""
+    dev = t.device
+    n = t.shape[0]
+    Dt, Ht = bv.Dt, bv.Ht
+    emb = ops.empty(n, Dt, device=dev)
+    ops.time_embedding(emb, t, Dt)
+    th = ops.empty(n, Ht, device=dev)
+    gemm(mat(emb), mat(bv.tw0), th, bias=bv.tb0)
+    ts = ops.empty(n, Ht, device=dev)
+    ops.silu(ts, th)
+    te = ops.empty(n, Dt, device=dev)
+    gemm(mat(ts), mat(bv.tw2), te, bias=bv.tb2)
+    tew = _stack_rows(bv.tew, Dt, dev)
+    teb = _stack_vecs(bv.teb, dev)
+    te_all = ops.empty(n, bv.nblk * bv.C, device=dev)
+    gemm(mat(te), mat(tew), te_all, bias=teb)
+    return emb, th, ts, te, tew, te_all
+
+
+def time_paths_ahead(flat, nparams, t_all, n_steps: int):
+    """Inference: the time path depends on t only, and the Euler solver knows every t in advance --
+    so it is computed ONCE for all steps (t_all = the steps' t vectors stacked, (n_steps * B,)), one
+    launch lane per branch, instead of 9 small launches per branch and step in front of the blocks.
+    Returns [step][branch] -> (B, nblk * C) row blocks of the stacked results (same arithmetic row by
+    row as the per-step path)."""
+    dev = t_all.device
+    nb = len(nparams)
+    B = t_all.shape[0] // n_steps
+    views, off = [], 0
+    for i in range(nb):
+        views.append(_BranchView(list(flat[off: off + nparams[i]])))
+        off += nparams[i]
+    lanes = ops.Lanes(dev, nb, "timepath")
+    full = []
+    for i in range(nb):
+        with lanes.lane(i):
+            full.append(_time_path(views[i], t_all)[-1])
+    return lanes, [[full[i][k * B: (k + 1) * B] for i in range(nb)] for k in range(n_steps)]
+
+
+def _branch_pre(bv: _BranchView, meta, x, t, cproj, training, keep, te_pre=None):
+    """STFT -> in_proj -> in_norm and the time path of one Fourier branch (modules.py:590-599,
+    569-573): everything in front of the ConvNeXt blocks.  Returns the branch's state."""
     n_fft, hop, up, window = meta
     dev = x.device
     B, T = x.shape
@@ -520,33 +576,29 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     flags = [_limit_draw(training)]
     xcur = ops.empty(rows, Cc, device=dev)
     ops.biasnorm_fwd(h0, xcur, rows, Cc, bv.beta_in, bv.ls_in.reshape(1))
-    # time path (modules.py:569-573,451,485)
-    Dt, Ht = bv.Dt, bv.Ht
-    emb = ops.empty(B, Dt, device=dev)
-    ops.time_embedding(emb, t, Dt)
-    th = ops.empty(B, Ht, device=dev)
-    gemm(mat(emb), mat(bv.tw0), th, bias=bv.tb0)
-    ts = ops.empty(B, Ht, device=dev)
-    ops.silu(ts, th)
-    te = ops.empty(B, Dt, device=dev)
-    gemm(mat(ts), mat(bv.tw2), te, bias=bv.tb2)
-    tew = _stack_rows(bv.tew, Dt, dev)
-    teb = _stack_vecs(bv.teb, dev)
     NC = bv.nblk * Cc
-    te_all = ops.empty(B, NC, device=dev)
-    gemm(mat(te), mat(tew), te_all, bias=teb)
-    Fce = cproj.shape[0] // B
-    saved_blocks = []
-    for j, bp in enumerate(bv.blks):
-        fn = _limit_draw(training)
-        y, z, a = block_fwd(bp, xcur, B, F, lens_f, cproj, NC, Fce, up, j * Cc, te_all, NC,
-                            j * Cc, keep=keep)
-        flags.append((fn, _limit_draw(training)))
-        if keep:
-            saved_blocks.append((xcur, z, a))
-        xcur = y
+    if te_pre is not None:      # computed ahead for all Euler steps (time_paths_ahead)
+        emb = th = ts = te = tew = None
+        te_all = te_pre
+    else:
+        emb, th, ts, te, tew, te_all = _time_path(bv, t)
+    return dict(packed=packed, h0=h0, xcur=xcur, emb=emb, th=th, ts=ts, te=te, tew=tew, te_all=te_all,
+                flags=flags, F=F, rows=rows, NC=NC, Fce=cproj.shape[0] // B, ldp=ldp, Kc=Kc,
+                bf16_chain=bf16_chain, blocks=[])
+
+
+def _branch_post(st, bv: _BranchView, meta, x_shape, wbranch_row, wscale, pred, accumulate, lens_f,
+                 lanes=None):
+    """out_proj -> iSTFT -> overlap-add into the shared prediction (modules.py:613-621,719)."""
+    n_fft, hop, up, window = meta
+    B, T = x_shape
+    N, F, rows, ldp, Kc = n_fft, st["F"], st["rows"], st["ldp"], st["Kc"]
+    Cc, Cin = bv.C, bv.Cin
+    xcur = st["xcur"]
+    dev = xcur.device
+    Wd, Wi = dft_matrices(N, dev)
     ifft = ops.fft_applies(N)       # inverse transform through the LDS FFT instead of the DFT GEMM
-    ybf = bf16_chain and lens_f is None       # (the inverse FFT reads bf16 spectra as well)
+    ybf = st["bf16_chain"] and lens_f is None       # (the inverse FFT reads bf16 spectra as well)
     yspec = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16) if ybf else ops.empty(rows, ldp, device=dev)
     gemm(mat(xcur, rows, Cc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), yspec,
          bias=_pad_vec(bv.b_out, Kc), split_k=1)
@@ -562,10 +614,84 @@ def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pre
     ops.istft_ola(frames, pred, B, F, N, hop, T, window, wbranch_row, wscale, accumulate)
     if lanes is not None:
         lanes.chain_leave()
+
+
+def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pred, accumulate,
+                    lens_f, training, keep, lanes=None, te_pre=None):
+    up = meta[2]
+    B = x.shape[0]
+    st = _branch_pre(bv, meta, x, t, cproj, training, keep, te_pre)
+    Cc, F, NC = bv.C, st["F"], st["NC"]
+    xcur = st["xcur"]
+    for j, bp in enumerate(bv.blks):
+        fn = _limit_draw(training)
+        y, z, a = block_fwd(bp, xcur, B, F, lens_f, cproj, NC, st["Fce"], up, j * Cc, st["te_all"], NC,
+                            j * Cc, keep=keep)
+        st["flags"].append((fn, _limit_draw(training)))
+        if keep:
+            st["blocks"].append((xcur, z, a))
+        xcur = y
+    st["xcur"] = xcur
+    _branch_post(st, bv, meta, x.shape, wbranch_row, wscale, pred, accumulate, lens_f, lanes)
     if keep:
-        return dict(packed=packed, h0=h0, blocks=saved_blocks, x_last=xcur, emb=emb, th=th, ts=ts,
-                    te=te, tew=tew, te_all=te_all, flags=flags, F=F)
+        return dict(packed=st["packed"], h0=st["h0"], blocks=st["blocks"], x_last=xcur, emb=st["emb"],
+                    th=st["th"], ts=st["ts"], te=st["te"], tew=st["tew"], te_all=st["te_all"],
+                    flags=st["flags"], F=F)
     return None
+
+
+def _multi_applies(views, x, keep) -> bool:
+    """All branches' ConvNeXt blocks of a layer as ONE launch (ops.fused_block_multi): plain-bf16
+    inference, 2-4 branches of equal depth whose shapes the fused block kernel has instances for."""
+    if keep or not (ops.FUSED_MULTI and ops.FUSED_BLOCK):
+        return False
+    if not (2 <= len(views) <= 4) or len({bv.nblk for bv in views}) != 1:
+        return False
+    for bv in views:
+        for bp in bv.blks:
+            if ops.operand_formats_ok(bp.C, bp.H) != 2 or bp.K != 7 or not ops.fused_mlp_applies(bp.C, bp.H):
+                return False
+    return True
+
+
+def _branches_forward_multi(views, metas, x, t, cprojs, wbranch, wscale, pred, lens_list, training,
+                            te_pre=None):
+    """The forward of all Fourier branches with layer-synchronous blocks: the parts in front of and
+    behind the blocks run on one launch lane per branch as before, layer j of all branches is one
+    launch on the caller's stream (tiles in order of decreasing cost: see fusedmlp.hip)."""
+    nb = len(views)
+    dev = x.device
+    B = x.shape[0]
+    sts = [None] * nb
+    lanes = ops.Lanes(dev, nb, "branch")
+    for i in range(nb):
+        with lanes.lane(i):
+            sts[i] = _branch_pre(views[i], metas[i], x, t, cprojs[i], training, False,
+                                 None if te_pre is None else te_pre[i])
+            for _ in range(2 * views[i].nblk):     # (the draws of the per-branch path, in its order)
+                _limit_draw(training)
+    lanes.join()
+    for j in range(views[0].nblk):
+        entries = []
+        for i in range(nb):
+            bv, st = views[i], sts[i]
+            bp = bv.blks[j]
+            Cc = bv.C
+            entries.append(dict(
+                x=st["xcur"], B=B, F=st["F"], Cc=Cc, K=bp.K, lens=lens_list[i], w_dw=bp.w_dw, b_dw=bp.b_dw,
+                beta=bp.beta, log_scale=bp.log_scale.reshape(1), wp=ops.mlp_pack(bp.w1, bp.w2), b1=bp.b1,
+                alpha=bp.alpha, b2=bp.b2, gamma=bp.gamma.reshape(Cc), out=ops.empty(st["rows"], Cc, device=dev),
+                Hh=bp.H, cproj=cprojs[i], ldcp=st["NC"], Fc=st["Fce"], up=metas[i][2], cp_off=j * Cc,
+                te=st["te_all"], ldte=st["NC"], te_off=j * Cc))
+        outs = ops.fused_block_multi(entries)
+        for i in range(nb):
+            sts[i]["xcur"] = outs[i]
+    lanes = ops.Lanes(dev, nb, "branch")
+    for i in range(nb):
+        wrow = None if wbranch is None else wbranch[i]
+        with lanes.lane(i):
+            _branch_post(sts[i], views[i], metas[i], x.shape, wrow, wscale, pred, i > 0, lens_list[i], lanes)
+    lanes.join()
 
 
 def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_row, wscale,
@@ -606,7 +732,8 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
         xj, z, a = sv["blocks"][j]
         fn, fs = flags[1 + j]
         g, gb = block_bwd(bv.blks[j], xj, z, a, g, B, F, lens_f, fn, fs, cproj, NC, Fce, up,
-                          j * Cc, sv["te_all"], NC, j * Cc, g_cproj=g_cproj, g_te=g_te_all)
+                          j * Cc, sv["te_all"], NC, j * Cc, g_cproj=g_cproj, g_te=g_te_all,
+                          g_cproj_store=True)   # g_cp is zero-filled, block j owns columns j*C..
         block_grads[j] = gb
     # in_norm / in_proj / STFT
     g_beta = ops.zeros(Cc, device=dev)
@@ -669,6 +796,10 @@ class ModelEvalFn(GradAwareFunction):
         # metas: one (n_fft, hop, up, window) per branch, optionally followed by ("scale", s): the
         # weight of every branch in the reduction (1/nb = mean, generator.py:165-168; 1 = sum)
         bscale = None
+        te_pre = None
+        if metas and metas[-1][0] == "te":      # inference: the time path computed ahead (per branch)
+            te_pre = metas[-1][1]
+            metas = metas[:-1]
         if metas and metas[-1][0] == "scale":
             bscale = float(metas[-1][1])
             metas = metas[:-1]
@@ -689,14 +820,22 @@ class ModelEvalFn(GradAwareFunction):
             off += nparams[i]
             lens_list.append(frames_lens(lens_cpu, metas[i][1], dev))
             dft_matrices(metas[i][0], dev)
-        lanes = ops.Lanes(dev, nb, "branch")  # one launch lane (HIP stream) per Fourier branch
-        for i in range(nb):
-            wrow = None if wbranch is None else wbranch[i]
-            with lanes.lane(i):
-                sv = _branch_forward(views[i], metas[i], x, t, cprojs[i], wrow, bscale, pred,
-                                     i > 0, lens_list[i], training, keep, lanes)
-            saved.append(sv)
-        lanes.join()
+        if keep:
+            te_pre = None
+        if _multi_applies(views, x, keep):
+            _branches_forward_multi(views, metas, x, t, cprojs, wbranch, bscale, pred, lens_list, training,
+                                    te_pre)
+            saved = [None] * nb
+        else:
+            lanes = ops.Lanes(dev, nb, "branch")  # one launch lane (HIP stream) per Fourier branch
+            for i in range(nb):
+                wrow = None if wbranch is None else wbranch[i]
+                with lanes.lane(i):
+                    sv = _branch_forward(views[i], metas[i], x, t, cprojs[i], wrow, bscale, pred,
+                                         i > 0, lens_list[i], training, keep, lanes,
+                                         None if te_pre is None else te_pre[i])
+                saved.append(sv)
+            lanes.join()
         if keep:
             # per-branch gradient hand-over to an armed exchange (dist._Sink)
             ctx.tickets = [sink_register(list(flat[sum(nparams[:i]): sum(nparams[:i + 1])]))

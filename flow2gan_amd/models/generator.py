@@ -9,11 +9,16 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor, nn
 
 from .. import fused, ops
 from .modules import AudioConvNeXt, CondEncoder, LinearFilterSpectrogram
+
+# inference: the time paths of all Euler steps are computed once, ahead of the loop (0: per step)
+TIME_AHEAD = os.environ.get("F2G_TIME_AHEAD", "1") != "0"
 
 
 class CondRows:
@@ -175,14 +180,23 @@ class BaseAudioGenerator(nn.Module):
                         torch.ones_like(mask))
         return w.t().contiguous()
 
-    def model_eval(self, x: Tensor, t: Tensor, cprojs: List[Tensor], lens_cpu,
-                   branch_weights: Optional[Tensor] = None) -> Tensor:
+    def _branch_flat(self):
         flat, nparams = [], []
         for est in self.estimators:
             p = fused.branch_params(est)
             nparams.append(len(p))
             flat += p
-        return fused.ModelEvalFn.apply(x, t, branch_weights, self._metas(), lens_cpu,
+        return flat, nparams
+
+    def model_eval(self, x: Tensor, t: Tensor, cprojs: List[Tensor], lens_cpu,
+                   branch_weights: Optional[Tensor] = None, te_pre=None) -> Tensor:
+        """te_pre (inference only): this evaluation's time-scale rows per branch, computed ahead by
+        fused.time_paths_ahead."""
+        flat, nparams = self._branch_flat()
+        metas = self._metas()
+        if te_pre is not None:
+            metas = metas + (("te", te_pre),)
+        return fused.ModelEvalFn.apply(x, t, branch_weights, metas, lens_cpu,
                                        self.training, tuple(nparams), *cprojs, *flat)
 
     def process_model(self, x: Tensor, cond, t: Optional[Tensor] = None,
@@ -227,22 +241,49 @@ class BaseAudioGenerator(nn.Module):
             ops.axpby_rows(ref, x1.contiguous(), x0.contiguous(), sa=1.0, sb=-1.0)
         return self.compute_loss(pred=pred, ref=ref, audio_lens=audio_lens, gt_audio=x1)
 
+    def _time_ahead(self, B: int, n_timesteps: int, device):
+        """Inference: every step's t is known before the solver starts, so the time paths of all
+        steps run as one batch on their own launch lanes, next to the condition encoder / condition
+        paths (fused.time_paths_ahead).  Returns None when gradients are wanted or F2G_TIME_AHEAD=0;
+        the caller joins the lanes (`[0].join()`) before the first model evaluation."""
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if grad or not TIME_AHEAD:
+            return None
+        t_span = torch.linspace(0, 1, n_timesteps + 1)
+        t_all = ops.empty(n_timesteps * B, device=device)
+        for k in range(n_timesteps):
+            ops.fill_(t_all[k * B: (k + 1) * B], float(t_span[k]))
+        flat, nparams = self._branch_flat()
+        tlanes, te_ahead = fused.time_paths_ahead(flat, nparams, t_all, n_timesteps)
+        return tlanes, te_ahead, t_all
+
     def infer(self, noise: Tensor, cond, audio_lens: Optional[Tensor] = None,
-              n_timesteps: int = 1, clamp_pred: bool = False) -> Tensor:
+              n_timesteps: int = 1, clamp_pred: bool = False, *, _time_ahead=None) -> Tensor:
         """Euler solver (generator.py:236-271)."""
         cond = self._as_cond_rows(cond)
         B, T = noise.shape
-        cprojs = self.cond_paths(cond, T)
-        lens_cpu = _lens_list(audio_lens)
         t_span = torch.linspace(0, 1, n_timesteps + 1)
         t, dt = float(t_span[0]), float(t_span[1] - t_span[0])
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        te_ahead = tlanes = t_all = None
+        if _time_ahead is None:
+            _time_ahead = self._time_ahead(B, n_timesteps, noise.device)
+        if _time_ahead is not None:
+            tlanes, te_ahead, t_all = _time_ahead
+        cprojs = self.cond_paths(cond, T)
+        if tlanes is not None:
+            tlanes.join()
+        lens_cpu = _lens_list(audio_lens)
         x = noise.contiguous()
         tdev = ops.empty(B, device=noise.device)
-        grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         for step in range(1, n_timesteps + 1):
-            tk = ops.fill_(ops.empty(B, device=noise.device), t) if grad else ops.fill_(tdev, t)
+            if te_ahead is not None:
+                tk = t_all[(step - 1) * B: step * B]
+            else:
+                tk = ops.fill_(ops.empty(B, device=noise.device), t) if grad else ops.fill_(tdev, t)
             bw = self._draw_branch_weights(B, noise.device)
-            pred = self.model_eval(x, tk, cprojs, lens_cpu, bw)
+            pred = self.model_eval(x, tk, cprojs, lens_cpu, bw,
+                                   None if te_ahead is None else te_ahead[step - 1])
             # generator.py:263-264: x += vt*dt with vt = (pred - x)/(1 - t) (x1 prediction) or pred
             a, b = (1.0 - dt / (1.0 - t), dt / (1.0 - t)) if self.pred_x1 else (1.0, dt)
             if grad:
@@ -289,6 +330,9 @@ class MelAudioGenerator(BaseAudioGenerator):
     def infer(self, cond: Tensor, audio_lens: Optional[Tensor] = None, n_timesteps: int = 1,
               clamp_pred: bool = False, *, noise: Optional[Tensor] = None) -> Tensor:
         """Euler inference from a mel (generator.py:327-366)."""
+        # (the time paths of all steps start first: they overlap the condition encoder, whose
+        # 6016-row launches leave most of the chip idle)
+        ahead = self._time_ahead(cond.shape[0], n_timesteps, cond.device)
         cond_rows = self.encode_cond(self._augment(cond))
         if noise is None:
             if audio_lens is None:
@@ -298,4 +342,4 @@ class MelAudioGenerator(BaseAudioGenerator):
             noise = torch.randn((cond.shape[0], length), device=cond.device,
                                 dtype=cond.dtype) * self.init_noise_scale
         return super().infer(noise=noise, cond=cond_rows, audio_lens=audio_lens,
-                             n_timesteps=n_timesteps, clamp_pred=clamp_pred)
+                             n_timesteps=n_timesteps, clamp_pred=clamp_pred, _time_ahead=ahead)

@@ -712,6 +712,8 @@ _SIDE_STREAMS: dict = {}
 
 
 def _side_streams(device, n: int, pool_name: str):
+    # (a HIGH-priority stream for the critical 768-channel branch was measured: no effect under graph
+    # replay, eager bf16 inference 8.6 -> 13.0 ms, stage-2 step 236.5 -> 242 ms -- not used)
     idx = torch.device(device).index
     key = (idx if idx is not None else torch.cuda.current_device(), pool_name)
     pool = _SIDE_STREAMS.setdefault(key, [])
@@ -868,7 +870,39 @@ def fused_block(x, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, wp, b1, alpha
     return out
 
 
+def fused_block_multi(entries):
+    """One launch for several independent blocks (the same layer of a decoder's Fourier branches).
+    entries: a list of dicts with the keyword arguments of fused_block (x, B, F, Cc, K, lens, w_dw,
+    b_dw, beta, log_scale, wp, b1, alpha, b2, gamma, out, Hh, cproj, ldcp, Fc, up, cp_off, te, ldte,
+    te_off).  Same results as len(entries) fused_block calls."""
+    n = len(entries)
+    fs = (DwnormFwd * n)()
+    ds = (L.FusedMlpDesc * n)()
+    flops = 0.0
+    for i, e in enumerate(entries):
+        x, out = e["x"], e["out"]
+        fs[i] = _dw_desc(x, x.stride(0), None, 0, e["B"], e["F"], e["Cc"], e["K"], e.get("lens"), e["w_dw"],
+                         e.get("b_dw"), e["beta"], e["log_scale"], e.get("cproj"), e.get("ldcp", 0),
+                         e.get("Fc", 0), e.get("up", 1), e.get("cp_off", 0), e.get("te"), e.get("ldte", 0),
+                         e.get("te_off", 0), None)
+        d = ds[i]
+        d.parts = 0
+        d.wp, d.b1, d.alpha, d.b2 = ptr(e["wp"]), ptr(e.get("b1")), ptr(e["alpha"]), ptr(e.get("b2"))
+        d.res, d.ldres, d.gamma = ptr(x), x.stride(0), ptr(e.get("gamma"))
+        d.out, d.ldo = ptr(out), out.stride(0)
+        d.rows, d.C, d.H = e["B"] * e["F"], e["Cc"], e["Hh"]
+        flops += 4.0 * d.rows * d.C * d.H
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_fused_block_multi", fs, ds, n), flops,
+                        (0, sum(e["B"] * e["F"] for e in entries), 0, 0), path="fused-mlp")
+    else:
+        call("f2g_fused_block_multi", fs, ds, n)
+    return [e["out"] for e in entries]
+
+
 FUSED_BLOCK = _os.environ.get("F2G_FUSED_BLOCK", "1") != "0"
+# all Fourier branches' blocks of a layer in one launch (bf16 inference; 0: one launch per branch and lane)
+FUSED_MULTI = _os.environ.get("F2G_FUSED_MULTI", "1") != "0"
 
 
 # ------------------------------------------------------------------ fused block kernels
@@ -905,13 +939,16 @@ def dwnorm_fwd(x, z, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=None,
 
 def dwnorm_bwd(x, gz, du, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=None, ldcp=0,
                Fc=0, up=1, cp_off=0, te=None, ldte=0, te_off=0, g_cproj=None, g_te=None,
-               g_beta=None, g_log_scale=None):
+               g_beta=None, g_log_scale=None, g_cproj_store=False):
+    """g_cproj_store: the caller zero-filled g_cproj's columns [cp_off, cp_off + Cc) and nothing else
+    adds to them -- the kernel then stores the condition gradient instead of read-modify-writing it."""
     d = DwnormBwd()
     d.f = _dw_desc(x, x.stride(0), None, 0, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj,
                    ldcp, Fc, up, cp_off, te, ldte, te_off, None)
     d.gz, d.ldgz = ptr(gz), gz.stride(0)
     d.du, d.lddu = ptr(du), du.stride(0)
     d.g_cproj = None if g_cproj is None else ptr(g_cproj) + 4 * cp_off
+    d.g_cproj_store = 1 if (g_cproj_store and g_cproj is not None) else 0
     d.g_te = None if g_te is None else ptr(g_te) + 4 * te_off
     d.g_beta, d.g_log_scale = ptr(g_beta), ptr(g_log_scale)
     ws = torch.empty(L.lib.f2g_dwnorm_bwd_workspace(B, F, Cc, up if cproj is not None else 1),

@@ -215,6 +215,11 @@ typedef struct {
    * g_te / g_log_scale are written there without atomics and summed by a second launch (the
    * sums are ADDED to g_beta/g_te/g_log_scale).  NULL: contended atomics. */
   float* partials;
+  /* 1: g_cproj is STORED instead of accumulated (the caller owns these columns exclusively and
+   * zero-filled them: every condition row receives its one sum from one wave, so the read of the
+   * read-modify-write -- a dependent memory round trip per condition row -- can go). */
+  int32_t g_cproj_store;
+  int32_t _pad2;
 } f2g_dwnorm_bwd_desc;
 int f2g_dwnorm_bwd(const f2g_dwnorm_bwd_desc* d, f2g_stream_t stream);
 int64_t f2g_dwnorm_bwd_workspace(int32_t B, int32_t F, int32_t C, int32_t up);
@@ -624,6 +629,13 @@ int f2g_fused_mlp(const f2g_fused_mlp_desc* d, f2g_stream_t stream);
  * the masks and the dwnorm parameters (its z / rstd / z_format fields are ignored), `mlp` the rest
  * (its z / ldz are ignored; mlp->rows must equal dw->B * dw->F, mlp->res is normally dw->x). */
 int f2g_fused_block(const f2g_dwnorm_fwd_desc* dw, const f2g_fused_mlp_desc* mlp, f2g_stream_t stream);
+/* n <= 4 independent blocks (dw[i], mlp[i]) in ONE launch: the same layer of a decoder's Fourier branches
+ * (modules.py:600-612 runs them one after the other).  Their row tiles form one grid in order of
+ * decreasing cost per tile, so the in-order workgroup dispatch schedules longest-first and the branches
+ * share the chip without waiting for each other's launches.  Results are those of n f2g_fused_block
+ * calls (row by row the same arithmetic; tile heights, hence kernel instances, may differ). */
+int f2g_fused_block_multi(const f2g_dwnorm_fwd_desc* dw, const f2g_fused_mlp_desc* mlp, int32_t n,
+                          f2g_stream_t stream);
 
 #ifdef __cplusplus
 }

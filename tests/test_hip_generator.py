@@ -377,8 +377,16 @@ def test_plain_bf16_inference_at_the_baseline_batch(f2g):
         with torch.no_grad():
             y2 = m.infer(mel, None, 4, True, noise=noise).clone()
             y64 = m.infer(mel.repeat(32, 1, 1), None, 4, True, noise=noise.repeat(32, 1)).clone()
+            # (default: every layer of the three branches is ONE launch, f2g_fused_block_multi;
+            # the per-branch launches on three lanes must give the same waveform)
+            multi_was, ops.FUSED_MULTI = ops.FUSED_MULTI, False
+            try:
+                y2_lanes = m.infer(mel, None, 4, True, noise=noise).clone()
+            finally:
+                ops.FUSED_MULTI = multi_was
     finally:
         ops.GEMM_PRECISION = was
+    assert ops.FUSED_MULTI
     sig = float(y32.double().pow(2).mean().sqrt())
     e2 = rms(y2, y32)
     assert 1e-6 < e2 < 0.05 * sig, (e2, sig)
@@ -387,6 +395,7 @@ def test_plain_bf16_inference_at_the_baseline_batch(f2g):
     # in another order, single activations cross a bf16 rounding boundary, and 4 steps x 8 blocks
     # carry that on -- so B = 64 differs from B = 2 by about the mode's own error (measured: 0.9 of
     # it), and it is held to the same bound against the exact-fp32 waveform ...
+    assert rms(y2_lanes, y2) < 3.0 * e2, (rms(y2_lanes, y2), e2)
     e64 = rms(y64, y32.repeat(32, 1))
     assert 1e-6 < e64 < 0.05 * sig and e64 < 3.0 * e2, (e64, e2, sig)
     # ... and so do the 32 copies of an item among themselves: stream-K / split-K launches (the

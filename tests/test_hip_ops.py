@@ -568,6 +568,15 @@ def test_dwnorm_fwd_bwd(ops, C, Fr, up, K):
                    g_cproj=g_cp, g_te=g_te, g_beta=g_beta, g_log_scale=g_ls)
     close(g_cp[:, C // 2: C // 2 + C], cproj.grad.permute(0, 2, 1).reshape(-1, C), rtol=1e-4, name="g_cproj")
     assert float(g_cp[:, :C // 2].abs().max()) == 0.0
+    # store mode (the block owns its zero-filled columns): same sums without the read-modify-write;
+    # a second accumulate-mode call doubles, a second store-mode call does not
+    g_cp2 = torch.zeros(B * Fc, NC, device=DEV)
+    junk = [torch.zeros(B, NC, device=DEV), torch.zeros(C, device=DEV), torch.zeros(1, device=DEV)]
+    for _ in range(2):
+        ops.dwnorm_bwd(xr, rows(gz), torch.empty_like(du), *args, cp_all, NC, Fc, up, C // 2, te_all, NC,
+                       C // 2, g_cproj=g_cp2, g_te=junk[0], g_beta=junk[1], g_log_scale=junk[2],
+                       g_cproj_store=True)
+    close(g_cp2, g_cp, rtol=1e-6, name="g_cproj store mode")
     close(g_te[:, C // 2: C // 2 + C], te.grad, rtol=1e-4, name="g_te")
     close(g_beta, beta.grad, rtol=2e-4, name="g_beta")
     close(g_ls, ls.grad.reshape(1), rtol=2e-4, name="g_log_scale")
@@ -1012,6 +1021,53 @@ def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
     p0 = (a0.clamp(min=0) + al.double() * a0.clamp(max=0)).float().to(torch.bfloat16)
     want2 = p0.double() @ w2b.double().t()
     assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())
+
+
+def test_fused_block_multi_equals_separate_launches(ops):
+    """f2g_fused_block_multi (the same layer of several branches in one launch, tiles ordered by
+    decreasing cost) against one f2g_fused_block per entry: the same body row by row -- entries handed over in an order that is NOT the cost order, ragged
+    row counts (partial last tiles), one entry without condition / time inputs."""
+    B, K = 3, 7
+    gen = torch.Generator().manual_seed(11)
+    entries, wants = [], []
+    for C, Fr, up, cond in ((384, 94, 4, True), (768, 23, 1, True), (512, 47, 2, False), (768, 5, 1, True)):
+        H = 3 * C
+        Fc = (Fr + up - 1) // up
+        NC = 2 * C
+        x = g(torch.randn(B * Fr, C, generator=gen))
+        e = dict(x=x, B=B, F=Fr, Cc=C, K=K, lens=g(torch.tensor([Fr, max(1, Fr - 4), max(1, Fr // 2)]).int()),
+                 w_dw=g(torch.randn(C, 1, K, generator=gen) * 0.3), b_dw=g(torch.randn(C, generator=gen) * 0.1),
+                 beta=g(torch.randn(C, generator=gen) * 0.1), log_scale=g(torch.tensor([0.6])),
+                 wp=ops.mlp_pack(g(torch.randn(H, C, generator=gen) * 0.05), g(torch.randn(C, H, generator=gen) * 0.03)),
+                 b1=g(torch.randn(H, generator=gen) * 0.1), alpha=g(0.25 + 0.2 * torch.randn(H, generator=gen)),
+                 b2=g(torch.randn(C, generator=gen) * 0.1), gamma=g(0.5 + torch.rand(C, generator=gen)),
+                 out=torch.full((B * Fr, C), float("nan"), device=DEV), Hh=H)
+        if cond:
+            e.update(cproj=g(torch.randn(B * Fc, NC, generator=gen)), ldcp=NC, Fc=Fc, up=up, cp_off=C // 2,
+                     te=g(torch.randn(B, NC, generator=gen) * 0.3), ldte=NC, te_off=C // 2)
+        want = torch.empty(B * Fr, C, device=DEV)
+        ops.fused_block(x, B, Fr, C, K, e["lens"], e["w_dw"], e["b_dw"], e["beta"], e["log_scale"], e["wp"],
+                        e["b1"], e["alpha"], e["b2"], e["gamma"], want, H, e.get("cproj"), e.get("ldcp", 0),
+                        e.get("Fc", 0), e.get("up", 1), e.get("cp_off", 0), e.get("te"), e.get("ldte", 0),
+                        e.get("te_off", 0))
+        entries.append(e)
+        wants.append(want)
+    outs = ops.fused_block_multi(entries)
+    torch.cuda.synchronize()
+    for e, got, want in zip(entries, outs, wants):
+        assert torch.isfinite(got).all(), e["Cc"]
+        # the same arithmetic row by row; a launch may pick another tile height than the multi launch
+        # (another instance of the kernel: the compiler's contraction choices in the z prologue can
+        # differ, and a z value that crosses a bf16 rounding boundary moves the outputs it feeds)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) < 2e-3 * scale, (e["Cc"], e["F"])
+        assert float((got - want).pow(2).mean().sqrt()) < 2e-5 * scale, (e["Cc"], e["F"])
+    # a single entry and the refusal of a fifth
+    one = dict(entries[2]); one["out"] = torch.empty_like(wants[2])
+    got1 = ops.fused_block_multi([one])[0]
+    assert float((got1 - wants[2]).abs().max()) < 2e-3 * float(wants[2].abs().max())
+    with pytest.raises(Exception):
+        ops.fused_block_multi(entries + [entries[0]])
 
 
 @pytest.mark.parametrize("C,B,Fr,up", [(768, 3, 47, 1), (512, 5, 94, 2), (384, 3, 94, 4), (512, 2, 9, 1)])

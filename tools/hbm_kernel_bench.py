@@ -30,7 +30,7 @@ for C, F, up in ((768, 94, 1), (512, 188, 2), (384, 376, 4)):
     t = timeit(lambda: ops.dwnorm_fwd(x, z, *args, cp, NC, Fc, up, 0, te, NC, 0))
     mb = rows * C * 4 * (2 + 1.0 / up) / 1e6
     print(f"{'dwnorm_fwd':14s} {C:4d} {F:4d} {up:2d} {t*1e6:8.1f} {mb:8.1f} {mb/1e3/t:8.0f} {100*mb/1e3/t/8000:10.1f}")
-    t = timeit(lambda: ops.dwnorm_bwd(x, gz, du, *args, cp, NC, Fc, up, 0, te, NC, 0, g_cproj=gcp, g_te=gte, g_beta=gb, g_log_scale=gl))
+    t = timeit(lambda: ops.dwnorm_bwd(x, gz, du, *args, cp, NC, Fc, up, 0, te, NC, 0, g_cproj=gcp, g_te=gte, g_beta=gb, g_log_scale=gl, g_cproj_store=True))
     mb = rows * C * 4 * (3 + 2.0 / up) / 1e6
     print(f"{'dwnorm_bwd':14s} {C:4d} {F:4d} {up:2d} {t*1e6:8.1f} {mb:8.1f} {mb/1e3/t:8.0f} {100*mb/1e3/t/8000:10.1f}")
     t = timeit(lambda: ops.dwconv_bwd(du, x, gx, B, F, C, 7, None, w, gres=gz, gamma=gam, g_w=gw, g_b=gbb, g_gamma=gg))

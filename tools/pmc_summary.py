@@ -2,7 +2,7 @@
 import csv, sys, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for row in csv.DictReader(open(sys.argv[1])):
-    k = re.sub(r"\(.*", "", row["Kernel_Name"])
+    k = re.sub(r"\(.*", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))
     agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in agg.items():
     if len(sys.argv) > 2 and sys.argv[2] not in k:
