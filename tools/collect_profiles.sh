@@ -22,17 +22,22 @@ python tools/streaming_latency.py 100 > $O/streaming.txt 2>/dev/null
 # round 3: fused block kernel, persistent MRD convs, weight-gradient splits, bf16 inference
 python tools/fused_mlp_bench.py > $O/fused_mlp_bench.txt 2>/dev/null
 SPECS="0_16 1_16 2_16 4_16 8_16 15_16 0_8 0_24" bash tools/micro/fusedmlp_lab.sh > $O/fused_mlp_lab.txt 2>/dev/null
+( python tools/fused_multi_bench.py 2>&1 | grep -v amdgpu.ids
+  for rt in 1 2 3 4; do echo "## F2G_MLP_RT=$rt (rows per tile = 32 x $rt where the shape has the instance)"; F2G_MLP_RT=$rt python3 tools/fused_multi_bench.py 2>&1 | grep "alone"; done ) > $O/fused_multi.txt
+bash tools/pmc_multi.sh > $O/pmc_multi.txt 2>&1
 python tools/conv32_probe.py > $O/conv32_probe.txt 2>/dev/null
 F2G_CONV32_V2=0 python tools/conv32_probe.py 2>/dev/null | grep "all 45" > $O/conv32_probe_round2_kernels.txt
 SWEEP=2,4,8,16 python tools/wgrad_probe.py > $O/wgrad_probe.txt 2>/dev/null
 BI="python bench.py --workload infer4 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-fast-mode --gemm bf16"
 ( echo "# $BI   [default: fused block kernel, HIP-graph replay]"; $BI 2>/dev/null | tail -1
   echo "# ... --no-graph"; $BI --no-graph 2>/dev/null | tail -1
+  echo "# F2G_FUSED_MULTI=0 F2G_TIME_AHEAD=0 (one block launch per branch and lane, time paths per step)"; F2G_FUSED_MULTI=0 F2G_TIME_AHEAD=0 $BI 2>/dev/null | tail -1
   echo "# F2G_FUSED_BLOCK=0 (dwnorm + fused MLP as two launches)"; F2G_FUSED_BLOCK=0 $BI 2>/dev/null | tail -1
   echo "# F2G_FUSED_BLOCK=0 F2G_FUSED_MLP=0 (round 2: dwnorm + two lean GEMMs)"; F2G_FUSED_BLOCK=0 F2G_FUSED_MLP=0 $BI 2>/dev/null | tail -1
   echo "# F2G_FUSED_BLOCK=0 F2G_FUSED_MLP=0 --no-graph (round 2 as it was launched)"; F2G_FUSED_BLOCK=0 F2G_FUSED_MLP=0 $BI --no-graph 2>/dev/null | tail -1 ) > $O/infer4_bf16_variants.txt
 python bench.py --workload infer4 --steps 10 --warmup 3 --no-cpu-baseline --no-fast-mode --gemm bf16 2>/dev/null | tail -1 > $O/bench_infer4_bf16.json
 BARGS="--workload infer4 --gemm bf16" bash tools/prof_timeline.sh > /dev/null 2>&1; cp $O/prof_tl.txt $O/infer4_bf16_timeline.txt
+python3 tools/timeline_last.py $O/prof_tl/p_kernel_trace.csv bct_to_rows 400 > $O/infer4_bf16_timeline_kernels.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode"
 F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o p -- $B > /dev/null 2>&1

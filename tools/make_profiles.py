@@ -39,10 +39,11 @@ if os.path.exists(f"{G}/prof_infer/p_kernel_stats.csv"):
     rows = list(csv.DictReader(open(f"{G}/prof_infer/p_kernel_stats.csv")))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     # inferences in the trace: 32 launches of the C = 768 block kernel each (8 blocks x 4 steps)
-    n768 = sum(int(r["Calls"]) for r in rows if "fused_mlp_kernel<2, 6" in r["Name"])
+    n768 = sum(int(r["Calls"]) for r in rows if "fused_mlp_kernel<2, 6" in r["Name"]
+               or "fused_block_multi_kernel" in r["Name"])
     ninf = n768 // 32 if n768 else 4
     L = ["# F2G_STREAMS=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --workload infer4 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode --gemm bf16",
-         f"# BASELINE config 2 (4-step inference, B=64, bf16; whole ConvNeXt blocks as one fused kernel, HIP-graph replay): {tot/ninf/1e6:.2f} ms of kernel time per 4-step inference ({ninf} in the trace: eager warm-up, capture warm-up, replays), launch lanes OFF = every kernel alone on the chip",
+         f"# BASELINE config 2 (4-step inference, B=64, bf16; one fused launch per layer for the ConvNeXt blocks of all three branches, HIP-graph replay): {tot/ninf/1e6:.2f} ms of kernel time per 4-step inference ({ninf} in the trace: eager warm-up, capture warm-up, replays), launch lanes OFF = every kernel alone on the chip",
          f"{'kernel':66s} {'calls':>6s} {'total_ms':>9s} {'avg_us':>9s} {'%':>6s}"]
     for r in rows[:24]:
         n = re.sub(r"\(anonymous namespace\)::", "", r["Name"]); n = re.sub(r"\(.*", "", n)[:66]
