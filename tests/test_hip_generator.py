@@ -95,6 +95,27 @@ def test_full_width_infer_matches_reference(f2g, golden):
             assert err < RMS_TOL, f"n={n}: rms {err:.3e}"
 
 
+def test_time_paths_ahead_equal_the_per_step_time_paths(f2g, golden, monkeypatch):
+    """Inference computes the time path (sinusoidal embedding -> MLP -> per-block projections,
+    modules.py:569-573,451) of ALL Euler steps once, as one batch, ahead of the solver
+    (generator._time_ahead / fused.time_paths_ahead) -- row by row the arithmetic of the per-step
+    path, so the waveform must not move (the only licence: another split of the small stacked GEMM)."""
+    from flow2gan_amd.models import generator as gen_mod
+    g = golden("full_width")
+    torch.manual_seed(int(g["seed"]))
+    from flow2gan_amd.models.config import get_generator_config
+    m = f2g.MelAudioGenerator(**get_generator_config("mel_24k_base")).to(DEV).eval()
+    noise = (0.1 * torch.randn(3, 64 * 256, generator=torch.Generator().manual_seed(5))).to(DEV)
+    mel = T(g["mel"]).to(DEV).repeat(3, 1, 1)
+    lens = torch.tensor([64 * 256, 50 * 256, 33 * 256 + 7])
+    assert gen_mod.TIME_AHEAD
+    with torch.no_grad():
+        ahead = m.infer(mel, lens, 4, True, noise=noise).clone()
+        monkeypatch.setattr(gen_mod, "TIME_AHEAD", False)
+        per_step = m.infer(mel, lens, 4, True, noise=noise).clone()
+    assert rms(ahead, per_step) < 2e-6, rms(ahead, per_step)
+
+
 @pytest.mark.parametrize("tag", ["nodrop", "drop"])
 def test_tiny_stage1_loss_and_all_grads(f2g, golden, tag, monkeypatch):
     g = golden("tiny_stage1")

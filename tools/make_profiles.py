@@ -49,9 +49,25 @@ if os.path.exists(f"{G}/prof_infer/p_kernel_stats.csv"):
         n = re.sub(r"\(anonymous namespace\)::", "", r["Name"]); n = re.sub(r"\(.*", "", n)[:66]
         L.append(f"{n:66s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:9.1f} {float(r['Percentage']):6.2f}")
     open(f"{P}/{R}_infer4_bf16_kernel_stats.txt", "w").write("\n".join(L) + "\n")
-for src, dst in (("lean3_bench.txt", "lean3_bench.txt"), ("conv32_b3_bench.txt", "conv32_split_bench.txt")):
-    if os.path.exists(f"{G}/{src}"):
-        open(f"{P}/{R}_{dst}", "w").write(open(f"{G}/{src}").read())
+HEAD = {
+    "fused_multi.txt": "# tools/fused_multi_bench.py: one layer of the three Fourier branches' ConvNeXt blocks (mel_24k_base, B = 64, bf16) as three launches one after the other / on three streams / as ONE f2g_fused_block_multi launch; then every block alone with the tile height forced (F2G_MLP_RT)\n",
+    "pmc_multi.txt": "# tools/pmc_multi.sh: rocprofv3 --pmc passes over tools/fused_multi_bench.py (MODE=multi, MODE=serial); per-kernel means\n",
+    "infer4_bf16_timeline_kernels.txt": "# tools/timeline_last.py over the kernel trace of tools/prof_timeline.sh: every kernel of the last graph-replayed bf16 4-step inference (start us, duration us, queue, blocks, kernel)\n",
+    "hbm_kernels.txt": "# tools/hbm_kernel_bench.py: the HBM-class ConvNeXt kernels back to back at the mel_24k_base branch shapes (B = 64); algorithmic bytes / HIP-event time against 8 TB/s\n",
+    "infer4_bf16_variants.txt": "",
+    "infer4_bf16_timeline.txt": "# tools/prof_timeline.sh (rocprofv3 --kernel-trace over the HIP-graph replayed bf16 4-step inference, launch lanes ON): overlap statistics of the last inference in the trace (profiled: ~5-15 % slower than unprofiled)\n",
+    "wgrad_probe.txt": "", "conv32_probe.txt": "", "fused_mlp_bench.txt": "", "fused_mlp_lab.txt": "",
+}
+for src, dst in (("lean3_bench.txt", "lean3_bench.txt"), ("conv32_b3_bench.txt", "conv32_split_bench.txt"),
+                 ("fused_multi.txt", "fused_multi.txt"), ("pmc_multi.txt", "fused_multi_pmc.txt"),
+                 ("infer4_bf16_timeline_kernels.txt", "infer4_bf16_timeline_kernels.txt"),
+                 ("hbm_kernels.txt", "hbm_kernels.txt"), ("infer4_bf16_variants.txt", "infer4_bf16_variants.txt"),
+                 ("infer4_bf16_timeline.txt", "infer4_bf16_timeline.txt")):
+    if os.path.exists(f"{G}/{src}") and os.path.getsize(f"{G}/{src}") > 0:
+        body = "\n".join(l for l in open(f"{G}/{src}").read().split("\n") if "amdgpu.ids" not in l)
+        open(f"{P}/{R}_{dst}", "w").write(HEAD.get(src, "") + body)
+if os.path.exists(f"{G}/bench_infer4_bf16.json"):
+    open(f"{P}/{R}_bench_infer4_bf16.json", "w").write(open(f"{G}/bench_infer4_bf16.json").read().strip().split("\n")[-1] + "\n")
 txt = open(f"{G}/shapes.txt").read().split("\n")
 i = next(k for k, l in enumerate(txt) if l.startswith("form"))
 open(f"{P}/{R}_gemm_shapes_fp32.txt", "w").write(
