@@ -28,6 +28,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -105,43 +106,45 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
       cok[k] = c < C;
       c4[k] = cok[k] ? c : 0;
     }
-    auto ld4 = [](float (&o)[4], const float* p) {
-      const float4 t = *reinterpret_cast<const float4*>(p);
-      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
-    };
-    // this lane's taps (channel e, tap j = tw[k][7 e + j]: 28 consecutive floats of the (C, 1, 7)
-    // checkpoint layout), depthwise bias and BiasNorm bias
-    float tw[NCQ][28], bdw[NCQ][4], bet[NCQ][4];
+    // Everything below works on four-channel vectors (ext_vector_type: the compiler keeps them in
+    // registers under literal indices and pairs the lanes' arithmetic into v_pk_fma_f32 / v_pk_mul_f32
+    // -- the scalar version of this prologue ran ~40 vector instructions per element with its
+    // spill moves, and the prologue is vector-ALU bound).
+    auto ldv = [](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+    // this lane's taps: 28 consecutive floats of the (C, 1, 7) checkpoint layout (channel e, tap j at
+    // 7 e + j) -> one vector per tap; depthwise bias and BiasNorm bias
+    f32x4 tw4[NCQ][7], bdw4[NCQ], bet4[NCQ];
 #pragma unroll
     for (int k = 0; k < NCQ; ++k) {
+      float t28[28];
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        float t4[4];
-        ld4(t4, P.w_dw + (long long)c4[k] * 7 + 4 * i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tw[k][4 * i + e] = t4[e];
+        const f32x4 t = ldv(P.w_dw + (long long)c4[k] * 7 + 4 * i);
+        t28[4 * i] = t[0]; t28[4 * i + 1] = t[1]; t28[4 * i + 2] = t[2]; t28[4 * i + 3] = t[3];
       }
-      if (P.b_dw) ld4(bdw[k], P.b_dw + c4[k]);
-      else bdw[k][0] = bdw[k][1] = bdw[k][2] = bdw[k][3] = 0.f;
-      ld4(bet[k], P.beta + c4[k]);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) tw4[k][j] = f32x4{t28[j], t28[7 + j], t28[14 + j], t28[21 + j]};
+      bdw4[k] = P.b_dw ? ldv(P.b_dw + c4[k]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bet4[k] = ldv(P.beta + c4[k]);
     }
     const long long last = (long long)d.rows - 1;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < RW / FW; ++g) {
       const int lr0 = w * RW + g * FW;              // first frame of the group inside the tile
       const long long r0 = (long long)m0 + lr0;     // ... in the flattened (item, frame) rows
-      float xr[NCQ][FW + 6][4];
+      f32x4 xr[NCQ][FW + 6];
 #pragma unroll
       for (int r = 0; r < FW + 6; ++r) {
         long long rr = r0 - 3 + r;
         rr = rr < 0 ? 0 : (rr > last ? last : rr);
         const float* xrow = P.x + rr * P.ldx;
 #pragma unroll
-        for (int k = 0; k < NCQ; ++k) ld4(xr[k][r], xrow + c4[k]);
+        for (int k = 0; k < NCQ; ++k) xr[k][r] = ldv(xrow + c4[k]);
       }
       // item / frame of every output row of the group; condition and time rows
       int fi[FW], li_[FW];
-      bool lv[FW];
-      float cp[FW][NCQ][4], te1[FW][NCQ][4];
+      bool lv[FW], hascp[FW];
+      f32x4 cp[FW][NCQ], te1[FW][NCQ];
 #pragma unroll
       for (int i = 0; i < FW; ++i) {
         const long long r = r0 + i;
@@ -153,38 +156,31 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
         li_[i] = len_b < F ? len_b : F;
         const int fc = P.cproj ? f / P.up : 0;
         const bool has = P.cproj && fc < P.Fc;
+        hascp[i] = has;
         const float* cprow = has ? P.cproj + ((long long)b * P.Fc + fc) * P.ldcp : P.x;
         const float* terow = P.te ? P.te + (long long)b * P.ldte : P.x;
 #pragma unroll
         for (int k = 0; k < NCQ; ++k) {
-          ld4(cp[i][k], cprow + c4[k]);
-          ld4(te1[i][k], terow + c4[k]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (!has) cp[i][k][e] = 0.f;
-            te1[i][k][e] = P.te ? te1[i][k][e] + 1.f : 1.f;
-          }
+          cp[i][k] = ldv(cprow + c4[k]);       // (consumed at the end of the group: no arithmetic on
+          te1[i][k] = ldv(terow + c4[k]);      //  them here, it would wait for them here)
         }
       }
       // (wave-uniform) does any tap of the group leave its item or its valid length?
       const bool interior = lv[FW - 1] && fi[FW - 1] == fi[0] + FW - 1 && fi[0] >= 3 &&
                             fi[FW - 1] + 3 < li_[0];
-      float u[FW][NCQ][4], ssq[FW];
+      f32x4 u[FW][NCQ];
+      float ssq[FW];
 #pragma unroll
       for (int i = 0; i < FW; ++i) ssq[i] = 0.f;
 #pragma unroll
       for (int k = 0; k < NCQ; ++k) {
 #pragma unroll
-        for (int i = 0; i < FW; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) u[i][k][e] = bdw[k][e];
+        for (int i = 0; i < FW; ++i) u[i][k] = bdw4[k];
         if (interior) {
 #pragma unroll
           for (int j = 0; j < 7; ++j)
 #pragma unroll
-            for (int i = 0; i < FW; ++i)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) u[i][k][e] += tw[k][7 * e + j] * xr[k][i + j][e];
+            for (int i = 0; i < FW; ++i) u[i][k] += tw4[k][j] * xr[k][i + j];
         } else {
 #pragma unroll
           for (int j = 0; j < 7; ++j)
@@ -192,18 +188,17 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
             for (int i = 0; i < FW; ++i) {
               const int fj = fi[i] + j - 3;
               const bool ok = fj >= 0 && fj < li_[i];      // (the masked input of modules.py:473)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) u[i][k][e] += tw[k][7 * e + j] * (ok ? xr[k][i + j][e] : 0.f);
+              u[i][k] += tw4[k][j] * (ok ? xr[k][i + j] : zero4);
             }
         }
         if (cok[k]) {
 #pragma unroll
-          for (int i = 0; i < FW; ++i)
+          for (int i = 0; i < FW; ++i) {
+            const f32x4 dl = u[i][k] - bet4[k];
+            // (the order and the fused multiply-adds of dwnorm4_kernel: the two kernels produce the same z)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float dlt = u[i][k][e] - bet[k][e];
-              ssq[i] += dlt * dlt;
-            }
+            for (int e = 0; e < 4; ++e) ssq[i] = fmaf(dl[e], dl[e], ssq[i]);
+          }
         }
       }
 #pragma unroll
@@ -213,12 +208,12 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
 #pragma unroll
         for (int k = 0; k < NCQ; ++k) {
           if (cok[k]) {
+            const f32x4 cpv = hascp[i] ? cp[i][k] : zero4;
+            const f32x4 tev = P.te ? te1[i][k] + 1.f : f32x4{1.f, 1.f, 1.f, 1.f};
+            const f32x4 zv = lv[i] ? (u[i][k] * sc + cpv) * tev : zero4;
             unsigned short hb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float zv = lv[i] ? (u[i][k][e] * sc + cp[i][k][e]) * te1[i][k][e] : 0.f;
-              hb[e] = __builtin_bit_cast(unsigned short, (__bf16)zv);
-            }
+            for (int e = 0; e < 4; ++e) hb[e] = __builtin_bit_cast(unsigned short, (__bf16)zv[e]);
             *reinterpret_cast<uint2*>(zs + (lr0 + i) * ZP + c4[k] * 2) =
                 make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
           }
