@@ -129,10 +129,12 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
     }
     const long long last = (long long)d.rows - 1;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < RW / FW; ++g) {
-      const int lr0 = w * RW + g * FW;              // first frame of the group inside the tile
-      const long long r0 = (long long)m0 + lr0;     // ... in the flattened (item, frame) rows
-      f32x4 xr[NCQ][FW + 6];
+    // A wave's rows are consecutive: consecutive groups share 6 of their FW + 6 input rows.  The
+    // window xr slides by FW rows per group, and the FW new rows of group g + 1 (xn) are requested
+    // before group g is computed -- with one wave per SIMD nothing else hides their round trip.
+    f32x4 xr[NCQ][FW + 6], xn[NCQ][FW];
+    {
+      const long long r0 = (long long)m0 + w * RW;
 #pragma unroll
       for (int r = 0; r < FW + 6; ++r) {
         long long rr = r0 - 3 + r;
@@ -141,6 +143,11 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
 #pragma unroll
         for (int k = 0; k < NCQ; ++k) xr[k][r] = ldv(xrow + c4[k]);
       }
+    }
+#pragma unroll 1
+    for (int g = 0; g < RW / FW; ++g) {
+      const int lr0 = w * RW + g * FW;              // first frame of the group inside the tile
+      const long long r0 = (long long)m0 + lr0;     // ... in the flattened (item, frame) rows
       // item / frame of every output row of the group; condition and time rows
       int fi[FW], li_[FW];
       bool lv[FW], hascp[FW];
@@ -165,6 +172,17 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
           te1[i][k] = ldv(terow + c4[k]);      //  them here, it would wait for them here)
         }
       }
+      if (g + 1 < RW / FW) {
+#pragma unroll
+        for (int i = 0; i < FW; ++i) {
+          long long rr = r0 + FW + 3 + i;
+          rr = rr < 0 ? 0 : (rr > last ? last : rr);
+          const float* xrow = P.x + rr * P.ldx;
+#pragma unroll
+          for (int k = 0; k < NCQ; ++k) xn[k][i] = ldv(xrow + c4[k]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // (the requests stay in front of the arithmetic)
       // (wave-uniform) does any tap of the group leave its item or its valid length?
       const bool interior = lv[FW - 1] && fi[FW - 1] == fi[0] + FW - 1 && fi[0] >= 3 &&
                             fi[FW - 1] + 3 < li_[0];
@@ -217,6 +235,16 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
             *reinterpret_cast<uint2*>(zs + (lr0 + i) * ZP + c4[k] * 2) =
                 make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
           }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < RW / FW) {        // slide the window
+#pragma unroll
+        for (int k = 0; k < NCQ; ++k) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) xr[k][r] = xr[k][r + FW];
+#pragma unroll
+          for (int i = 0; i < FW; ++i) xr[k][6 + i] = xn[k][i];
         }
       }
     }
