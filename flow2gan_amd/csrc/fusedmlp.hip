@@ -129,6 +129,7 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
     }
     const long long last = (long long)d.rows - 1;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int upshift = P.up >= 4 ? 2 : (P.up >= 2 ? 1 : 0);
     // A wave's rows are consecutive: consecutive groups share 6 of their FW + 6 input rows.  The
     // window xr slides by FW rows per group, and the FW new rows of group g + 1 (xn) are requested
     // before group g is computed -- with one wave per SIMD nothing else hides their round trip.
@@ -152,16 +153,21 @@ __device__ __forceinline__ void fused_mlp_body(const f2g_fused_mlp_desc& d, cons
       int fi[FW], li_[FW];
       bool lv[FW], hascp[FW];
       f32x4 cp[FW][NCQ], te1[FW][NCQ];
+      // (item, frame) of the group's first row by one division, of the others by counting on (a
+      // division again only where the group crosses an item end); rows past the end: the last row
+      const int r0c = (int)(r0 <= last ? r0 : last);
+      const int b0 = r0c / F, f0 = r0c - b0 * F;
 #pragma unroll
       for (int i = 0; i < FW; ++i) {
         const long long r = r0 + i;
         lv[i] = r <= last;
-        const int rc = (int)(lv[i] ? r : last);
-        const int b = rc / F, f = rc - b * F;
+        int b = b0, f = f0 + i;
+        if (f >= F) { const int q = f / F; b += q; f -= q * F; }
+        if (!lv[i]) { b = P.B - 1; f = F - 1; }
         fi[i] = f;
         const int len_b = P.lens ? P.lens[b] : F;
         li_[i] = len_b < F ? len_b : F;
-        const int fc = P.cproj ? f / P.up : 0;
+        const int fc = P.cproj ? f >> upshift : 0;      // up is 1, 2 or 4
         const bool has = P.cproj && fc < P.Fc;
         hascp[i] = has;
         const float* cprow = has ? P.cproj + ((long long)b * P.Fc + fc) * P.ldcp : P.x;
@@ -654,7 +660,7 @@ static int check_block(const f2g_dwnorm_fwd_desc& w, const f2g_fused_mlp_desc& d
   if (!w.x || !w.w_dw || !w.beta || !w.log_scale || !d.wp || !d.alpha || !d.out) return F2G_EINVAL;
   if (!f2g_fused_mlp_ok(d.C, d.H) || w.C != d.C || w.K != 7 || w.B <= 0 || w.F <= 0 ||
       (long long)w.B * w.F != d.rows || (w.ldx & 3) || w.ldx < d.C || !al16(w.x) || !al16(w.w_dw) ||
-      !al16(w.beta) || (w.b_dw && !al16(w.b_dw)) || (w.cproj && (!al16(w.cproj) || (w.ldcp & 3) || w.up < 1)) ||
+      !al16(w.beta) || (w.b_dw && !al16(w.b_dw)) || (w.cproj && (!al16(w.cproj) || (w.ldcp & 3) || (w.up != 1 && w.up != 2 && w.up != 4))) ||
       (w.te && (!al16(w.te) || (w.ldte & 3))) || (d.res && (d.ldres < d.C || (d.ldres & 3) || !al16(d.res))) ||
       d.ldo < d.C || (d.ldo & 3) || !al16(d.out) || !al16(d.wp) || (d.gamma && !al16(d.gamma)) ||
       (long long)d.rows * d.ldo * 4 >= 0x7ff00000ll || (d.res && (long long)d.rows * d.ldres * 4 >= 0x7ff00000ll)) {
