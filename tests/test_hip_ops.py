@@ -1023,6 +1023,57 @@ def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
     assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("C,rows,tile", [(768, 64 * 130 + 7, 64), (512, 96 * 128 + 5, 96), (512, 64 * 129, 64),
+                                         (384, 128 * 128 + 3, 128), (384, 64 * 130 + 1, 64)])
+def test_fused_mlp_taller_tiles(ops, C, rows, tile):
+    """The fused kernel picks its tile height by the row count (fusedmlp.hip: pick_rt; the small cases
+    above all run on 32-row tiles): row counts that select the 64 / 96 / 128-row instances, against a
+    float64 torch restatement of the same arithmetic (computed on the GPU), with and without the z
+    prologue (f2g_fused_block against f2g_dwnorm_fwd + f2g_fused_mlp on the same rows)."""
+    H = 3 * C
+    assert (rows + tile - 1) // tile >= 128            # (what makes pick_rt take this height)
+    gen = torch.Generator().manual_seed(C + rows)
+    z = torch.randn(rows, C, generator=gen).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(H, C, generator=gen) * 0.05).to(DEV)
+    w2 = (torch.randn(C, H, generator=gen) * 0.03).to(DEV)
+    b1 = (torch.randn(H, generator=gen) * 0.1).to(DEV)
+    al = (0.25 + 0.2 * torch.randn(H, generator=gen)).to(DEV)
+    b2 = (torch.randn(C, generator=gen) * 0.1).to(DEV)
+    x = torch.randn(rows, C, generator=gen).to(DEV)
+    gam = (0.5 + torch.rand(C, generator=gen)).to(DEV)
+    w1b, w2b = w1.to(torch.bfloat16).double(), w2.to(torch.bfloat16).double()
+    a = z.double() @ w1b.t() + b1.double()
+    p = (a.clamp(min=0) + al.double() * a.clamp(max=0)).float().to(torch.bfloat16)
+    want = p.double() @ w2b.t() + b2.double() + gam.double() * x.double()
+    wp = ops.mlp_pack(w1, w2)
+    out = torch.full((rows, C), float("nan"), device=DEV)
+    ops.fused_mlp(z, wp, b1, al, b2, x, gam, out, rows, C, H)
+    assert torch.isfinite(out).all()
+    scale = float(want.abs().max())
+    assert float((out.double() - want).abs().max()) < 2e-3 * scale
+    assert float((out.double() - want).pow(2).mean().sqrt()) < 1e-4 * scale
+    # the block kernel on the same tile height: rows = B * F with ragged lengths
+    B = 8
+    if rows % B == 0:
+        Fr = rows // B
+    else:
+        Fr, rows = rows // B, (rows // B) * B
+    xs = x[:rows]
+    lens = g(torch.tensor([Fr, Fr - 3, Fr // 2, Fr, Fr - 1, 7, Fr, Fr - 11]).int())
+    args = (B, Fr, C, 7, lens, g(torch.randn(C, 1, 7, generator=gen) * 0.3), g(torch.randn(C, generator=gen) * 0.1),
+            g(torch.randn(C, generator=gen) * 0.1), g(torch.tensor([0.7])))
+    zz = torch.empty(rows, C, device=DEV, dtype=torch.bfloat16)
+    ops.dwnorm_fwd(xs, zz, *args, z_format=2)
+    want_b = torch.empty(rows, C, device=DEV)
+    ops.fused_mlp(zz, wp, b1, al, b2, xs, gam, want_b, rows, C, H)
+    got_b = torch.full((rows, C), float("nan"), device=DEV)
+    ops.fused_block(xs, *args, wp, b1, al, b2, gam, got_b, H)
+    sb = float(want_b.abs().max())
+    assert torch.isfinite(got_b).all()
+    assert float((got_b - want_b).abs().max()) < 2e-3 * sb
+    assert float((got_b - want_b).pow(2).mean().sqrt()) < 2e-5 * sb
+
+
 def test_fused_block_multi_equals_separate_launches(ops):
     """f2g_fused_block_multi (the same layer of several branches in one launch, tiles ordered by
     decreasing cost) against one f2g_fused_block per entry: the same body row by row -- entries handed over in an order that is NOT the cost order, ragged
