@@ -102,7 +102,14 @@ class FftDesc(C.Structure):  # == f2g_fft_desc
     _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("hop", C.c_int32), ("n_fft", C.c_int32),
                 ("F", C.c_int32), ("rows", C.c_int32), ("window", C.c_void_p), ("twiddle", C.c_void_p),
                 ("spec", C.c_void_p), ("ld_spec", C.c_int64), ("interleaved", C.c_int32),
-                ("spec_cols", C.c_int32), ("frames", C.c_void_p), ("ld_frames", C.c_int64)]
+                ("spec_cols", C.c_int32), ("frames", C.c_void_p), ("ld_frames", C.c_int64),
+                ("reflect_T", C.c_int32), ("_pad", C.c_int32)]
+
+
+class OlaMultiDesc(C.Structure):  # == f2g_ola_multi_desc
+    _fields_ = [("frames", C.c_void_p * 4), ("ldf", C.c_int64 * 4), ("F", C.c_int32 * 4),
+                ("n_fft", C.c_int32 * 4), ("hop", C.c_int32 * 4), ("window", C.c_void_p * 4),
+                ("wbranch", C.c_void_p * 4), ("n", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Mpd0Desc(C.Structure):  # == f2g_mpd0_desc
@@ -208,6 +215,7 @@ _SIGS = {
     "f2g_fused_mlp": [C.POINTER(FusedMlpDesc)],
     "f2g_fused_block": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc)],
     "f2g_fused_block_multi": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc), C.c_int32],
+    "f2g_istft_ola_multi": [C.POINTER(OlaMultiDesc), _P, _I, _I, _F, _I],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
                                  "f2g_gemm_lean_ok", "f2g_fused_mlp_ok",

@@ -50,8 +50,20 @@ __global__ __launch_bounds__(256) void fft_frames_kernel(const f2g_fft_desc d) {
   for (int j = threadIdx.x; j < H; j += 256) tw[j] = reinterpret_cast<const float2*>(d.twiddle)[j];
   const float inv_n = 1.f / (float)N;
   if (MODE == 0) {
-    const float* x = d.x + (long long)item * d.x_stride + (long long)m * d.hop;
-    for (int n = tid; n < N; n += NT) buf0[n] = make_float2(d.window[n] * x[n], 0.f);
+    if (d.reflect_T > 0) {
+      // torch.stft's center / reflect padding applied here (no padded copy of the signal)
+      const float* x = d.x + (long long)item * d.x_stride;
+      const int T = d.reflect_T, q0 = m * d.hop - H;
+      for (int n = tid; n < N; n += NT) {
+        int q = q0 + n;
+        q = q < 0 ? -q : q;
+        q = q >= T ? 2 * T - 2 - q : q;
+        buf0[n] = make_float2(d.window[n] * x[q], 0.f);
+      }
+    } else {
+      const float* x = d.x + (long long)item * d.x_stride + (long long)m * d.hop;
+      for (int n = tid; n < N; n += NT) buf0[n] = make_float2(d.window[n] * x[n], 0.f);
+    }
   } else if (MODE == 3) {
     const float* x = d.frames + (long long)row * d.ld_frames;
     for (int n = tid; n < N; n += NT) buf0[n] = make_float2(d.window[n] * x[n], 0.f);
@@ -145,6 +157,7 @@ extern "C" int f2g_fft_frames(const f2g_fft_desc* d, int32_t mode, f2g_stream_t 
   const int N = d->n_fft;
   if (N < 64 || N > 4096 || (N & (N - 1))) return F2G_EINVAL;
   if (!d->window || (mode == 0 ? !d->x : !d->frames)) return F2G_EINVAL;
+  if (mode == 0 && d->reflect_T != 0 && d->reflect_T <= N / 2) return F2G_EINVAL;
   if ((d->interleaved & 2) && (d->interleaved & 1)) return F2G_EINVAL;    // bf16 spectra are planar
   if (d->spec_cols > d->ld_spec) return F2G_EINVAL;
   if (d->rows <= 0) return F2G_OK;

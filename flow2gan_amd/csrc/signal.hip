@@ -35,6 +35,43 @@ __global__ __launch_bounds__(256) void ola_kernel(const float* frames, long long
   }
 }
 
+// the overlap-adds of up to four branches in one pass over the output (same arithmetic and the
+// same order of the branch sums as n ola_kernel launches)
+__global__ __launch_bounds__(256) void ola_multi_kernel(const f2g_ola_multi_desc d, float* out, int B,
+                                                        int T, float wscale, int accumulate) {
+  const int b = blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
+    const long long o = (long long)b * T + j;
+    float acc = accumulate ? out[o] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < d.n) {
+        const int F = d.F[i], N = d.n_fft[i], hop = d.hop[i];
+        const int Lout = hop * (F - 1);
+        float y = 0.f;
+        if (j < Lout) {
+          const int p = j + N / 2;
+          int mhi = p / hop;
+          if (mhi > F - 1) mhi = F - 1;
+          int mlo = (p - N + hop) / hop;
+          if (p - N + 1 <= 0) mlo = 0;
+          float val = 0.f, env = 0.f;
+          for (int m = mlo; m <= mhi; ++m) {
+            const int n = p - m * hop;
+            val += d.frames[i][((long long)b * F + m) * d.ldf[i] + n];
+            const float w = d.window[i][n];
+            env += w * w;
+          }
+          y = val / env;
+        }
+        const float sc = wscale * (d.wbranch[i] ? d.wbranch[i][b] : 1.f);
+        acc = (i == 0 && !accumulate) ? sc * y : acc + sc * y;
+      }
+    }
+    out[o] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void ola_bwd_kernel(const float* gout, float* gframes,
                                                       long long ldf, int B, int F, int N, int hop,
                                                       int T, const float* window,
@@ -213,6 +250,20 @@ extern "C" int f2g_istft_ola(const float* frames, int64_t ldf, float* out, int32
   dim3 grid(f2g_grid_for(T, 256, 1024), B);
   hipLaunchKernelGGL(ola_kernel, grid, dim3(256), 0, (hipStream_t)stream, frames, (long long)ldf,
                      out, B, F, n_fft, hop, T, window, wbranch, wscale, accumulate);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_istft_ola_multi(const f2g_ola_multi_desc* d, float* out, int32_t B, int32_t T,
+                                   float wscale, int32_t accumulate, f2g_stream_t stream) {
+  if (!d || !out || d->n < 1 || d->n > 4) return F2G_EINVAL;
+  for (int i = 0; i < d->n; ++i)
+    if (!d->frames[i] || !d->window[i] || d->n_fft[i] < 2 || d->hop[i] < 1 || d->hop[i] > d->n_fft[i] ||
+        d->F[i] < 1)
+      return F2G_EINVAL;
+  if (B <= 0 || T <= 0) return F2G_OK;
+  dim3 grid(f2g_grid_for(T, 256, 1024), B);
+  hipLaunchKernelGGL(ola_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d, out, B, T, wscale,
+                     accumulate);
   return f2g_check_launch();
 }
 

@@ -588,8 +588,10 @@ def _branch_pre(bv: _BranchView, meta, x, t, cproj, training, keep, te_pre=None)
 
 
 def _branch_post(st, bv: _BranchView, meta, x_shape, wbranch_row, wscale, pred, accumulate, lens_f,
-                 lanes=None):
-    """out_proj -> iSTFT -> overlap-add into the shared prediction (modules.py:613-621,719)."""
+                 lanes=None, ola: bool = True):
+    """out_proj -> iSTFT -> overlap-add into the shared prediction (modules.py:613-621,719).
+    ola=False: stop in front of the overlap-add and return the frames (the caller adds all branches
+    with one launch)."""
     n_fft, hop, up, window = meta
     B, T = x_shape
     N, F, rows, ldp, Kc = n_fft, st["F"], st["rows"], st["ldp"], st["Kc"]
@@ -609,11 +611,14 @@ def _branch_post(st, bv: _BranchView, meta, x_shape, wbranch_row, wscale, pred, 
         ops.istft_fft(yspec, N, F, frames)
     else:
         gemm(mat(yspec, rows, Kc, split=2 if ybf else 0), mat(_pad_cols(Wi, Kc)), frames, split_k=1)
+    if not ola:
+        return frames
     if lanes is not None:
         lanes.chain_enter()  # pred is accumulated branch after branch
     ops.istft_ola(frames, pred, B, F, N, hop, T, window, wbranch_row, wscale, accumulate)
     if lanes is not None:
         lanes.chain_leave()
+    return None
 
 
 def _branch_forward(bv: _BranchView, meta, x, t, cproj, wbranch_row, wscale, pred, accumulate,
@@ -687,11 +692,16 @@ def _branches_forward_multi(views, metas, x, t, cprojs, wbranch, wscale, pred, l
         for i in range(nb):
             sts[i]["xcur"] = outs[i]
     lanes = ops.Lanes(dev, nb, "branch")
+    frames = [None] * nb
     for i in range(nb):
-        wrow = None if wbranch is None else wbranch[i]
         with lanes.lane(i):
-            _branch_post(sts[i], views[i], metas[i], x.shape, wrow, wscale, pred, i > 0, lens_list[i], lanes)
+            frames[i] = _branch_post(sts[i], views[i], metas[i], x.shape, None, wscale, pred, i > 0,
+                                     lens_list[i], lanes, ola=False)
     lanes.join()
+    # the overlap-adds of all branches (their weighted mean) as one pass over the prediction
+    ops.istft_ola_multi([(frames[i], sts[i]["F"], metas[i][0], metas[i][1], metas[i][3],
+                          None if wbranch is None else wbranch[i]) for i in range(nb)],
+                        pred, B, x.shape[1], wscale)
 
 
 def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_row, wscale,

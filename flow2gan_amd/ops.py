@@ -1002,6 +1002,19 @@ def istft_ola(frames, out, B, F, n_fft, hop, T, window, wbranch, wscale, accumul
          ptr(window), ptr(wbranch), float(wscale), 1 if accumulate else 0)
 
 
+def istft_ola_multi(entries, out, B, T, wscale, accumulate=False):
+    """The overlap-adds of up to four branches in one launch; entries: (frames, F, n_fft, hop, window,
+    wbranch or None) in the order their sums are to be added."""
+    d = L.OlaMultiDesc()
+    d.n = len(entries)
+    for i, (frames, F, n_fft, hop, window, wbranch) in enumerate(entries):
+        d.frames[i], d.ldf[i] = ptr(frames), frames.stride(0)
+        d.F[i], d.n_fft[i], d.hop[i] = F, n_fft, hop
+        d.window[i], d.wbranch[i] = ptr(window), ptr(wbranch)
+    call("f2g_istft_ola_multi", C.byref(d), ptr(out), B, T, float(wscale), 1 if accumulate else 0)
+    return out
+
+
 def istft_ola_bwd(gout, gframes, B, F, n_fft, hop, T, window, wbranch, wscale):
     call("f2g_istft_ola_bwd", ptr(gout), ptr(gframes), gframes.stride(0), B, F, n_fft, hop, T,
          ptr(window), ptr(wbranch), float(wscale))
@@ -1264,17 +1277,26 @@ def _spec_flags(spec, interleaved: bool) -> int:
     return (1 if interleaved else 0) | (2 if spec.dtype == torch.bfloat16 else 0)
 
 
+FFT_REFLECT = _os.environ.get("F2G_FFT_REFLECT", "1") != "0"   # center / reflect padding inside the FFT kernel
+
+
 def stft_fft(x, n_fft: int, hop: int, F: int, spec, interleaved: bool = False, zero_pad: bool = False):
     """spec (B*F, ld) = STFT of x (B, T) (center, reflect, periodic hann) through the LDS FFT.  spec
     may be a bf16 tensor (planar rows); zero_pad: the kernel also zeroes columns [n_fft + 2, ld)."""
     B, T = x.shape
     pad = n_fft // 2
-    Tp = pad4(T + 2 * pad)
-    xp = torch.empty(B, Tp, device=x.device, dtype=torch.float32)
-    call("f2g_reflect_pad", ptr(xp), ptr(x), B, T, pad, Tp)
     win, tw = _fft_tables(n_fft, x.device)
     d = L.FftDesc()
-    d.x, d.x_stride, d.hop, d.n_fft, d.F, d.rows = ptr(xp), Tp, hop, n_fft, F, B * F
+    if FFT_REFLECT and T > pad and x.stride(1) == 1:
+        # the kernel reflects at the signal's ends itself: no padded copy, no extra launch
+        xp = x
+        d.x, d.x_stride, d.reflect_T = ptr(x), x.stride(0), T
+    else:
+        Tp = pad4(T + 2 * pad)
+        xp = torch.empty(B, Tp, device=x.device, dtype=torch.float32)
+        call("f2g_reflect_pad", ptr(xp), ptr(x), B, T, pad, Tp)
+        d.x, d.x_stride = ptr(xp), Tp
+    d.hop, d.n_fft, d.F, d.rows = hop, n_fft, F, B * F
     d.window, d.twiddle = ptr(win), ptr(tw)
     d.spec, d.ld_spec, d.interleaved = ptr(spec), spec.stride(0), _spec_flags(spec, interleaved)
     d.spec_cols = spec.shape[1] if zero_pad else 0

@@ -266,6 +266,19 @@ int f2g_biasnorm_bwd(const float* x, int64_t ldx, const float* gy, int64_t ldgy,
 int f2g_istft_ola(const float* frames, int64_t ldf, float* out, int32_t B, int32_t F,
                   int32_t n_fft, int32_t hop, int32_t T, const float* window,
                   const float* wbranch, float wscale, int32_t accumulate, f2g_stream_t stream);
+/* The same for up to four branches in one launch:
+ *   out[b,t] (=|+=) sum_i wscale * wbranch_i[b] * y_i[b,t]   (summed in the order of the entries:
+ * what n f2g_istft_ola calls, the first with `accumulate`, the others accumulating, leave in out). */
+typedef struct {
+  const float* frames[4];
+  int64_t ldf[4];
+  int32_t F[4], n_fft[4], hop[4];
+  const float* window[4];
+  const float* wbranch[4]; /* (B) each, or NULL */
+  int32_t n, _pad;
+} f2g_ola_multi_desc;
+int f2g_istft_ola_multi(const f2g_ola_multi_desc* d, float* out, int32_t B, int32_t T, float wscale,
+                        int32_t accumulate, f2g_stream_t stream);
 /* Backward: gframes[b,m,n] = gout[b, m*hop+n-n_fft/2] / env * wbranch[b]*wscale (the synthesis
  * window itself is folded into the inverse-DFT matrix). */
 int f2g_istft_ola_bwd(const float* gout, float* gframes, int64_t ldf, int32_t B, int32_t F,
@@ -400,6 +413,11 @@ typedef struct {
                         * zeros (0: leave them alone) */
   float* frames;
   int64_t ld_frames;
+  int32_t reflect_T;   /* mode 0: > 0 = x is the UNPADDED signal (items of reflect_T samples, x_stride
+                        * apart) and the kernel applies torch.stft's center / reflect padding itself:
+                        * frame m, sample n reads x[reflect(m*hop + n - n_fft/2)] (needs
+                        * reflect_T > n_fft/2); 0 = x is already padded (f2g_reflect_pad) */
+  int32_t _pad;
 } f2g_fft_desc;
 int f2g_fft_frames(const f2g_fft_desc* d, int32_t mode, f2g_stream_t stream);
 

@@ -336,6 +336,22 @@ def test_stft_lds_fft_forward_and_adjoint(ops, n_fft, hop, T, inter):
     else:
         want = torch.cat([ref.real, ref.imag], 1).permute(0, 2, 1).reshape(B * Fr, 2 * nb)
     close(spec[:, :2 * nb], want.detach(), rtol=5e-6, name="fft-stft")
+    # (default: the kernel applies the center / reflect padding itself; the padded-copy path -- a
+    # f2g_reflect_pad launch in front -- gives the same spectrum bit for bit, and a non-contiguous
+    # batch of signals goes through it)
+    assert ops.FFT_REFLECT
+    spec_p = torch.full((B * Fr, ld), 7.0, device=DEV)
+    ops.FFT_REFLECT = False
+    try:
+        ops.stft_fft(g(x), n_fft, hop, Fr, spec_p, interleaved=inter)
+    finally:
+        ops.FFT_REFLECT = True
+    assert torch.equal(spec_p[:, :2 * nb], spec[:, :2 * nb])
+    xw = torch.zeros(B, T + 5, device=DEV)
+    xw[:, 2:T + 2] = g(x)
+    spec_v = torch.full((B * Fr, ld), 7.0, device=DEV)
+    ops.stft_fft(xw[:, 2:T + 2], n_fft, hop, Fr, spec_v, interleaved=inter)      # rows T + 5 apart
+    assert torch.equal(spec_v[:, :2 * nb], spec[:, :2 * nb])
     # adjoint: d<gs, stft(x)>/dx through frames_fold
     gs = rnd(B * Fr, ld, seed=12)
     gfr = torch.empty(B * Fr, n_fft, device=DEV)
@@ -640,6 +656,23 @@ def test_istft_gemm_ola_fwd_bwd(ops, n_fft, hop, T):
     out = torch.full((B, T), 1.0, device=DEV)
     ops.istft_ola(frames, out, B, Fr, n_fft, hop, T, g(win.float()), g(wb), 1.0 / 3, True)
     close(out, 1.0 + y.detach() * wb.double()[:, None] / 3, name="istft")
+    # f2g_istft_ola_multi: three "branches" (the same frames with other weights / no weights) in one
+    # launch = three launches one after the other, bit for bit
+    wb2 = g(torch.tensor([2.0, -1.0]))
+    seq = torch.full((B, T), 0.25, device=DEV)
+    ops.istft_ola(frames, seq, B, Fr, n_fft, hop, T, g(win.float()), g(wb), 1.0 / 3, True)
+    ops.istft_ola(frames, seq, B, Fr, n_fft, hop, T, g(win.float()), None, 1.0 / 3, True)
+    ops.istft_ola(frames, seq, B, Fr, n_fft, hop, T, g(win.float()), wb2, 1.0 / 3, True)
+    one = torch.full((B, T), 0.25, device=DEV)
+    ent = [(frames, Fr, n_fft, hop, g(win.float()), w_) for w_ in (g(wb), None, wb2)]
+    ops.istft_ola_multi(ent, one, B, T, 1.0 / 3, accumulate=True)
+    assert torch.equal(one, seq)
+    seq2 = torch.full((B, T), float("nan"), device=DEV)
+    ops.istft_ola(frames, seq2, B, Fr, n_fft, hop, T, g(win.float()), g(wb), 1.0 / 3, False)
+    ops.istft_ola(frames, seq2, B, Fr, n_fft, hop, T, g(win.float()), wb2, 1.0 / 3, True)
+    one2 = torch.full((B, T), float("nan"), device=DEV)
+    ops.istft_ola_multi([ent[0], ent[2]], one2, B, T, 1.0 / 3)
+    assert torch.equal(one2, seq2)
     gfr = torch.empty(B * Fr, n_fft, device=DEV)
     ops.istft_ola_bwd(g(gy.float()), gfr, B, Fr, n_fft, hop, T, g(win.float()), g(wb), 1.0 / 3)
     gp = torch.empty(B * Fr, 2 * nb + 2, device=DEV)
