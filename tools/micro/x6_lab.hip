@@ -303,7 +303,10 @@ float run(const __bf16* Ap, const __bf16* Wp, float* C, int M, int N, int K, int
 int main() {
   const int shapes[][3] = {{38016, 1024, 5120}, {38016, 1024, 2560}, {19008, 1024, 5120}, {113920, 512, 640},
                            {6016, 768, 2304}, {24064, 1152, 384}};
+  int shape_i = 0;
+  const int nshapes = getenv("LAB_SHAPES") ? atoi(getenv("LAB_SHAPES")) : 6;
   for (auto& sh : shapes) {
+    if (shape_i++ >= nshapes) break;
     const int M = sh[0], N = sh[1], K = sh[2];
     std::vector<float> ha((size_t)M * K), hw((size_t)N * K);
     unsigned s = 12345;
@@ -323,7 +326,9 @@ int main() {
     std::vector<float> hc((size_t)M * N);
     // float64 reference and the plain fp32 fmaf chain (what the fp32 MFMA computes) on sampled entries
     const int NS = 96;
+    const int only = getenv("LAB_ONLY") ? atoi(getenv("LAB_ONLY")) : -1;
     for (int cfg = 0; cfg < 12; ++cfg) {
+      if (only >= 0 && cfg != only) continue;
       const int np = 2 + (cfg & 1), bk = (cfg & 2) && cfg < 8 ? 16 : 32;
       const int pipe = cfg >= 10 ? 3 : (cfg >= 8 ? 2 : (cfg >= 4 ? 1 : 0));
       float ms = 0;
