@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // loader: a plane of a slab = 128 rows x CPR chunks of 16 bytes = NQ per thread
   constexpr int RSTEP = 256 / CPR;                           // rows covered by one pass of the block
-  const int ch = tid % CPR, r0 = tid / CPR;
+  // (staged row of a thread: quads of lanes read one 64-byte line each; the two quads of an 8-lane
+  // LDS store group take rows 8 apart -- one apart, their 16-byte stores share 12 of 16 banks)
+  const int ch = tid % CPR, q4 = tid / CPR;
+  const int r0 = CPR == 4 ? ((q4 & ~15) | ((q4 & 1) << 3) | ((q4 >> 1) & 7)) : q4;
   const __bf16* ga[NQ];
   const __bf16* gw[NQ];
 #pragma unroll
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
     ga[q] = Ap + (long long)ra * K + ch * 8;
     gw[q] = Wp + (long long)rw * K + ch * 8;
   }
-  u32x4 la[NP][NQ], lw[NP][NQ], ya[NP][NQ], yw[NP][NQ];
+  u32x4 la[NP][NQ], lw[NP][NQ], ya[NP][NQ], yw[NP][NQ], za3[NP][NQ], zw3[NP][NQ];
   auto gload2 = [&](int k0, u32x4 (&xa)[NP][NQ], u32x4 (&xw)[NP][NQ]) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -148,8 +151,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[j][ni], acc[mi][ni], 0, 0, 0);
       }
   };
-  if constexpr (PIPE == 2) {
-    static_assert(BK == 32 || PIPE != 2, "two k-steps per slab");
+  if constexpr (PIPE == 2 || PIPE == 4) {
     bf16x8 f0a[NP][2], f0b[NP][2], f1a[NP][2], f1b[NP][2];
     auto frags = [&](int cur, int ks, bf16x8 (&fa)[NP][2], bf16x8 (&fb)[NP][2]) {
 #pragma unroll
@@ -195,6 +197,12 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
       __builtin_amdgcn_sched_barrier(0);
       mfmas(f0a, f0b);
       lstore2((t + 1) & 1, xa, xw);
+      // issue order: one LDS store behind each of the first MFMAs
+#pragma unroll
+      for (int i = 0; i < NP * NP * 4 - (NP == 3 ? 12 : 4); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 2 * NP * NQ) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
@@ -203,12 +211,47 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
       mfmas(f1a, f1b);
       __builtin_amdgcn_sched_barrier(0);
     };
+    if constexpr (PIPE == 4) {
+      // three register stages: the loads of slab t + 3 are requested in pass t (two passes of cover)
+      auto step3 = [&](int t, u32x4 (&sa)[NP][NQ], u32x4 (&sw)[NP][NQ], u32x4 (&na)[NP][NQ], u32x4 (&nw)[NP][NQ]) {
+        const int cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;
+        frags(cur, 1, f1a, f1b);
+        gload2(t + 3 < nt ? (t + 3) * BK : 0, na, nw);      // into the set slab t occupied
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(f0a, f0b);
+        lstore2((t + 1) & 1, sa, sw);
+#pragma unroll
+        for (int i = 0; i < NP * NP * 4 - (NP == 3 ? 12 : 4); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < 2 * NP * NQ) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        frags(nxt, 0, f0a, f0b);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(f1a, f1b);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // sets: slab s lives in set s % 3 = (la, ya, za3); slab 1 is in la after the prologue above ->
+      // rename: la = slab 1, then load slab 2 into ya
+      gload2(nt > 2 ? 2 * BK : 0, ya, yw);
+      int t = 0;
+      for (; t + 2 < nt; t += 3) {
+        step3(t, la, lw, za3, zw3);          // stores slab t+1 (la), loads t+3 -> za3
+        step3(t + 1, ya, yw, la, lw);        // stores slab t+2 (ya), loads t+4 -> la
+        step3(t + 2, za3, zw3, ya, yw);      // stores slab t+3 (za3), loads t+5 -> ya
+      }
+      if (t < nt) { step3(t, la, lw, za3, zw3); ++t; }
+      if (t < nt) { step3(t, ya, yw, la, lw); ++t; }
+    } else {
     int t = 0;
     for (; t + 1 < nt; t += 2) {
       step(t, la, lw, ya, yw);
       step(t + 1, ya, yw, la, lw);
     }
     if (t < nt) step(t, la, lw, ya, yw);
+    }
     }
   } else if constexpr (PIPE == 1) {
     gload2(0, la, lw);
@@ -327,10 +370,10 @@ int main() {
     // float64 reference and the plain fp32 fmaf chain (what the fp32 MFMA computes) on sampled entries
     const int NS = 96;
     const int only = getenv("LAB_ONLY") ? atoi(getenv("LAB_ONLY")) : -1;
-    for (int cfg = 0; cfg < 12; ++cfg) {
+    for (int cfg = 0; cfg < 14; ++cfg) {
       if (only >= 0 && cfg != only) continue;
       const int np = 2 + (cfg & 1), bk = (cfg & 2) && cfg < 8 ? 16 : 32;
-      const int pipe = cfg >= 10 ? 3 : (cfg >= 8 ? 2 : (cfg >= 4 ? 1 : 0));
+      const int pipe = cfg >= 12 ? 4 : (cfg >= 10 ? 3 : (cfg >= 8 ? 2 : (cfg >= 4 ? 1 : 0)));
       float ms = 0;
       switch (cfg) {
         case 0: ms = run<2, 32>(Ap, Wp, C, M, N, K, iters); break;
@@ -344,7 +387,9 @@ int main() {
         case 8: ms = run<2, 32, 2>(Ap, Wp, C, M, N, K, iters); break;
         case 9: ms = run<3, 32, 2>(Ap, Wp, C, M, N, K, iters); break;
         case 10: ms = run<2, 32, 2>(Ap, Wp, C, M, N, K, iters, 1); break;
-        default: ms = run<3, 32, 2>(Ap, Wp, C, M, N, K, iters, 1); break;
+        case 11: ms = run<3, 32, 2>(Ap, Wp, C, M, N, K, iters, 1); break;
+        case 12: ms = run<2, 32, 4>(Ap, Wp, C, M, N, K, iters); break;
+        default: ms = run<3, 32, 4>(Ap, Wp, C, M, N, K, iters); break;
       }
       hipMemcpy(hc.data(), C, hc.size() * 4, hipMemcpyDeviceToHost);
       double worst = 0, worst32 = 0, scale = 0;
@@ -364,7 +409,7 @@ int main() {
       }
       printf("M=%6d N=%5d K=%5d  slab %2d %s %s: %8.1f us = %6.1f TFLOP/s fp32-equivalent (%d bf16 MFMAs per product: %.2f of the bf16 peak) | "
              "max |err| / sum|a w| over %d entries: %.2e  (fp32 fmaf chain: %.2e)\n",
-             M, N, K, bk, pipe == 3 ? "BARE MFMA stream (results garbage)" : pipe == 2 ? "2-stage + fragment sets" : (pipe ? "2-stage" : "simple "), np == 2 ? "3 products (2 pieces)" : "6 products (3 pieces)", ms * 1e3, flop / ms / 1e9,
+             M, N, K, bk, pipe == 4 ? "3-stage + fragment sets" : pipe == 3 ? "BARE MFMA stream (results garbage)" : pipe == 2 ? "2-stage + fragment sets" : (pipe ? "2-stage" : "simple "), np == 2 ? "3 products (2 pieces)" : "6 products (3 pieces)", ms * 1e3, flop / ms / 1e9,
              np == 2 ? 3 : 6, flop * (np == 2 ? 3 : 6) / ms / 1e9 / 2500.0, NS, worst, worst32);
     }
     hipFree(A); hipFree(W); hipFree(C); hipFree(Ap); hipFree(Wp);
