@@ -215,22 +215,29 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
       // three register stages: the loads of slab t + 3 are requested in pass t (two passes of cover)
       auto step3 = [&](int t, u32x4 (&sa)[NP][NQ], u32x4 (&sw)[NP][NQ], u32x4 (&na)[NP][NQ], u32x4 (&nw)[NP][NQ]) {
         const int cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;
-        frags(cur, 1, f1a, f1b);
         gload2(t + 3 < nt ? (t + 3) * BK : 0, na, nw);      // into the set slab t occupied
         __builtin_amdgcn_sched_barrier(0);
+        frags(cur, 1, f1a, f1b);
         mfmas(f0a, f0b);
         lstore2((t + 1) & 1, sa, sw);
+        // issue order: ONE MFMA first (its fragments are a pass old: the wait in front of it must not
+        // cover the reads below), then the next k-step's fragment reads, then an LDS store behind
+        // each of the following MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);
 #pragma unroll
-        for (int i = 0; i < NP * NP * 4 - (NP == 3 ? 12 : 4); ++i) {
+        for (int i = 1; i < NP * NP * 4 - (NP == 3 ? 12 : 4); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (i < 2 * NP * NQ) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (i <= 2 * NP * NQ) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         frags(nxt, 0, f0a, f0b);
-        __builtin_amdgcn_sched_barrier(0);
         mfmas(f1a, f1b);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NP * NP * 4, 0);
         __builtin_amdgcn_sched_barrier(0);
       };
       // sets: slab s lives in set s % 3 = (la, ya, za3); slab 1 is in la after the prologue above ->
