@@ -8,6 +8,10 @@
 // Operand planes are separate row-major bf16 matrices [piece][rows][K]; a block stages 3 x (128 + 128)
 // rows x 64 bytes per slab (LDS rows 80 bytes apart: conflict-free ds_read_b128), double-buffered.
 // build: hipcc -O3 --offload-arch=gfx950 tools/micro/x6_lab.hip -o tools/micro/x6_lab
+//   -DLAB_IMG: operands as a slab-interleaved image (the three pieces of a row's 32-element slab side by
+//   side, 192 contiguous bytes: whole cache lines per row instead of three half lines); configurations
+//   8 / 9 / 12 / 13 only.  LAB_ONLY=<configuration>, LAB_SHAPES=<n>, LAB_ABL=<bits> (timing ablations of
+//   configurations 8 / 9: 2 no global loads, 4 no LDS stores, 8 no barrier, 16 no fragment reads).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,7 +24,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128;
 
-__global__ void split3_kernel(const float* __restrict__ x, __bf16* __restrict__ p, long long n) {
+__global__ void split3_kernel(const float* __restrict__ x, __bf16* __restrict__ p, long long n, long long K) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const float v = x[i];
@@ -28,9 +32,18 @@ __global__ void split3_kernel(const float* __restrict__ x, __bf16* __restrict__ 
     const float r1 = v - (float)a;
     const __bf16 b = (__bf16)r1;
     const __bf16 c = (__bf16)(r1 - (float)b);
+#ifdef LAB_IMG
+    // slab-interleaved image: the three pieces of a row's 32-element slab lie side by side (192 bytes)
+    const long long r = i / K, k = i - r * K;
+    const long long o = (r * (K / 32) + k / 32) * 96 + (k & 31);
+    p[o] = a;
+    p[o + 32] = b;
+    p[o + 64] = c;
+#else
     p[i] = a;
     p[n + i] = b;
     p[2 * n + i] = c;
+#endif
   }
 }
 
@@ -88,6 +101,34 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
     gw[q] = Wp + (long long)rw * K + ch * 8;
   }
   u32x4 la[NP][NQ], lw[NP][NQ], ya[NP][NQ], yw[NP][NQ], za3[NP][NQ], zw3[NP][NQ];
+#ifdef LAB_IMG
+  // slab-interleaved image (BK = 32): a row's slab = 4 NP chunks of 16 contiguous bytes (the first NP
+  // pieces of its 192); chunk id = tid + 256 j -> (row, chunk); LDS rows hold the same bytes in order
+  constexpr int CPRI = 4 * NP;
+  auto gload2 = [&](int k0, u32x4 (&xa)[NP][NQ], u32x4 (&xw)[NP][NQ]) {
+    const long long so = (long long)(k0 / 32) * 192;
+#pragma unroll
+    for (int j = 0; j < NP * NQ; ++j) {
+      const int id = tid + 256 * j, row = id / CPRI, c = id - row * CPRI;
+      int ra = m0 + row, rw = n0 + row;
+      ra = ra < M ? ra : M - 1;
+      rw = rw < N ? rw : N - 1;
+      const unsigned char* pa8 = reinterpret_cast<const unsigned char*>(Ap) + (long long)ra * (K / 32) * 192 + so + c * 16;
+      const unsigned char* pw8 = reinterpret_cast<const unsigned char*>(Wp) + (long long)rw * (K / 32) * 192 + so + c * 16;
+      xa[j / NQ][j % NQ] = *reinterpret_cast<const u32x4*>(pa8);
+      xw[j / NQ][j % NQ] = *reinterpret_cast<const u32x4*>(pw8);
+    }
+  };
+  auto lstore2 = [&](int buf, const u32x4 (&xa)[NP][NQ], const u32x4 (&xw)[NP][NQ]) {
+#pragma unroll
+    for (int j = 0; j < NP * NQ; ++j) {
+      const int id = tid + 256 * j, row = id / CPRI, c = id - row * CPRI;
+      unsigned char* base = smem + buf * STAGE + row * PITCH + c * 16;
+      *reinterpret_cast<u32x4*>(base) = xa[j / NQ][j % NQ];
+      *reinterpret_cast<u32x4*>(base + OPER) = xw[j / NQ][j % NQ];
+    }
+  };
+#else
   auto gload2 = [&](int k0, u32x4 (&xa)[NP][NQ], u32x4 (&xw)[NP][NQ]) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -107,6 +148,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
         *reinterpret_cast<u32x4*>(base + OPER + p * PSTEP + q * RSTEP * PITCH) = xw[p][q];
       }
   };
+#endif
   auto gload = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -181,7 +223,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
     gload2(nt > 1 ? BK : 0, la, lw);
     __syncthreads();
     frags(0, 0, f0a, f0b);
-    if (bare) {       // (lab: the bare MFMA stream of this schedule -- no LDS, no loads in the loop)
+    if (bare == 1) {  // (lab: the bare MFMA stream of this schedule -- no LDS, no loads in the loop)
       frags(0, 1, f1a, f1b);
       for (int t = 0; t < nt; ++t) {
         mfmas(f0a, f0b);
@@ -192,11 +234,13 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
     } else {
     auto step = [&](int t, u32x4 (&xa)[NP][NQ], u32x4 (&xw)[NP][NQ], u32x4 (&za)[NP][NQ], u32x4 (&zw)[NP][NQ]) {
       const int cur = (t & 1) * STAGE, nxt = ((t + 1) & 1) * STAGE;
-      frags(cur, 1, f1a, f1b);
-      gload2(t + 2 < nt ? (t + 2) * BK : 0, za, zw);
+      // (ablation bits of `bare`, timing only: 2 no global loads, 4 no LDS stores, 8 no barrier,
+      // 16 no fragment reads)
+      if (!(bare & 16)) frags(cur, 1, f1a, f1b);
+      if (!(bare & 2)) gload2(t + 2 < nt ? (t + 2) * BK : 0, za, zw);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(f0a, f0b);
-      lstore2((t + 1) & 1, xa, xw);
+      if (!(bare & 4)) lstore2((t + 1) & 1, xa, xw);
       // issue order: one LDS store behind each of the first MFMAs
 #pragma unroll
       for (int i = 0; i < NP * NP * 4 - (NP == 3 ? 12 : 4); ++i) {
@@ -204,9 +248,9 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
         if (i < 2 * NP * NQ) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
+      if (!(bare & 8)) __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      frags(nxt, 0, f0a, f0b);
+      if (!(bare & 16)) frags(nxt, 0, f0a, f0b);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(f1a, f1b);
       __builtin_amdgcn_sched_barrier(0);
@@ -369,13 +413,14 @@ int main() {
     hipMalloc(&Ap, ha.size() * 6); hipMalloc(&Wp, hw.size() * 6);
     hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, A, Ap, (long long)ha.size());
-    hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, W, Wp, (long long)hw.size());
+    hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, A, Ap, (long long)ha.size(), (long long)K);
+    hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, W, Wp, (long long)hw.size(), (long long)K);
     const double flop = 2.0 * M * N * (double)K;
     const int iters = 10;
     std::vector<float> hc((size_t)M * N);
     // float64 reference and the plain fp32 fmaf chain (what the fp32 MFMA computes) on sampled entries
     const int NS = 96;
+    const int abl = getenv("LAB_ABL") ? atoi(getenv("LAB_ABL")) : 0;
     const int only = getenv("LAB_ONLY") ? atoi(getenv("LAB_ONLY")) : -1;
     for (int cfg = 0; cfg < 14; ++cfg) {
       if (only >= 0 && cfg != only) continue;
@@ -391,8 +436,8 @@ int main() {
         case 5: ms = run<3, 32, 1>(Ap, Wp, C, M, N, K, iters); break;
         case 6: ms = run<2, 16, 1>(Ap, Wp, C, M, N, K, iters); break;
         case 7: ms = run<3, 16, 1>(Ap, Wp, C, M, N, K, iters); break;
-        case 8: ms = run<2, 32, 2>(Ap, Wp, C, M, N, K, iters); break;
-        case 9: ms = run<3, 32, 2>(Ap, Wp, C, M, N, K, iters); break;
+        case 8: ms = run<2, 32, 2>(Ap, Wp, C, M, N, K, iters, abl); break;
+        case 9: ms = run<3, 32, 2>(Ap, Wp, C, M, N, K, iters, abl); break;
         case 10: ms = run<2, 32, 2>(Ap, Wp, C, M, N, K, iters, 1); break;
         case 11: ms = run<3, 32, 2>(Ap, Wp, C, M, N, K, iters, 1); break;
         case 12: ms = run<2, 32, 4>(Ap, Wp, C, M, N, K, iters); break;
