@@ -105,18 +105,24 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
   // slab-interleaved image (BK = 32): a row's slab = 4 NP chunks of 16 contiguous bytes (the first NP
   // pieces of its 192); chunk id = tid + 256 j -> (row, chunk); LDS rows hold the same bytes in order
   constexpr int CPRI = 4 * NP;
+  // buffer loads: the resource in SGPRs, one per-thread CONSTANT byte offset per chunk (decoded once),
+  // the slab advance in a scalar register -- no vector address arithmetic in the loop
+  const unsigned rowbytes = (unsigned)(K / 32) * 192u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (unsigned)M * rowbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (unsigned)N * rowbytes, 0x00020000);
+  unsigned voA[NP * NQ], voW[NP * NQ];
+#pragma unroll
+  for (int j = 0; j < NP * NQ; ++j) {
+    const int id = tid + 256 * j, row = id / CPRI, c = id - row * CPRI;
+    voA[j] = (unsigned)(m0 + row) * rowbytes + c * 16;      // rows past the end: out of range = zeros
+    voW[j] = (unsigned)(n0 + row) * rowbytes + c * 16;
+  }
   auto gload2 = [&](int k0, u32x4 (&xa)[NP][NQ], u32x4 (&xw)[NP][NQ]) {
-    const long long so = (long long)(k0 / 32) * 192;
+    const int so = (k0 / 32) * 192;
 #pragma unroll
     for (int j = 0; j < NP * NQ; ++j) {
-      const int id = tid + 256 * j, row = id / CPRI, c = id - row * CPRI;
-      int ra = m0 + row, rw = n0 + row;
-      ra = ra < M ? ra : M - 1;
-      rw = rw < N ? rw : N - 1;
-      const unsigned char* pa8 = reinterpret_cast<const unsigned char*>(Ap) + (long long)ra * (K / 32) * 192 + so + c * 16;
-      const unsigned char* pw8 = reinterpret_cast<const unsigned char*>(Wp) + (long long)rw * (K / 32) * 192 + so + c * 16;
-      xa[j / NQ][j % NQ] = *reinterpret_cast<const u32x4*>(pa8);
-      xw[j / NQ][j % NQ] = *reinterpret_cast<const u32x4*>(pw8);
+      xa[j / NQ][j % NQ] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], so, 0);
+      xw[j / NQ][j % NQ] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], so, 0);
     }
   };
   auto lstore2 = [&](int buf, const u32x4 (&xa)[NP][NQ], const u32x4 (&xw)[NP][NQ]) {
