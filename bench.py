@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--eager-gpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16", "bf16x6"],
                     help="GEMM arithmetic of the headline number (fp32 = exact, the reference's)")
     ap.add_argument("--no-fast-mode", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
@@ -305,7 +305,9 @@ def main():
                                "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
                                "direct-conv": "conv32 / conv2ch direct kernels",
                                "lean-streamk": "gemm_lean_kernel (stream-K)",
-                               "narrow": "narrow VALU kernels"}[dn],
+                               "x6": "gemm_x6_kernel (fp32 class on the bf16 pipe: three bf16 pieces per "
+                                     "operand, six MFMAs per product)",
+                               "narrow": "narrow VALU kernels"}.get(dn, dn),
                     # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
                     "achieved": round(dfl / dsec / 1e12, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(dfl / dsec / 1e12 / peak, 4),
@@ -364,6 +366,7 @@ def main():
             "host_issue_ms_per_step": host_issue_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (split-bf16 GEMM, fp32 accumulate)",
+                      "bf16x6": "f32 (three-piece bf16 GEMM for the generator's plain GEMMs, fp32 accumulate)",
                       "bf16": "bf16 GEMM operands, fp32 accumulate / activations"}[args.gemm],
             "data": "synthetic (0.1*randn clipped, seeded per rank); seeded random-init weights",
             "config": {"workload": args.model + " " + {

@@ -216,10 +216,11 @@ _SIGS = {
     "f2g_fused_block": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc)],
     "f2g_fused_block_multi": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc), C.c_int32],
     "f2g_istft_ola_multi": [C.POINTER(OlaMultiDesc), _P, _I, _I, _F, _I],
+    "f2g_split_bf16x3": [_P, _P, _L, _I, _I],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
                                  "f2g_gemm_lean_ok", "f2g_fused_mlp_ok",
-                                 "f2g_dwnorm_bwd_workspace",
+                                 "f2g_dwnorm_bwd_workspace", "f2g_split_bf16x3_bytes", "f2g_gemm_x6_ok",
                                  "f2g_dwconv_bwd_workspace", "f2g_sadam_chunk_elems"])
 
 
@@ -243,6 +244,10 @@ def _load():
         fn.restype = C.c_int64
     lib.f2g_gemm_lean_ok.argtypes = [C.POINTER(GemmDesc)]
     lib.f2g_gemm_lean_ok.restype = C.c_int
+    lib.f2g_split_bf16x3_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.f2g_split_bf16x3_bytes.restype = C.c_int64
+    lib.f2g_gemm_x6_ok.argtypes = [C.POINTER(GemmDesc)]
+    lib.f2g_gemm_x6_ok.restype = C.c_int
     lib.f2g_fused_mlp_ok.argtypes = [C.c_int32, C.c_int32]
     lib.f2g_fused_mlp_ok.restype = C.c_int
     lib.f2g_sadam_chunk_elems.argtypes = []

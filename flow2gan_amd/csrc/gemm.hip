@@ -2181,6 +2181,171 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
 // Which kernel family the last f2g_gemm call of this process dispatched to (diagnostics for the
 // benchmark's per-kernel roofline; not thread safe): 0 generic MFMA kernels, 1 lean kernel,
 // 2 lean kernel in stream-K mode, 3 narrow (VALU) kernels.
+// ---- fp32-class GEMM on the bf16 matrix pipe (precision 3; round 3) -------------------------------
+// Every fp32 operand is split into THREE bf16 pieces x = p0 + p1 + p2 (24 mantissa bits) and a product
+// is the six MFMAs with i + j <= 2 (a0b0, a0b1, a1b0, a0b2, a1b1, a2b0; fp32 accumulation, smallest
+// terms first): what is dropped is <= 2^-24 relative -- the error class of fp32 rounding itself
+// (measured 8e-8 ... 1e-7 of sum |a w| where the fp32 fmaf chain has 7e-8 ... 2e-7, tools/micro/x6_lab.hip),
+// not the 2^-16 of the two-piece mode.  The fp32 MFMA needs 8 x 64 cycles for the block of products
+// these six 32-cycle MFMAs cover, so the matrix pipe is 2.7x less busy per FLOP.
+// Operand image (f2g_split_bf16x3): row-major, per 32-element slab of a row its three pieces side by
+// side, [row][K / 32][piece][32] bf16 = 192 contiguous bytes per row and slab (whole cache lines).
+// Kernel: the simplest structure that works -- 128 x 128 x 32 tiles, 4 waves of 64 x 64, single LDS
+// buffer (rows 208 bytes apart: 52 dwords, conflict-free for ds_read_b128), the next slab's operands
+// requested one pass ahead by buffer loads with per-thread constant offsets, the whole slab's fragments
+// in registers, TWO blocks per CU hide each other's store / barrier / read phases:
+//   store slab t -> barrier -> read its 24 fragments -> barrier -> 48 MFMAs.
+// Plain (rows x K) operands only (the generator's 1x1 convolutions and linears); epilogue = the generic
+// kernel's (bias, residual, PReLU with both outputs, PReLU backward with column sums, ...).
+__global__ __launch_bounds__(256) void split3_img_kernel(__bf16* __restrict__ dst, const float* __restrict__ src,
+                                                         long long ld, long long rows, int K) {
+  const long long total = rows * (K / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / (K / 4);
+    const int k4 = (int)(i - r * (K / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + r * ld + k4);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned short p[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 a = (__bf16)x[e];
+      const float r1 = x[e] - (float)a;
+      const __bf16 b = (__bf16)r1;
+      const __bf16 c = (__bf16)(r1 - (float)b);
+      p[0][e] = __builtin_bit_cast(unsigned short, a);
+      p[1][e] = __builtin_bit_cast(unsigned short, b);
+      p[2][e] = __builtin_bit_cast(unsigned short, c);
+    }
+    __bf16* o = dst + (r * (K / 32) + k4 / 32) * 96 + (k4 & 31);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      *reinterpret_cast<uint2*>(o + 32 * q) =
+          make_uint2(p[q][0] | ((unsigned)p[q][1] << 16), p[q][2] | ((unsigned)p[q][3] << 16));
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(128, 128, m0, n0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const unsigned rowbytes = (unsigned)(K / 32) * 192u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, (unsigned)M * rowbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytes, 0x00020000);
+  // chunk id = tid + 256 j -> (row of the tile, 16-byte chunk of the row's 192 bytes); rows past the
+  // end lie outside the resource: zeros
+  unsigned voA[NJ], voW[NJ];
+  int lo[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int id = tid + 256 * j, row = id / 12, c = id - row * 12;
+    voA[j] = (unsigned)(m0 + row) * rowbytes + c * 16;
+    voW[j] = (unsigned)(n0 + row) * rowbytes + c * 16;
+    lo[j] = row * PITCH + c * 16;
+  }
+  u32x4 xa[NJ], xw[NJ];
+  auto gload = [&](int t) {
+    const int so = t * 192;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], so, 0);
+      xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], so, 0);
+    }
+  };
+  const unsigned char* rA = smem6 + (wm * 64 + li) * PITCH + h * 16;
+  const unsigned char* rB = smem6 + OPER + (wn * 64 + li) * PITCH + h * 16;
+  const int nt = K / 32;
+  gload(0);
+  for (int t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      *reinterpret_cast<u32x4*>(smem6 + lo[j]) = xa[j];
+      *reinterpret_cast<u32x4*>(smem6 + OPER + lo[j]) = xw[j];
+    }
+    gload(t + 1 < nt ? t + 1 : 0);       // (past the end: re-read, never used)
+    __syncthreads();
+    bf16x8 fa[2][3][2], fb[2][3][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + i * 32 * PITCH + ks * 32);
+          fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int j = sdeg - i;
+          if (j < 0 || j > 2) continue;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+        }
+  }
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+}
+
+// 1 if a form-0 descriptor over fp32 tensors could run as precision 3 once both operands are handed
+// over as f2g_split_bf16x3 images
+static bool x6_shape_ok(const f2g_gemm_desc& d) {
+  if (d.form != 0 || !host_plain(d.A) || !host_plain(d.B) || d.A.cols != d.B.cols) return false;
+  const long long M = d.A.rows, N = d.B.rows, K = d.A.cols;
+  if (K < 32 || (K % 32) || M < 1 || N < 1) return false;
+  if (M * K * 6 >= 0xfff00000ll || N * K * 6 >= 0xfff00000ll) return false;      // 32-bit buffer offsets
+  if (d.A.alpha || d.A.lrelu_src || d.B.alpha || d.B.lrelu_src) return false;    // (no on-load transforms)
+  if (d.E.c_bf16 || d.E.atomic || d.split_k > 1) return false;
+  return true;
+}
+
+static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
+  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
+  constexpr size_t smem = 2 * 128 * 208;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  dim3 grid((M + 127) / 128, (N + 127) / 128);
+  hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K);
+  g_last_path = 4;
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_gemm_x6_ok(const f2g_gemm_desc* d) { return d && x6_shape_ok(*d) ? 1 : 0; }
+
+extern "C" int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K) { return (int64_t)rows * K * 6; }
+
+extern "C" int f2g_split_bf16x3(void* dst, const float* src, int64_t ld, int32_t rows, int32_t K,
+                                f2g_stream_t stream) {
+  if (!dst || !src || rows < 0 || K < 32 || (K % 32) || ld < K || (ld & 3) || (((uintptr_t)src) & 15) ||
+      (((uintptr_t)dst) & 15))
+    return F2G_EINVAL;
+  if (rows == 0) return F2G_OK;
+  const long long total = (long long)rows * (K / 4);
+  hipLaunchKernelGGL(split3_img_kernel, dim3(f2g_grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<__bf16*>(dst), src, (long long)ld, (long long)rows, K);
+  return f2g_check_launch();
+}
+
 extern "C" int f2g_gemm_last_path(void) { return g_last_path; }
 
 // Would f2g_gemm run this form-0 descriptor on the lean kernel (whatever its precision)?  The host
@@ -2258,6 +2423,14 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   const f2g_gemm_desc& d = *dp;
   hipStream_t st = (hipStream_t)stream;
   int split = d.split_k > 0 ? d.split_k : 1;
+  if (d.precision == 3) {
+    // fp32-class products from three-piece images (both operands f2g_split_bf16x3 images: split = 3)
+    if (d.A.split != 3 || d.B.split != 3 || !x6_shape_ok(d)) {
+      f2g_set_error("f2g_gemm precision 3: form 0 over plain f2g_split_bf16x3 images (split = 3), K % 32 == 0");
+      return F2G_EINVAL;
+    }
+    return launch_x6(d, st);
+  }
   {
     const int nr = f2g_gemm_narrow(d, st);  // <= 4 output columns / gradient rows: VALU kernels
     g_last_path = nr != 0 ? 3 : 0;

@@ -458,11 +458,11 @@ def _mrd_forward_one(x2, win: int, prm: list):
                           seq_stride=Ft * ldp, offset=lo * 2)
             else:
                 A = win2d(x, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2)
-            if l == 0 and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+            if l == 0 and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                 # 2 -> 32 channels over the band of the spectrogram: direct kernel (conv2ch.hip)
                 y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
                 ops.conv2ch_fwd(packed, Ft * ldp, ldp, lo * 2, S, Ft, Win, wp, b, SLOPE, y)
-            elif l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+            elif l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                 # 32 -> 32 channels, (3, 9) taps, stride (1, 2): direct LDS-tiled kernel (conv32.hip)
                 y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
                 ops.conv32_s2_fwd(x, S, Ft, Win, Wout, wp, b, SLOPE, y)
@@ -480,7 +480,7 @@ def _mrd_forward_one(x2, win: int, prm: list):
     wpost, bpost = prm[50], prm[51]
     scores = ops.empty(S * Ft * Wcat, 1, device=dev)
     w9 = ops.derived(wpost, "pack", pack_conv_weight)      # (1, 9*32): [tap][ci]
-    if DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+    if DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
         ops.convpost_fwd(cat, S, Ft, Wcat, w9, bpost, scores)
     else:
         gemm(win2d(cat, S, Ft, Wcat, MRD_CH, Wcat, 3, 3, 1, 1, 1), mat(w9), scores, bias=bpost)
@@ -496,7 +496,7 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
     Cin, kh, kw = w.shape[1], w.shape[2], w.shape[3]
     dev = g_pre.device
     pw = kw // 2
-    if (DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1) and Cin == MRD_CH and Cout == MRD_CH and kw == 9
+    if (DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3) and Cin == MRD_CH and Cout == MRD_CH and kw == 9
             and sw == 2 and x_line is None and x_off == 0):
         # 32 -> 32 channels, (3, 9) taps, stride (1, 2): direct transposed convolution (conv32.hip)
         def build_t(t):
@@ -607,7 +607,7 @@ class MRDLossFn(torch.autograd.Function):
             wpost = prm[50]
             if train_disc:
                 gwp = ops.zeros(1, 9 * C, device=dev)
-                if DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+                if DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                     ops.convpost_wgrad(cat, S, Ft, Wcat, gs, gwp)
                 else:
                     ops.wgrad(gs, 1, 1, win2d(cat, S, Ft, Wcat, C, Wcat, 3, 3, 1, 1, 1), gwp)
@@ -617,7 +617,7 @@ class MRDLossFn(torch.autograd.Function):
                 grads_w[51] = gb
             # gradient of the concatenated layer-4 maps (only the sequences in backward)
             gcat = ops.empty(Sx * Ft * Wcat, C, device=dev)
-            if DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+            if DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                 ops.convpost_dgrad(gs, Sx, Ft, Wcat, ops.derived(wpost, "pack", pack_conv_weight),
                                    gcat, g_off=soff * Ft * Wcat)
             else:
@@ -668,9 +668,9 @@ class MRDLossFn(torch.autograd.Function):
                         else:
                             dY = mat(g, S * Ft * Wout, C)
                         tiles = ((3 * kw * Cin + 255) // 256)
-                        if l == 0 and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+                        if l == 0 and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                             ops.conv2ch_wgrad(packed, Ft * ldp, ldp, lo * 2, S, Ft, Win, g, gwp)
-                        elif l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+                        elif l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                             ops.conv32_s2_wgrad(x_in, g, S, Ft, Win, Wout, gwp)
                         else:
                             gemm(dY, X, gwp, form=2, atomic=True,
@@ -706,7 +706,7 @@ class MRDLossFn(torch.autograd.Function):
                             else:
                                 ops.lrelu_bwd(gx, yb, None, 0.0, SLOPE, 1, nb_, nb_, y_off=mk[1])
                         g = gx
-                    elif not train_disc and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1):
+                    elif not train_disc and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                         def build_c2t(t):
                             out = ops.empty(27, 2, C, device=t.device)   # [tap][ci][co]
                             ops.permute4(out, t, (27, 2, C, 1), (1, 27, 2 * 27, 0))

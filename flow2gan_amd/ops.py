@@ -290,6 +290,12 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.form = form
     d.split_k = split_k
     d.precision = GEMM_PRECISION
+    if GEMM_PRECISION == 3:
+        d.precision = 0       # (what does not qualify below runs on the exact fp32 MFMA)
+        if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS and not atomic \
+                and split_k <= 1 and out.dtype == torch.float32 and L.lib.f2g_gemm_x6_ok(C.byref(d)):
+            d.A, d.B = _x3_operand(A), _x3_operand(Bm)
+            d.precision = 3
     if ((GEMM_PRECISION == 1 and form in (0, 2)) or (GEMM_PRECISION == 2 and form == 0)) and LEAN_SPLIT:
         ok = L.lib.f2g_gemm_lean_ok(C.byref(d))
         if GEMM_PRECISION == 2 and (ok & 2) and (A.split == 2 or BF16_IMAGES):
@@ -402,6 +408,29 @@ def _bf16_operand(o: Operand) -> Operand:
         call("f2g_to_bf16", ptr(img), o.base, extent)
         n.base = ptr(img)
     n.split = 2
+    n._keep = (img,) + tuple(o._keep)
+    return n
+
+
+X6_MIN_ROWS = int(_os.environ.get("F2G_X6_MIN_ROWS", "1024"))
+
+
+def _x3_operand(o: Operand) -> Operand:
+    """Copy of a plain fp32 matrix operand over its three-piece image (f2g_split_bf16x3): cached for
+    weights (and cached re-layouts of weights), written here for activations."""
+    t = o._keep[0]
+    rows, K, ld = o.rows, o.cols, o.seq_stride
+    off = o.base - ptr(t)
+
+    def build(tt):
+        img = torch.empty(rows * K * 3, device=tt.device, dtype=torch.bfloat16)
+        call("f2g_split_bf16x3", ptr(img), ptr(tt) + off, ld, rows, K)
+        return img
+    img = derived(t, ("x3", off, rows, K, ld), build) if _is_const(t) else build(t)
+    n = Operand()
+    C.memmove(C.byref(n), C.byref(o), C.sizeof(Operand))
+    n.base = ptr(img)
+    n.split = 3
     n._keep = (img,) + tuple(o._keep)
     return n
 
@@ -646,7 +675,7 @@ class GemmTimer:
         call("f2g_gemm", C.byref(d))
         e.record()
         self.records.append((s, e, flops))
-        self.paths.append(("generic", "lean", "lean-streamk", "narrow")[L.lib.f2g_gemm_last_path()])
+        self.paths.append(("generic", "lean", "lean-streamk", "narrow", "x6")[L.lib.f2g_gemm_last_path()])
         nn = Bm.rows if form == 0 else Bm.cols
         mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
         self.shapes.append((form, mm, nn, kk))
@@ -688,17 +717,20 @@ GEMM_TIMER = None
 # accumulate).  Selected with F2G_GEMM=fp32|bf16x3 (default fp32) or set_gemm_precision().
 import os as _os
 
-GEMM_PRECISION = {"bf16x3": 1, "split": 1, "1": 1, "bf16": 2, "2": 2}.get(
+GEMM_PRECISION = {"bf16x3": 1, "split": 1, "1": 1, "bf16": 2, "2": 2, "bf16x6": 3, "3": 3}.get(
     _os.environ.get("F2G_GEMM", "fp32").lower(), 0)
 
 
 def set_gemm_precision(name: str) -> None:
     global GEMM_PRECISION
-    if name not in ("fp32", "bf16x3", "bf16"):
-        raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
+    if name not in ("fp32", "bf16x3", "bf16", "bf16x6"):
+        raise ValueError("precision must be 'fp32', 'bf16x3', 'bf16x6' or 'bf16'")
     # "bf16": plain bf16 operands, fp32 accumulate -- inference throughput mode (BASELINE config 2),
     # not a parity mode (waveform error ~1e-3 RMS instead of <= 1e-4)
-    GEMM_PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2}[name]
+    # "bf16x6": fp32-class -- three bf16 pieces per operand, six MFMAs per product (error ~2^-23 per
+    # product, like fp32 rounding itself) for the plain-matrix forward / data-gradient GEMMs (the
+    # generator's 1x1 convolutions and linears); everything else stays on the exact fp32 MFMA
+    GEMM_PRECISION = {"fp32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}[name]
 
 
 # ------------------------------------------------------------------ concurrent launch lanes

@@ -59,7 +59,8 @@ typedef struct {
   int32_t step0, pad0, unit, L0u;
   int64_t seq_stride, line_stride;
   int32_t reflect;
-  /* 1: `base` holds the split-bf16 image written by f2g_split_bf16 (same addressing);
+  /* 3: `base` is a f2g_split_bf16x3 image of the plain (rows, cols) matrix (precision 3 only);
+   * 1: `base` holds the split-bf16 image written by f2g_split_bf16 (same addressing);
    * 2: `base` is a TRUE bf16 tensor (f2g_to_bf16 or a bf16 producer): strides / offsets stay in
    *    elements, the reduction needs whole 64-element slabs (precision 2, lean kernel only) */
   int32_t split;
@@ -135,7 +136,8 @@ typedef struct {
    * hi+lo bf16 and each product is hi*hi + hi*lo + lo*hi with fp32 accumulation (per-product
    * relative error <= ~2^-16, i.e. ~100x tighter than plain bf16), ~3-5x the throughput;
    * 2 = plain bf16 operands (hi part only, one MFMA per product), fp32 accumulation: the
-   * throughput mode of BASELINE config 2 (inference), not a parity mode. */
+   * throughput mode of BASELINE config 2 (inference), not a parity mode;
+   * 3 = three-piece images (f2g_split_bf16x3), six MFMAs per product: fp32-class accuracy. */
   int32_t precision;
   int32_t _pad3;
 } f2g_gemm_desc;
@@ -157,6 +159,18 @@ int f2g_split_bf16(float* dst, const float* src, int64_t n, f2g_stream_t stream)
  * with split = 2 (BASELINE config 2: bf16 activations in HBM).  f2g_gemm_lean_ok returns 3 instead
  * of 1 when a form-0 descriptor can also be served from such tensors. */
 int f2g_to_bf16(void* dst, const float* src, int64_t n, f2g_stream_t stream);
+/* Three-piece image for precision 3 (fp32-class products on the bf16 matrix pipe: every value
+ * x = p0 + p1 + p2 with bf16 pieces, a product = the six MFMAs with i + j <= 2, fp32 accumulation;
+ * error <= ~2^-23 per product, the class of fp32 rounding -- tools/micro/x6_lab.hip).  dst
+ * (f2g_split_bf16x3_bytes(rows, K) = 6 * rows * K bytes) = the (rows, K) row-major fp32 matrix src
+ * (row stride ld floats, K % 32 == 0) laid out [row][K / 32][piece][32] bf16: 192 contiguous bytes per
+ * row and 32-element slab.  f2g_gemm with precision = 3 takes form 0 descriptors whose operands are BOTH
+ * plain matrices given as such images (f2g_operand.split = 3, rows / cols = the logical extents);
+ * f2g_gemm_x6_ok(d) says whether a descriptor over the fp32 tensors would qualify.  All epilogues of the
+ * generic kernel apply (bias, residual, PReLU with both outputs, PReLU backward with column sums, ...). */
+int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K);
+int f2g_split_bf16x3(void* dst, const float* src, int64_t ld, int32_t rows, int32_t K, f2g_stream_t stream);
+int f2g_gemm_x6_ok(const f2g_gemm_desc* d);
 /* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
  * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels. */
 int f2g_gemm_last_path(void);

@@ -94,7 +94,7 @@ def gemm_mode(request):
     from flow2gan_amd import ops
 
     was = ops.GEMM_PRECISION
-    ops.set_gemm_precision({"split": "bf16x3", "1": "bf16x3", "2": "bf16"}.get(request.param, request.param))
+    ops.set_gemm_precision({"split": "bf16x3", "1": "bf16x3", "2": "bf16", "3": "bf16x6"}.get(request.param, request.param))
     try:
         yield request.param
     finally:

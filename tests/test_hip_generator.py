@@ -294,7 +294,9 @@ def test_full_size_batch_64_reproduces_reference_waveform(f2g, golden):
     from flow2gan_amd import ops as _ops
     # rows agree with each other (up to the summation order of split tiles; the opt-in split-bf16
     # GEMM mode amplifies those last-bit differences through its 2^-16 products)
-    assert float((y - y[:1]).abs().max()) < (5e-5 if _ops.GEMM_PRECISION == 1 else 1e-5)
+    # (bf16x6: the same last-bit differences of the atomically accumulated time-MLP GEMMs, seen through
+    # other roundings: measured 1.6e-5)
+    assert float((y - y[:1]).abs().max()) < {1: 5e-5, 3: 3e-5}.get(_ops.GEMM_PRECISION, 1e-5)
 
 
 def test_full_width_stage1_loss_and_grads_vs_oracle_then_batch_64(f2g, monkeypatch):

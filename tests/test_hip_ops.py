@@ -1056,6 +1056,62 @@ def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
     assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(6016, 768, 2304), (1500, 200, 96), (4099, 1152, 384)])
+def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K):
+    """precision 3 (`bf16x6`): three bf16 pieces per operand, six MFMAs per product.  Against float64 its
+    error must be of the class of the exact-fp32 kernel's on the same operands (max over ALL entries of
+    |err| / sum |a w| below 1e-6 and within 3x of the fp32 MFMA's; plain bf16 is at 1e-3), on ragged extents, with bias / residual / PReLU epilogues
+    and as a data gradient (form 1 through the cached transpose)."""
+    gen = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=gen) * (1.0 + 3.0 * torch.rand(M, K, generator=gen))
+    w = torch.randn(N, K, generator=gen) * 0.05
+    bias = torch.randn(N, generator=gen)
+    res = torch.randn(M, N, generator=gen)
+    gam = 0.5 + torch.rand(N, generator=gen)
+    ref = a.double() @ w.double().t()
+    mag = a.abs().double() @ w.abs().double().t()
+    ad, wd = g(a), torch.nn.Parameter(g(w))
+    was = ops.GEMM_PRECISION
+    try:
+        ops.set_gemm_precision("bf16x6")
+        out = torch.full((M, N), float("nan"), device=DEV)
+        timer = ops.GemmTimer()
+        ops.GEMM_TIMER = timer
+        try:
+            ops.gemm(ops.mat(ad), ops.mat(wd), out)
+        finally:
+            ops.GEMM_TIMER = None
+        assert timer.paths[-1] == "x6", timer.paths          # (the six-product kernel did run)
+        err = float(((out.cpu().double() - ref).abs() / mag).max())
+        assert err < 1e-6, err
+        out2 = torch.empty(M, N, device=DEV)
+        ops.gemm(ops.mat(ad), ops.mat(wd), out2, bias=g(bias), res=g(res), gamma=g(gam))
+        want2 = ref + bias.double() + gam.double() * res.double()
+        assert float(((out2.cpu().double() - want2).abs() / (mag + 1)).max()) < 1e-6
+        al = 0.25 + 0.2 * torch.rand(N, generator=gen)
+        pre, act = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        ops.gemm(ops.mat(ad), ops.mat(wd), pre, bias=g(bias), prelu=g(al), prelu_out=act)
+        v = ref + bias.double()
+        assert float(((pre.cpu().double() - v).abs() / (mag + 1)).max()) < 1e-6
+        assert float(((act.cpu().double() - (v.clamp(min=0) + al.double() * v.clamp(max=0))).abs() / (mag + 1)).max()) < 1e-6
+        # data gradient: g (M, N) @ w (N, K) -> (M, K)
+        if N % 32 == 0:
+            gy = torch.randn(M, N, generator=gen)
+            gx = torch.empty(M, K, device=DEV)
+            ops.gemm(ops.mat(g(gy)), ops.mat(wd), gx, form=1)
+            refg = gy.double() @ w.double()
+            magg = gy.abs().double() @ w.abs().double()
+            assert float(((gx.cpu().double() - refg).abs() / magg).max()) < 1e-6
+        # the exact-fp32 result on the same operands, for scale
+        ops.set_gemm_precision("fp32")
+        o32 = torch.empty(M, N, device=DEV)
+        ops.gemm(ops.mat(ad), ops.mat(wd), o32)
+        e32 = float(((o32.cpu().double() - ref).abs() / mag).max())
+        assert err < 3 * e32 + 1e-7, (err, e32)
+    finally:
+        ops.GEMM_PRECISION = was
+
+
 @pytest.mark.parametrize("C,rows,tile", [(768, 64 * 130 + 7, 64), (512, 96 * 128 + 5, 96), (512, 64 * 129, 64),
                                          (384, 128 * 128 + 3, 128), (384, 64 * 130 + 1, 64)])
 def test_fused_mlp_taller_tiles(ops, C, rows, tile):

@@ -379,6 +379,121 @@ __global__ __launch_bounds__(256, BK == 16 ? 2 : 1) void x6_kernel(const __bf16*
     }
 }
 
+#ifdef LAB_IMG
+// x6c: the structure that leans on TWO blocks per CU instead of intra-wave pipelining -- single LDS
+// buffer (rows 208 bytes apart = 52 dwords: conflict-free like every odd multiple of 4), the whole slab's
+// fragments in registers, next slab's operands requested one pass ahead by buffer loads:
+//   store slab t -> barrier -> read its 24 fragments -> barrier -> 48 MFMAs   (53 KB of LDS, <= 256 registers)
+template <int NP>
+__global__ __launch_bounds__(256, 2) void x6c_kernel(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Wp,
+                                                     float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int PITCH = 208, OPER = 128 * PITCH, CPRI = 4 * NP, NJ = 2 * NP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  const int tiles_n = gridDim.y, tiles_m = gridDim.x, nblk = tiles_m * tiles_n;
+  int bid = blockIdx.y * tiles_m + blockIdx.x;
+  {
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const unsigned rowbytes = (unsigned)(K / 32) * 192u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (unsigned)M * rowbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (unsigned)N * rowbytes, 0x00020000);
+  unsigned voA[NJ], voW[NJ];
+  int lo[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int id = tid + 256 * j, row = id / CPRI, c = id - row * CPRI;
+    voA[j] = (unsigned)(m0 + row) * rowbytes + c * 16;
+    voW[j] = (unsigned)(n0 + row) * rowbytes + c * 16;
+    lo[j] = row * PITCH + c * 16;
+  }
+  u32x4 xa[NJ], xw[NJ];
+  auto gload = [&](int t) {
+    const int so = t * 192;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], so, 0);
+      xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], so, 0);
+    }
+  };
+  const unsigned char* rA = smem + (wm * 64 + li) * PITCH + h * 16;
+  const unsigned char* rB = smem + OPER + (wn * 64 + li) * PITCH + h * 16;
+  const int nt = K / 32;
+  gload(0);
+  for (int t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      *reinterpret_cast<u32x4*>(smem + lo[j]) = xa[j];
+      *reinterpret_cast<u32x4*>(smem + OPER + lo[j]) = xw[j];
+    }
+    gload(t + 1 < nt ? t + 1 : 0);
+    __syncthreads();
+    bf16x8 fa[2][NP][2], fb[2][NP][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + i * 32 * PITCH + ks * 32);
+          fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int s = NP - 1; s >= 0; --s)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int j = s - i;
+          if (j < 0 || j >= NP) continue;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+        }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + (wn * 2 + ni) * 32 + li;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + (wm * 2 + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < M && col < N) C[(long long)row * N + col] = acc[mi][ni][e];
+      }
+    }
+}
+
+template <int NP>
+float run_c(const __bf16* Ap, const __bf16* Wp, float* C, int M, int N, int K, int iters) {
+  const size_t smem = 2 * 128 * 208;
+  dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((x6c_kernel<NP>), grid, dim3(256), smem, 0, Ap, Wp, C, M, N, K);
+  hipEventRecord(e0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((x6c_kernel<NP>), grid, dim3(256), smem, 0, Ap, Wp, C, M, N, K);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / iters;
+}
+#endif
+
 template <int NP, int BK, int PIPE = 0>
 float run(const __bf16* Ap, const __bf16* Wp, float* C, int M, int N, int K, int iters, int bare = 0) {
   const size_t smem = 2 * 2 * 128 * (BK == 32 ? 272 : 144);
@@ -428,10 +543,10 @@ int main() {
     const int NS = 96;
     const int abl = getenv("LAB_ABL") ? atoi(getenv("LAB_ABL")) : 0;
     const int only = getenv("LAB_ONLY") ? atoi(getenv("LAB_ONLY")) : -1;
-    for (int cfg = 0; cfg < 14; ++cfg) {
+    for (int cfg = 0; cfg < 16; ++cfg) {
       if (only >= 0 && cfg != only) continue;
       const int np = 2 + (cfg & 1), bk = (cfg & 2) && cfg < 8 ? 16 : 32;
-      const int pipe = cfg >= 12 ? 4 : (cfg >= 10 ? 3 : (cfg >= 8 ? 2 : (cfg >= 4 ? 1 : 0)));
+      const int pipe = cfg >= 14 ? 5 : cfg >= 12 ? 4 : (cfg >= 10 ? 3 : (cfg >= 8 ? 2 : (cfg >= 4 ? 1 : 0)));
       float ms = 0;
       switch (cfg) {
         case 0: ms = run<2, 32>(Ap, Wp, C, M, N, K, iters); break;
@@ -447,7 +562,13 @@ int main() {
         case 10: ms = run<2, 32, 2>(Ap, Wp, C, M, N, K, iters, 1); break;
         case 11: ms = run<3, 32, 2>(Ap, Wp, C, M, N, K, iters, 1); break;
         case 12: ms = run<2, 32, 4>(Ap, Wp, C, M, N, K, iters); break;
-        default: ms = run<3, 32, 4>(Ap, Wp, C, M, N, K, iters); break;
+        case 13: ms = run<3, 32, 4>(Ap, Wp, C, M, N, K, iters); break;
+#ifdef LAB_IMG
+        case 14: ms = run_c<2>(Ap, Wp, C, M, N, K, iters); break;
+        default: ms = run_c<3>(Ap, Wp, C, M, N, K, iters); break;
+#else
+        default: continue;
+#endif
       }
       hipMemcpy(hc.data(), C, hc.size() * 4, hipMemcpyDeviceToHost);
       double worst = 0, worst32 = 0, scale = 0;
@@ -467,7 +588,7 @@ int main() {
       }
       printf("M=%6d N=%5d K=%5d  slab %2d %s %s: %8.1f us = %6.1f TFLOP/s fp32-equivalent (%d bf16 MFMAs per product: %.2f of the bf16 peak) | "
              "max |err| / sum|a w| over %d entries: %.2e  (fp32 fmaf chain: %.2e)\n",
-             M, N, K, bk, pipe == 4 ? "3-stage + fragment sets" : pipe == 3 ? "BARE MFMA stream (results garbage)" : pipe == 2 ? "2-stage + fragment sets" : (pipe ? "2-stage" : "simple "), np == 2 ? "3 products (2 pieces)" : "6 products (3 pieces)", ms * 1e3, flop / ms / 1e9,
+             M, N, K, bk, pipe == 5 ? "two blocks per CU, single LDS buffer" : pipe == 4 ? "3-stage + fragment sets" : pipe == 3 ? "BARE MFMA stream (results garbage)" : pipe == 2 ? "2-stage + fragment sets" : (pipe ? "2-stage" : "simple "), np == 2 ? "3 products (2 pieces)" : "6 products (3 pieces)", ms * 1e3, flop / ms / 1e9,
              np == 2 ? 3 : 6, flop * (np == 2 ? 3 : 6) / ms / 1e9 / 2500.0, NS, worst, worst32);
     }
     hipFree(A); hipFree(W); hipFree(C); hipFree(Ap); hipFree(Wp);
