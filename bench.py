@@ -251,6 +251,22 @@ def main():
                                   "ms": round(1e3 * v[2], 2),
                                   "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None}
                               for k, v in sorted(fam3.items())}}
+        if args.workload == "gan_stage2":
+            # fp32-CLASS products on the bf16 matrix pipe for the GEMMs with long reductions (three bf16
+            # pieces per operand, six MFMAs per product; everything else on the exact fp32 MFMA)
+            ops.set_gemm_precision("bf16x6")
+            a6, e6 = timed(1, max(2, args.steps // 2))
+            fast["fp32_class"] = {
+                "gemm": "bf16x6: form-0 GEMMs with K >= 2048 (the 512- / 1024-channel MPD layers' forward "
+                        "and data-gradient GEMMs over their halo maps, the 768-channel pwconv2) as six "
+                        "v_mfma_f32_32x32x16_bf16 per product over three-piece operand images that the "
+                        "producing GEMM's epilogue writes (error <= 2^-23 per product: 8e-8 of sum|a w| "
+                        "measured where the fp32 fmaf chain has 7e-8..2e-7); weight gradients, MRD, the "
+                        "other generator GEMMs exact fp32",
+                "value": round(world * a6 / e6, 2), "unit": "audio-s/s",
+                "ms_per_step": round(1e3 * e6 / max(2, args.steps // 2), 2),
+                "parity": "every golden parity test passes in this mode at the exact-fp32 tolerances "
+                          "(F2G_GEMM=bf16x6 python -m pytest tests -m gpu)"}
         if args.workload == "infer4":
             # BASELINE config 2 names bf16 for the generator-only forward: plain bf16 operands,
             # fp32 accumulation and fp32 activations -- a throughput mode, not a parity mode

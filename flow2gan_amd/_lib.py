@@ -42,6 +42,7 @@ class Epilogue(C.Structure):
         ("prelu_slope", C.c_void_p), ("prelu_out", C.c_void_p), ("ld_prelu_out", C.c_int64),
         ("mask_src", C.c_void_p), ("fm_ref", C.c_void_p), ("fm_wdev", C.c_void_p),
         ("mask_slope", C.c_float), ("fm_w", C.c_float),
+        ("x3_out", C.c_void_p),
     ]
 
 

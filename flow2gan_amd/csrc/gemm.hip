@@ -2225,7 +2225,17 @@ __global__ __launch_bounds__(256) void split3_img_kernel(__bf16* __restrict__ ds
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, int M, int N, int K) {
+// A rows: plain (row r at r * K * 6 bytes of a dense image) or single-segment windows over the flat image
+// of a contiguous buffer (MPD halo maps: row (s, p) at s * seq6 + p * step6 + off6 bytes, K contiguous --
+// element e of a contiguous buffer lives at (e / 32) * 192 + piece * 64 + (e % 32) * 2 whatever its row
+// length, so a window that starts on a 32-element boundary addresses the image like the tensor)
+struct x6_rows {
+  int P0;
+  unsigned seq6, step6, off6, bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                         const x6_rows R) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
   constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2240,7 +2250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const unsigned rowbytes = (unsigned)(K / 32) * 192u;
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, (unsigned)M * rowbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytes, 0x00020000);
   // chunk id = tid + 256 j -> (row of the tile, 16-byte chunk of the row's 192 bytes); rows past the
   // end lie outside the resource: zeros
@@ -2249,7 +2259,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int id = tid + 256 * j, row = id / 12, c = id - row * 12;
-    voA[j] = (unsigned)(m0 + row) * rowbytes + c * 16;
+    const int r = m0 + row, sq = r / R.P0;
+    voA[j] = r < M ? (unsigned)sq * R.seq6 + (unsigned)(r - sq * R.P0) * R.step6 + R.off6 + c * 16
+                   : 0xf0000000u;                 // (outside the resource: zeros)
     voW[j] = (unsigned)(n0 + row) * rowbytes + c * 16;
     lo[j] = row * PITCH + c * 16;
   }
@@ -2301,17 +2313,70 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
         }
   }
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (d.E.x3_out) {
+    // the tile's three-piece image for the next GEMM: read back what the block has just stored (L2;
+    // the barrier orders the block's own stores before these loads) and write whole 16-byte pieces
+    __syncthreads();
+    const f2g_epilogue& E = d.E;
+    for (int u = tid; u < 128 * 16; u += 256) {
+      const int row = m0 + (u >> 4), col = n0 + (u & 15) * 8;
+      if (row >= M || col >= N) continue;
+      long long off;
+      if (E.P0o > 0) {
+        const int sq = row / E.P0o;
+        off = (long long)sq * E.seq_stride_o + (long long)(row - sq * E.P0o) * E.row_stride_o + E.off_o + col;
+      } else {
+        off = (long long)row * E.ldc + col;
+      }
+      const float4 v0 = *reinterpret_cast<const float4*>(E.C + off);
+      const float4 v1 = *reinterpret_cast<const float4*>(E.C + off + 4);
+      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      unsigned pk[3][4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const __bf16 a = (__bf16)x[e];
+        const float r1 = x[e] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const __bf16 c = (__bf16)(r1 - (float)b);
+        const unsigned sa = __builtin_bit_cast(unsigned short, a), sb = __builtin_bit_cast(unsigned short, b),
+                       sc = __builtin_bit_cast(unsigned short, c);
+        if (e & 1) pk[0][e >> 1] |= sa << 16, pk[1][e >> 1] |= sb << 16, pk[2][e >> 1] |= sc << 16;
+        else pk[0][e >> 1] = sa, pk[1][e >> 1] = sb, pk[2][e >> 1] = sc;
+      }
+      __bf16* q = reinterpret_cast<__bf16*>(E.x3_out) + (off >> 5) * 96 + (off & 31);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        *reinterpret_cast<uint4*>(q + 32 * pc) = make_uint4(pk[pc][0], pk[pc][1], pk[pc][2], pk[pc][3]);
+    }
+  }
 }
 
 // 1 if a form-0 descriptor over fp32 tensors could run as precision 3 once both operands are handed
 // over as f2g_split_bf16x3 images
+// extent in elements of what the A operand's rows may touch, or 0 if precision 3 cannot read it
+static long long x6_a_extent(const f2g_operand& A) {
+  if (host_plain(A)) return (long long)A.rows * A.cols;
+  // single-segment windows that never leave their sequence (halo layouts), everything on slab boundaries
+  if (A.P1 != 1 || A.L1 != 1 || A.P0 < 1 || A.seglen < A.cols || A.reflect || A.pad0 > 0 || A.rows % A.P0)
+    return 0;
+  const long long step = (long long)A.step0 * A.unit, off = -(long long)A.pad0 * A.unit;
+  if ((step % 32) || (off % 32) || (A.seq_stride % 32) || step < 0) return 0;
+  if ((long long)(A.P0 - 1) * step + off + A.cols > A.L0u) return 0;
+  return (long long)(A.rows / A.P0 - 1) * A.seq_stride + A.L0u;
+}
+
 static bool x6_shape_ok(const f2g_gemm_desc& d) {
-  if (d.form != 0 || !host_plain(d.A) || !host_plain(d.B) || d.A.cols != d.B.cols) return false;
-  const long long M = d.A.rows, N = d.B.rows, K = d.A.cols;
-  if (K < 32 || (K % 32) || M < 1 || N < 1) return false;
-  if (M * K * 6 >= 0xfff00000ll || N * K * 6 >= 0xfff00000ll) return false;      // 32-bit buffer offsets
+  if (d.form != 0 || !host_plain(d.B) || d.A.cols != d.B.cols) return false;
+  const long long M = d.A.rows, N = d.B.rows, K = d.A.cols, ext = x6_a_extent(d.A);
+  if (K < 32 || (K % 32) || M < 1 || N < 1 || ext <= 0) return false;
+  if (ext * 6 >= 0xe0000000ll || N * K * 6 >= 0xe0000000ll) return false;        // 32-bit buffer offsets
   if (d.A.alpha || d.A.lrelu_src || d.B.alpha || d.B.lrelu_src) return false;    // (no on-load transforms)
   if (d.E.c_bf16 || d.E.atomic || d.split_k > 1) return false;
+  if (d.E.x3_out) {     // whole 8-element groups of the output on 8-element boundaries of its buffer
+    const f2g_epilogue& E = d.E;
+    if (E.prelu_out || (((uintptr_t)E.x3_out) & 15) || (((uintptr_t)E.C) & 15) || (N % 8)) return false;
+    if (E.P0o > 0 ? ((E.seq_stride_o | E.row_stride_o | E.off_o) & 7) != 0 : (E.ldc & 7) != 0) return false;
+  }
   return true;
 }
 
@@ -2324,8 +2389,16 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
+  x6_rows R;
+  if (host_plain(d.A)) {
+    R.P0 = 1, R.seq6 = (unsigned)K * 6u, R.step6 = 0, R.off6 = 0;
+  } else {
+    R.P0 = d.A.P0, R.seq6 = (unsigned)(d.A.seq_stride * 6);
+    R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 6), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 6);
+  }
+  R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
   dim3 grid((M + 127) / 128, (N + 127) / 128);
-  hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K);
+  hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K, R);
   g_last_path = 4;
   return f2g_check_launch();
 }
@@ -2430,6 +2503,10 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       return F2G_EINVAL;
     }
     return launch_x6(d, st);
+  }
+  if (d.E.x3_out) {
+    f2g_set_error("f2g_gemm: E.x3_out belongs to precision 3");
+    return F2G_EINVAL;
   }
   {
     const int nr = f2g_gemm_narrow(d, st);  // <= 4 output columns / gradient rows: VALU kernels

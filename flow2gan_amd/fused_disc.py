@@ -80,7 +80,7 @@ def mpd_params(mpd) -> list:
 HALO = 2  # zero rows kept on both sides of every sequence of an MPD map (conv padding (2, 0))
 
 
-def _halo_rows(S: int, H: int, Cc: int, dev):
+def _halo_rows(S: int, H: int, Cc: int, dev, x3: bool = False):
     """(S, H + 2*HALO, Cc) channels-last map whose halo rows are zero: the (5,1)/(3,1) convs and
     their data gradients read it as plain strided windows (no bounds tests in the GEMM K loop)."""
     buf = ops.empty(S * (H + 2 * HALO), Cc, device=dev)
@@ -88,6 +88,8 @@ def _halo_rows(S: int, H: int, Cc: int, dev):
         ops.zero_halo(buf, S, H + 2 * HALO, Cc, HALO, HALO)
     else:
         ops.fill_(buf, 0.0)
+    if x3:     # (bf16x6 mode) room for the map's three-piece image, written by its producers' epilogues
+        ops.x3_reserve(buf, (S, H + 2 * HALO, Cc, HALO, HALO))
     return buf
 
 
@@ -118,7 +120,7 @@ def _mpd_forward_one(x2, p: int, prm: list, keep_images: bool = False):
         Cin, Cout, st = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
         Hout = (H + 4 - 5) // st + 1
         wp = ops.derived(w, "pack", pack_conv_weight)
-        y = _halo_rows(S, Hout, Cout, dev)
+        y = _halo_rows(S, Hout, Cout, dev, x3=(0 < l < 4))   # (the next layer's GEMM operand)
         if l == 0 and ops.MPD0_DIRECT and Cout == 32 and st == 3:
             # 1 -> 32 channels, 5 taps: an HBM stream, not a GEMM (mpd0.hip)
             ops.mpd0_fwd(x, S, H, Hout, HALO, w.reshape(Cout, 5), b, SLOPE, y)
@@ -133,9 +135,9 @@ def _mpd_forward_one(x2, p: int, prm: list, keep_images: bool = False):
         if keep_images and l > 0:
             shares[l] = ops.split_sharing(x)
             with shares[l]:
-                gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout))
+                gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout), x3_out=(l < 4))
         else:
-            gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout))
+            gemm(A, mat(wp), y, bias=b, lrelu=SLOPE, rowmap=_halo_map(Hout, Cout), x3_out=(0 < l < 4))
         acts.append(y)
         hs.append(Hout)
         x, H = y, Hout
@@ -168,7 +170,8 @@ def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=Tru
     One forward-form GEMM per stride residue against the cached re-laid weights."""
     Cin, K = w.shape[1], w.shape[2] * w.shape[3]
     dev = g_pre.device
-    gx = _halo_rows(S, Hin, Cin, dev) if out_halo else ops.empty(S * Hin, Cin, device=dev)
+    # (bf16x6 mode: the gradient map's image for the data gradient of the layer below)
+    gx = _halo_rows(S, Hin, Cin, dev, x3=(Cin >= 128)) if out_halo else ops.empty(S * Hin, Cin, device=dev)
     for rho, j0, nt, e0, Lq in _residues(K, stride, pad, Hin):
         if Lq == 0:
             continue
@@ -184,7 +187,7 @@ def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=Tru
             rm = (Lq, Hin * Cin, stride * Cin, rho * Cin)
         # mask / fm / colsum: leaky-ReLU backward of the layer whose output gradient this is (every
         # element of gx is written by exactly one stride residue)
-        gemm(A, mat(wq), gx, rowmap=rm, mask=mask, fm=fm, colsum=colsum)
+        gemm(A, mat(wq), gx, rowmap=rm, mask=mask, fm=fm, colsum=colsum, x3_out=out_halo and Cin >= 128)
     return gx
 
 
@@ -297,7 +300,9 @@ class MPDLossFn(torch.autograd.Function):
                 """Run `producer(mask, fm, colsum)` -> gradient map landing on acts[l_out], with its
                 leaky-ReLU backward fused (FUSE_LRELU & 1) or as a separate pass."""
                 mk, fk, ck = below(l_out)
-                if FUSE_LRELU & 1:
+                # (bf16x6 mode: the six-product kernel runs the generic epilogue anyway, and its image
+                # pass must see the final map)
+                if (FUSE_LRELU & 1) or ops.GEMM_PRECISION == 3:
                     return producer(mk, fk, ck)
                 gm = producer(None, None, None)
                 y = acts[l_out]

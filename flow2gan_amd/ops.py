@@ -243,7 +243,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
          res=None, ldres: Optional[int] = None, gamma=None, aux=None, ldaux: Optional[int] = None,
          alpha_n=None, colsum_alpha=None, colsum=None, lrelu: float = 0.0, scale: float = 0.0,
          accumulate: bool = False, atomic: bool = False, split_k: int = 0, out_offset: int = 0,
-         rowmap=None, prelu=None, prelu_out=None, mask=None, fm=None):
+         rowmap=None, prelu=None, prelu_out=None, mask=None, fm=None, x3_out: bool = False):
     """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None.
     split_k: 0 = let the library decide (forms 0/1: split-K onto a zeroed output when the tile
     grid would leave most of the last wave of CUs idle), 1 = off, > 1 = as given."""
@@ -292,10 +292,22 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.precision = GEMM_PRECISION
     if GEMM_PRECISION == 3:
         d.precision = 0       # (what does not qualify below runs on the exact fp32 MFMA)
-        if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS and not atomic \
-                and split_k <= 1 and out.dtype == torch.float32 and L.lib.f2g_gemm_x6_ok(C.byref(d)):
+        if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS and A.cols >= X6_MIN_K \
+                and not atomic \
+                and split_k <= 1 and out.dtype == torch.float32 and _x3_window_ok(A) \
+                and L.lib.f2g_gemm_x6_ok(C.byref(d)):
             d.A, d.B = _x3_operand(A), _x3_operand(Bm)
             d.precision = 3
+        if x3_out:
+            # the three-piece image of `out` for the next GEMM, written by this one's epilogue (every
+            # writer of the buffer must do so, or the image is dropped: x3_reserve / _x3_operand)
+            buf = getattr(out, "_f2g_x3_buf", None)
+            if d.precision == 3 and buf is not None and not getattr(out, "_f2g_x3_bad", False) \
+                    and out_offset % 32 == 0 and prelu_out is None:
+                d.E.x3_out = ptr(buf) + (out_offset // 32) * 192
+                out._f2g_x3 = buf
+            else:
+                out._f2g_x3_bad = True
     if ((GEMM_PRECISION == 1 and form in (0, 2)) or (GEMM_PRECISION == 2 and form == 0)) and LEAN_SPLIT:
         ok = L.lib.f2g_gemm_lean_ok(C.byref(d))
         if GEMM_PRECISION == 2 and (ok & 2) and (A.split == 2 or BF16_IMAGES):
@@ -413,6 +425,9 @@ def _bf16_operand(o: Operand) -> Operand:
 
 
 X6_MIN_ROWS = int(_os.environ.get("F2G_X6_MIN_ROWS", "1024"))
+# measured in the step (profiles/r03_x6_step.txt): the six-product kernel beats the fp32 lean kernel from
+# reductions of ~2000 on (184 against 131 TFLOP/s at K = 5120, 137 : 121 at 2048) and loses below ~1200
+X6_MIN_K = int(_os.environ.get("F2G_X6_MIN_K", "2048"))
 
 
 def _x3_operand(o: Operand) -> Operand:
@@ -421,18 +436,72 @@ def _x3_operand(o: Operand) -> Operand:
     t = o._keep[0]
     rows, K, ld = o.rows, o.cols, o.seq_stride
     off = o.base - ptr(t)
-
-    def build(tt):
-        img = torch.empty(rows * K * 3, device=tt.device, dtype=torch.bfloat16)
-        call("f2g_split_bf16x3", ptr(img), ptr(tt) + off, ld, rows, K)
-        return img
-    img = derived(t, ("x3", off, rows, K, ld), build) if _is_const(t) else build(t)
+    if o.P0 == 1 and o.P1 == 1:
+        def build(tt):
+            img = torch.empty(rows * K * 3, device=tt.device, dtype=torch.bfloat16)
+            call("f2g_split_bf16x3", ptr(img), ptr(tt) + off, ld, rows, K)
+            return img
+        img = derived(t, ("x3", off, rows, K, ld), build) if _is_const(t) else build(t)
+        shift = 0
+    else:
+        # windows over a contiguous map (halo layouts): the flat image of the whole buffer -- element e
+        # at (e / 32) * 192 bytes whatever the row length -- addressed by the same window geometry
+        img = getattr(t, "_f2g_x3", None)      # left by the producers' epilogues (gemm(x3_out=True))
+        if img is None or getattr(t, "_f2g_x3_bad", False):
+            img = x3_flat_image(t)
+        elif _os.environ.get("F2G_X3_CHECK"):
+            ref = x3_flat_image(t)
+            torch.cuda.synchronize()
+            neq = img.view(torch.int16) != ref.view(torch.int16)
+            if bool(neq.any()):
+                idx = neq.nonzero()[:, 0]
+                e = (idx // 96) * 32 + idx % 32
+                Cc = t.shape[1]
+                print("X3 MISMATCH", tuple(t.shape), int(neq.sum()), "rows", sorted(set((e // Cc).tolist()))[:12],
+                      "P0", o.P0, "seq", o.seq_stride, "cols", sorted(set((e % Cc).tolist()))[:6], flush=True)
+        shift = (off // 4 // 32) * 192
     n = Operand()
     C.memmove(C.byref(n), C.byref(o), C.sizeof(Operand))
-    n.base = ptr(img)
+    n.base = ptr(img) + shift
     n.split = 3
     n._keep = (img,) + tuple(o._keep)
     return n
+
+
+def x3_flat_image(t):
+    """Three-piece bf16 image of a whole contiguous fp32 buffer (numel % 32 == 0)."""
+    n = t.numel()
+    assert t.is_contiguous() and n % 32 == 0 and t.dtype == torch.float32
+    img = torch.empty(n * 3, device=t.device, dtype=torch.bfloat16)
+    call("f2g_split_bf16x3", ptr(img), ptr(t), 32, n // 32, 32)
+    return img
+
+
+def x3_reserve(t, halo=None):
+    """Storage for the three-piece image of the contiguous fp32 buffer `t` that the GEMMs writing `t`
+    fill in their epilogues (gemm(x3_out=True)); halo = (S, Hp, C, top, bottom): those rows of every
+    sequence are zero in `t` and are zeroed in the image too.  No-op outside the bf16x6 mode."""
+    if GEMM_PRECISION != 3 or not X3_PRODUCERS or t.numel() % 32 or not t.is_contiguous():
+        return t
+    img = torch.empty(t.numel() * 3, device=t.device, dtype=torch.bfloat16)
+    if halo is not None:
+        S, Hp, Cc, top, bot = halo
+        if Cc % 32:
+            return t
+        zero_halo(img.view(torch.float32).view(S * Hp, Cc * 3 // 2), S, Hp, Cc * 3 // 2, top, bot)
+    t._f2g_x3_buf = img
+    return t
+
+
+X3_PRODUCERS = _os.environ.get("F2G_X3_PRODUCERS", "1") != "0"
+
+
+def _x3_window_ok(o: Operand) -> bool:
+    if o.P0 == 1 and o.P1 == 1:
+        return True
+    t = o._keep[0]
+    return (t is not None and t.is_contiguous() and t.numel() % 32 == 0 and t.dtype == torch.float32
+            and (o.base - ptr(t)) % 128 == 0 and ptr(t) % 16 == 0)
 
 
 def operand_formats_ok(Cc: int, Hh: int) -> int:

@@ -115,6 +115,12 @@ typedef struct {
   const float* fm_wdev;
   float mask_slope;
   float fm_w;
+  /* precision 3 only: besides C, the value is written into the f2g_split_bf16x3 image of the CONTIGUOUS
+   * buffer C points into -- element e of that buffer (e = the store offset from C) at
+   * x3_out + (e / 32) * 192 + piece * 64 + (e % 32) * 2 bytes -- so the next precision-3 GEMM reads its
+   * operand without an image pass.  C must sit on a 32-element boundary of that buffer; plain /
+   * row-mapped / accumulating stores (no atomics, no prelu_out). */
+  void* x3_out;
 } f2g_epilogue;
 
 /* form: 0 = C[r,n] = sum_k A[r,k] * B[n,k]   (forward; B = weights [n][k])

@@ -1071,9 +1071,10 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K):
     ref = a.double() @ w.double().t()
     mag = a.abs().double() @ w.abs().double().t()
     ad, wd = g(a), torch.nn.Parameter(g(w))
-    was = ops.GEMM_PRECISION
+    was = ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS
     try:
         ops.set_gemm_precision("bf16x6")
+        ops.X6_MIN_K, ops.X6_MIN_ROWS = 32, 1          # (the model's profitability thresholds off)
         out = torch.full((M, N), float("nan"), device=DEV)
         timer = ops.GemmTimer()
         ops.GEMM_TIMER = timer
@@ -1109,7 +1110,72 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K):
         e32 = float(((o32.cpu().double() - ref).abs() / mag).max())
         assert err < 3 * e32 + 1e-7, (err, e32)
     finally:
-        ops.GEMM_PRECISION = was
+        ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS = was
+
+
+@pytest.mark.parametrize("B2,T,p", [(4, 24000, 3), (2, 11025, 11), (6, 6000, 2)])
+def test_fp32_class_gemm_over_halo_windows_and_producer_images(ops, B2, T, p):
+    """precision 3 over the MPD stack's operands: conv windows into the halo maps (rows a stride apart, K
+    contiguous over the taps) read from the flat three-piece image of the map, and that image written by
+    the PRODUCING GEMM (E.x3_out: bias + leaky ReLU forward, leaky-ReLU-backward mask in the data
+    gradients, stride residues interleaving rows).  Every produced image must equal f2g_split_bf16x3 of the
+    stored map bit for bit (zero halo rows included), and maps / gradients must agree with the exact-fp32
+    path to fp32 rounding."""
+    from flow2gan_amd import fused_disc as fd
+    gen = torch.Generator().manual_seed(T + p)
+    x2 = g(0.1 * torch.randn(B2, T, generator=gen))
+    ch = fd.MPD_CH
+    prm = []
+    for l in range(5):
+        prm += [g(torch.randn(ch[l + 1], ch[l], 5, 1, generator=gen) * (2.0 / (5 * ch[l]) ** 0.5)),
+                g(0.01 * torch.randn(ch[l + 1], generator=gen))]
+    prm += [g(0.05 * torch.randn(1, 1024, 3, 1, generator=gen)), g(torch.zeros(1))]
+    was = ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS
+    try:
+        ops.set_gemm_precision("fp32")
+        ref = fd._mpd_forward_one(x2, p, prm)
+        S, hs = ref["S"], ref["hs"]
+        gmaps = {}
+        for l in (4, 3, 2):
+            gm = fd._halo_rows(S, hs[l + 1], ch[l + 1], DEV)
+            gm.view(S, hs[l + 1] + 2 * fd.HALO, ch[l + 1])[:, fd.HALO:fd.HALO + hs[l + 1]] = \
+                g(torch.randn(S, hs[l + 1], ch[l + 1], generator=gen))
+            gmaps[l] = gm
+        ref_gx = {l: fd._conv1d_dgrad(gmaps[l], S, hs[l + 1], ch[l + 1], prm[2 * l], fd.MPD_STRIDE[l], 2, hs[l],
+                                      mask=(ref["acts"][l], 0, fd.SLOPE)) for l in (4, 3, 2)}
+        ops.set_gemm_precision("bf16x6")
+        ops.X6_MIN_K, ops.X6_MIN_ROWS = 32, 1
+        timer = ops.GemmTimer()
+        ops.GEMM_TIMER = timer
+        try:
+            st = fd._mpd_forward_one(x2, p, prm)
+        finally:
+            ops.GEMM_TIMER = None
+        assert timer.paths.count("x6") == 4, timer.paths      # layers 1..4 (layer 0 and conv_post are HBM streams)
+        nimg = 0
+        for l, (y, yr) in enumerate(zip(st["acts"], ref["acts"])):
+            scale = float(yr.abs().max())
+            assert float((y - yr).abs().max()) < 2e-5 * scale, l
+            img = getattr(y, "_f2g_x3", None)
+            assert (img is not None) == (l in (2, 3, 4)), l      # the maps the next GEMM reads
+            if img is not None:
+                assert not getattr(y, "_f2g_x3_bad", False)
+                assert torch.equal(img.view(torch.int16), ops.x3_flat_image(y).view(torch.int16)), l
+                nimg += 1
+        for l in (4, 3, 2):
+            gx = fd._conv1d_dgrad(gmaps[l], S, hs[l + 1], ch[l + 1], prm[2 * l], fd.MPD_STRIDE[l], 2, hs[l],
+                                  mask=(st["acts"][l], 0, fd.SLOPE))
+            # (pixels whose activation changed sign between the two forward passes would differ by the slope)
+            same = (st["acts"][l] > 0) == (ref["acts"][l] > 0)
+            d = ((gx - ref_gx[l]).abs() * same).max()
+            assert float(d) < 2e-5 * float(ref_gx[l].abs().max()), l
+            img = getattr(gx, "_f2g_x3", None)
+            assert img is not None and not getattr(gx, "_f2g_x3_bad", False), l
+            assert torch.equal(img.view(torch.int16), ops.x3_flat_image(gx).view(torch.int16)), l
+            nimg += 1
+        assert nimg == 6
+    finally:
+        ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS = was
 
 
 @pytest.mark.parametrize("C,rows,tile", [(768, 64 * 130 + 7, 64), (512, 96 * 128 + 5, 96), (512, 64 * 129, 64),
