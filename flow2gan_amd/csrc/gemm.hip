@@ -1912,6 +1912,158 @@ void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
 }
 
+// ---- weight gradient with fp32-class products on the bf16 pipe (precision 3, form 2) -----------------
+// The operands of gemm_leanw3_kernel (A plain R x M, B plain or an unbounded 1-D window), read as the
+// fp32 tensors they are: a weight gradient reduces over ROWS, so the row-major three-piece images of
+// the forward kernel are of no use here -- instead every thread splits the 4-float chunks it loads
+// into three bf16 pieces on their way into LDS (5.5 VALU instructions per element next to 48 MFMAs
+// per slab and wave: the other block of the CU runs its MFMAs meanwhile), K-major planes
+// [A p0 | A p1 | A p2 | B p0 | B p1 | B p2] of 32 rows x 128 bf16 with gemm_leanw3_kernel's swizzle, the
+// transposing ds_read_b64_tr_b16 fragments, and the six products with i + j <= 2 (smallest first).
+// One 48 KB LDS buffer, two blocks per CU:  split + store slab t -> request slab t + 1 -> barrier ->
+// read its 24 fragments -> barrier -> 48 MFMAs.
+__device__ __forceinline__ void split3x4(const u32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  // (by value first: __builtin_bit_cast applied to a vector-element expression reads element 0)
+  const unsigned u0 = v.x, u1 = v.y, u2 = v.z, u3 = v.w;
+  const float x[4] = {__uint_as_float(u0), __uint_as_float(u1), __uint_as_float(u2), __uint_as_float(u3)};
+  unsigned short q[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 a = (__bf16)x[e];
+    const float r1 = x[e] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    q[0][e] = __builtin_bit_cast(unsigned short, a);
+    q[1][e] = __builtin_bit_cast(unsigned short, b);
+    q[2][e] = __builtin_bit_cast(unsigned short, c);
+  }
+  p0 = u32x2{q[0][0] | ((unsigned)q[0][1] << 16), q[0][2] | ((unsigned)q[0][3] << 16)};
+  p1 = u32x2{q[1][0] | ((unsigned)q[1][1] << 16), q[1][2] | ((unsigned)q[1][3] << 16)};
+  p2 = u32x2{q[2][0] | ((unsigned)q[2][1] << 16), q[2][2] | ((unsigned)q[2][3] << 16)};
+}
+
+template <bool BWIN>
+__global__ __launch_bounds__(256, 2)
+void gemm_leanw6_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
+  constexpr int PL = 32 * 256;            // bytes of one plane (32 rows x 128 bf16)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(128, 128, m0, n0);
+  const int kbeg = blockIdx.z * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  const int nt = (kend - kbeg + BK - 1) / BK;
+  if (nt <= 0) return;
+  const int rid = tid >> 5, c = tid & 31;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.A.base, 0, (unsigned)((long long)K * d.A.seq_stride * 4), 0x00020000);
+  const long long b_bytes = BWIN ? (long long)(d.B.rows / d.B.P0) * d.B.seq_stride * 4
+                                 : (long long)K * d.B.seq_stride * 4;
+  __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)b_bytes, 0x00020000);
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    offA[q] = (unsigned)(((long long)(rid + 8 * q) * d.A.seq_stride + m0 + 4 * c) * 4);
+    offB[q] = (unsigned)(((long long)(rid + 8 * q) * d.B.seq_stride + n0 + 4 * c) * 4);
+  }
+  const int stepA = (int)(BK * d.A.seq_stride * 4), stepB = (int)(BK * d.B.seq_stride * 4);
+  const unsigned mgP0 = BWIN ? magic_of(d.B.P0) : 0u;
+  const int colB = (n0 + 4 * c) * 4;
+  int wofs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = rid + 8 * q;
+    wofs[q] = r * 256 + ((((c >> 3) ^ (r & 3))) << 6) + (c & 7) * 8;
+  }
+  const int g = lane >> 4, i16 = lane & 15;
+  const int rrow = (g >> 1) * 8 + (i16 >> 2), sw = i16 >> 2, within = (g & 1) * 32 + (i16 & 3) * 8;
+  int rofA[2], rofB[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    rofA[t] = rrow * 256 + ((((wm * 2 + t) ^ sw)) << 6) + within;
+    rofB[t] = rrow * 256 + ((((wn * 2 + t) ^ sw)) << 6) + within;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  int ka = (int)((long long)kbeg * d.A.seq_stride * 4), kb = (int)((long long)kbeg * d.B.seq_stride * 4);
+  const int ka0 = ka, kb0 = kb;
+  int srow = kbeg;   // first row of the slab being loaded (window operands)
+  u32x4 xa[4], xb[4];
+  auto gload = [&](bool valid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // rows past K pair with nothing: zeros (the resource ends at K rows for A; B is tested)
+      const int r = (valid ? srow : kbeg) + rid + 8 * q;
+      xa[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, r < K ? offA[q] : 0x80000000u, valid ? ka : ka0, 0);
+      if constexpr (BWIN) {
+        const int sq = fast_div(r, d.B.P0, mgP0), pp = r - sq * d.B.P0;
+        const long long off = ((long long)sq * d.B.seq_stride + (long long)(pp * d.B.step0 - d.B.pad0) * d.B.unit) * 4 + colB;
+        const unsigned vo = (r < K && off >= 0 && off < b_bytes) ? (unsigned)off : 0x80000000u;
+        xb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, vo, 0, 0);
+      } else {
+        xb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, r < K ? offB[q] : 0x80000000u, valid ? kb : kb0, 0);
+      }
+    }
+  };
+  for (int t = 0; t < nt; ++t) {
+    if (t == 0) gload(true);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x2 p0, p1, p2;
+      unsigned char* pa = sm + wofs[q];
+      split3x4(xa[q], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(pa) = p0;
+      *reinterpret_cast<u32x2*>(pa + PL) = p1;
+      *reinterpret_cast<u32x2*>(pa + 2 * PL) = p2;
+      split3x4(xb[q], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(pa + 3 * PL) = p0;
+      *reinterpret_cast<u32x2*>(pa + 4 * PL) = p1;
+      *reinterpret_cast<u32x2*>(pa + 5 * PL) = p2;
+    }
+    ka += stepA;
+    kb += stepB;
+    srow += BK;
+    gload(t + 1 < nt);           // (past the end: the first slab again, never used)
+    __syncthreads();
+    bf16x8 fa[2][3][2], fb[2][3][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          fa[ks][pc][tt] = tr_frag(sm + ks * 16 * 256 + pc * PL + rofA[tt]);
+          fb[ks][pc][tt] = tr_frag(sm + ks * 16 * 256 + (3 + pc) * PL + rofB[tt]);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int j = sdeg - i;
+          if (j < 0 || j > 2) continue;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+        }
+  }
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
+}
+
 // ---- lean weight-gradient kernel, exact fp32 ---------------------------------------------------
 // Same operands as gemm_leanw3_kernel (A plain R x M, B plain or an unbounded 1-D window), fp32 MFMA.
 // v_mfma_f32_32x32x2_f32 takes ONE k per lane half, so K-major tiles are its natural layout: the
@@ -2150,6 +2302,27 @@ int launch_leanw3(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
     hipLaunchKernelGGL(gemm_leanw3_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
   else
     hipLaunchKernelGGL(gemm_leanw3_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  return f2g_check_launch();
+}
+
+int launch_leanw6(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+  constexpr size_t smem = 6 * 32 * 256;
+  int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
+  const int zs = (K + kchunk - 1) / kchunk;
+  dim3 grid(M / 128, N / 128, zs);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw6_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw6_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  g_last_path = 4;
+  if (host_plain(d.B))
+    hipLaunchKernelGGL(gemm_leanw6_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
+  else
+    hipLaunchKernelGGL(gemm_leanw6_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, kchunk);
   return f2g_check_launch();
 }
 
@@ -2496,6 +2669,15 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   const f2g_gemm_desc& d = *dp;
   hipStream_t st = (hipStream_t)stream;
   int split = d.split_k > 0 ? d.split_k : 1;
+  if (d.precision == 3 && d.form == 2) {
+    // fp32-class weight gradient: fp32 operands, split into three pieces inside the kernel
+    if (d.A.split || d.B.split || d.A.rows != d.B.rows || !leanw_ok(d) || d.E.x3_out ||
+        (split > 1 && !d.E.atomic)) {
+      f2g_set_error("f2g_gemm precision 3, form 2: fp32 operands the K-major weight-gradient kernel reads");
+      return F2G_EINVAL;
+    }
+    return launch_leanw6(d, d.A.cols, d.B.cols, d.A.rows, split, st);
+  }
   if (d.precision == 3) {
     // fp32-class products from three-piece images (both operands f2g_split_bf16x3 images: split = 3)
     if (d.A.split != 3 || d.B.split != 3 || !x6_shape_ok(d)) {

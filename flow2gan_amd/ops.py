@@ -298,6 +298,9 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
                 and L.lib.f2g_gemm_x6_ok(C.byref(d)):
             d.A, d.B = _x3_operand(A), _x3_operand(Bm)
             d.precision = 3
+        if form == 2 and X6_WGRAD and atomic and A.split == 0 and Bm.split == 0 and A.lrelu_src is None \
+                and A.rows >= X6_MIN_K and (Bm.P0 == 1 or Bm.P0 >= 32) and L.lib.f2g_gemm_lean_ok(C.byref(d)):
+            d.precision = 3       # weight gradient: gemm_leanw6_kernel splits the fp32 operands itself
         if x3_out:
             # the three-piece image of `out` for the next GEMM, written by this one's epilogue (every
             # writer of the buffer must do so, or the image is dropped: x3_reserve / _x3_operand)
@@ -494,6 +497,7 @@ def x3_reserve(t, halo=None):
 
 
 X3_PRODUCERS = _os.environ.get("F2G_X3_PRODUCERS", "1") != "0"
+X6_WGRAD = _os.environ.get("F2G_X6_WGRAD", "1") != "0"
 
 
 def _x3_window_ok(o: Operand) -> bool:

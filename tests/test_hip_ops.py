@@ -124,16 +124,19 @@ def _lean_wgrad_expected(mode):
     # split-bf16: always the K-major kernel; exact fp32: only long reductions per block by default
     # (F2G_LEAN_WGRAD=2 forces it -- the kernel tests below run under that setting as well)
     import os
+    if mode == "bf16x6":      # gemm_leanw6_kernel (reported as the six-product family)
+        return 4
     return 1 if (mode == "bf16x3" or os.environ.get("F2G_LEAN_WGRAD", "1") == "2") else 0
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("R,M,N", [(3000, 128, 256), (777, 384, 128), (64, 256, 1152), (24064, 128, 128)])
-def test_wgrad_k_major_lean_kernels(ops, R, M, N, mode):
+def test_wgrad_k_major_lean_kernels(ops, R, M, N, mode, monkeypatch):
     """Weight gradient on the K-major lean kernels (exact fp32: single-float fragments; split-bf16:
     operands transposed by the LDS transpose read): g[m, n] += sum_r dY[r, m] X[r, n], atomic
     split-K onto an initialised output, partial last slab."""
     dY, X, g0 = rnd(R, M, seed=1), rnd(R, N, seed=2), rnd(M, N, seed=3)
+    monkeypatch.setattr(ops, "X6_MIN_K", 32)      # (bf16x6: the profitability threshold off)
     was = ops.GEMM_PRECISION
     ops.set_gemm_precision(mode)
     try:
@@ -142,7 +145,11 @@ def test_wgrad_k_major_lean_kernels(ops, R, M, N, mode):
         assert ops.L.lib.f2g_gemm_last_path() == _lean_wgrad_expected(mode), "unexpected wgrad kernel family"
     finally:
         ops.GEMM_PRECISION = was
-    close(out, g0.double() + dY.double().t() @ X.double(), rtol=5e-5, name="leanw")
+    want = g0.double() + dY.double().t() @ X.double()
+    close(out, want, rtol=5e-5, name="leanw")
+    if mode == "bf16x6":     # three pieces, six products: the error class of fp32 rounding
+        mag = dY.abs().double().t() @ X.abs().double() + g0.abs().double()
+        assert float(((out.cpu().double() - want).abs() / mag).max()) < 1e-6
 
 
 @pytest.mark.parametrize("windowed", [False, True])
@@ -174,9 +181,9 @@ def test_wgrad_fp32_k_major_kernel_on_long_reductions(ops, windowed):
         close(out, g0.double() + dY.double().t() @ X.double(), rtol=2e-5, name="leanw fp32")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16x6"])
 @pytest.mark.parametrize("S,Hin,stv", [(5, 50, 3), (7, 131, 1), (3, 400, 3)])
-def test_wgrad_unbounded_windows(ops, mode, S, Hin, stv):
+def test_wgrad_unbounded_windows(ops, mode, S, Hin, stv, monkeypatch):
     """MPD-style weight gradient: X = (5,1)-tap windows over a halo layout, read past the sequence
     ends where the gradient map's halo rows are zero (f2g_operand.unbounded); slabs that straddle
     sequence ends, the first rows before the buffer, the last ones behind it."""
@@ -187,6 +194,7 @@ def test_wgrad_unbounded_windows(ops, mode, S, Hin, stv):
     x[:, HALO:HALO + Hin] = rnd(S, Hin, Cin, seed=1)
     gy = torch.zeros(S, Hp, Cout)
     gy[:, HALO:HALO + Hout] = rnd(S, Hout, Cout, seed=2)
+    monkeypatch.setattr(ops, "X6_MIN_K", 32)
     was = ops.GEMM_PRECISION
     ops.set_gemm_precision(mode)
     try:
@@ -195,7 +203,7 @@ def test_wgrad_unbounded_windows(ops, mode, S, Hin, stv):
         assert X.unbounded == 1
         ops.wgrad(g(gy).reshape(S * Hp, Cout), Cout, Cout, X, out)
         # (sequences shorter than a slab stay on the generic kernel)
-        assert ops.L.lib.f2g_gemm_last_path() == (_lean_wgrad_expected(mode) if (Hp >= 32 or mode != "fp32") else 0)
+        assert ops.L.lib.f2g_gemm_last_path() == (_lean_wgrad_expected(mode) if (Hp >= 32 or mode == "bf16x3") else 0)
     finally:
         ops.GEMM_PRECISION = was
     # conv1d(k=5, stride, pad=2) over the un-haloed input: output row o reads input rows o*stv-2 .. +2
