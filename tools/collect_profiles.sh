@@ -25,6 +25,18 @@ SPECS="0_16 1_16 2_16 4_16 8_16 15_16 0_8 0_24" bash tools/micro/fusedmlp_lab.sh
 ( python tools/fused_multi_bench.py 2>&1 | grep -v amdgpu.ids
   for rt in 1 2 3 4; do echo "## F2G_MLP_RT=$rt (rows per tile = 32 x $rt where the shape has the instance)"; F2G_MLP_RT=$rt python3 tools/fused_multi_bench.py 2>&1 | grep "alone"; done ) > $O/fused_multi.txt
 bash tools/pmc_multi.sh > $O/pmc_multi.txt 2>&1
+# round 3: fp32-class products on the bf16 pipe (bf16x6): per-shape tables in the step, every eligible GEMM
+# (thresholds off) and the default rule; the laned step with and without the weight-gradient kernel /
+# the producer-written images; a kernel trace of the mode
+F2G_X6_MIN_K=32 F2G_GEMM_REPORT=60 python bench.py --gemm bf16x6 --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode 2> $O/x6_shapes_all.txt > /dev/null
+F2G_GEMM_REPORT=60 python bench.py --gemm bf16x6 --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode 2> $O/x6_shapes.txt > $O/x6_bench_roofline.json
+( for env in "" "F2G_X6_WGRAD=0" "F2G_X6_WGRAD=0 F2G_X3_PRODUCERS=0" "F2G_X6_MIN_K=32"; do
+    echo "# $env python bench.py --gemm bf16x6 --steps 8 --warmup 3 --no-cpu-baseline --no-fast-mode --no-roofline"
+    env $env python bench.py --gemm bf16x6 --steps 8 --warmup 3 --no-cpu-baseline --no-fast-mode --no-roofline 2>/dev/null | tail -1 | cut -c1-260
+  done
+  echo "# python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-fast-mode --no-roofline   (exact fp32, same box)"
+  python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-fast-mode --no-roofline 2>/dev/null | tail -1 | cut -c1-260 ) > $O/x6_step_variants.txt
+python tools/x6_gemm_bench.py > $O/x6_gemm_bench.txt 2>/dev/null
 python tools/conv32_probe.py > $O/conv32_probe.txt 2>/dev/null
 F2G_CONV32_V2=0 python tools/conv32_probe.py 2>/dev/null | grep "all 45" > $O/conv32_probe_round2_kernels.txt
 SWEEP=2,4,8,16 python tools/wgrad_probe.py > $O/wgrad_probe.txt 2>/dev/null
@@ -44,6 +56,7 @@ F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_se
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lanes -o p -- $B > /dev/null 2>&1
 F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b3 -o p -- $B --gemm bf16x3 > /dev/null 2>&1
 F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -o p -- python3 $R/bench.py --workload infer4 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode --gemm bf16 > /dev/null 2>&1
+F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_x6 -o p -- $B --gemm bf16x6 > /dev/null 2>&1
 B1="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode"
 for set in FETCH_SIZE WRITE_SIZE; do
   F2G_STREAMS=0 timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcb_$set -o p -- $B1 > /dev/null 2>&1

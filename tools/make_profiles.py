@@ -35,6 +35,27 @@ stats(f"{G}/prof_lanes/p_kernel_stats.csv", f"{P}/{R}_gan_stage2_kernel_stats_la
 stats(f"{G}/prof_b3/p_kernel_stats.csv", f"{P}/{R}_fast_mode_kernel_stats.txt",
       f"# F2G_STREAMS=0 rocprofv3 --kernel-trace --stats -- {CMD} --gemm bf16x3\n"
       "# the same step in the split-bf16 fast mode (pre-split operand images; lean / K-major weight-gradient / direct-conv kernels), launch lanes OFF")
+if os.path.exists(f"{G}/prof_x6/p_kernel_stats.csv"):
+    stats(f"{G}/prof_x6/p_kernel_stats.csv", f"{P}/{R}_x6_mode_kernel_stats.txt",
+          f"# F2G_STREAMS=0 rocprofv3 --kernel-trace --stats -- {CMD} --gemm bf16x6\n"
+          "# the same step with fp32-class products on the bf16 pipe for the long-reduction GEMMs (gemm_x6_kernel: forward / data gradient over three-piece images; "
+          "gemm_leanw6_kernel: weight gradients, operands split in the kernel), launch lanes OFF")
+if os.path.exists(f"{G}/x6_shapes.txt"):
+    def table(path, n):
+        t = [l for l in open(path).read().split("\n") if "amdgpu.ids" not in l]
+        i = next(k for k, l in enumerate(t) if l.startswith("form"))
+        return "\n".join(t[i:i + n + 1])
+    fam = json.loads(open(f"{G}/x6_bench_roofline.json").read().strip().split("\n")[-1])["roofline"]["mfma_class"]
+    open(f"{P}/{R}_x6_step.txt", "w").write(
+        "# bf16x6 mode (fp32-class products on the bf16 matrix pipe: three bf16 pieces per operand, six MFMAs per product) in the GAN stage-2 step (B = 64)\n"
+        "# per-shape HIP-event timing of every f2g_gemm launch of one step, launch lanes off (F2G_GEMM_REPORT=60 python bench.py --gemm bf16x6 --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode);\n"
+        "# form 0 = forward / data gradient (gemm_x6_kernel where it applies), 2 = weight gradient (gemm_leanw6_kernel); TFLOP/s = 2*M*N*K / time, fp32-equivalent\n"
+        "# the exact-fp32 numbers of the same shapes: profiles/" + R + "_gemm_shapes_fp32.txt\n\n"
+        "## default rule (form 0: K >= 2048 and >= 1024 rows; form 2: >= 2048 rows): MFMA class by family " + json.dumps(fam["by_family"]) + "\n"
+        + table(f"{G}/x6_shapes.txt", 48) + "\n\n## F2G_X6_MIN_K=32: every eligible GEMM on the six-product kernels (how the rule was found)\n"
+        + table(f"{G}/x6_shapes_all.txt", 48) + "\n\n## the laned step (ms_per_step), variants\n" + open(f"{G}/x6_step_variants.txt").read()
+        + "\n## tools/x6_gemm_bench.py: the generator's plain GEMMs alone on the chip (image pass of the activation included)\n"
+        + "\n".join(l for l in open(f"{G}/x6_gemm_bench.txt").read().split("\n") if "amdgpu.ids" not in l))
 if os.path.exists(f"{G}/prof_infer/p_kernel_stats.csv"):
     rows = list(csv.DictReader(open(f"{G}/prof_infer/p_kernel_stats.csv")))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flow2gan_amd import ops
 dev = "cuda"
+ops.X6_MIN_K, ops.X6_MIN_ROWS = 32, 1     # (the model's profitability thresholds off: every shape on the kernel)
 def timeit(fn, n=20):
     for _ in range(3): fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
