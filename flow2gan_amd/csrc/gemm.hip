@@ -2137,8 +2137,10 @@ void gemm_leanw_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = rid + 8 * q;
-        long long off = sob + (long long)offB[q] + (pp + r >= d.B.P0 ? wrapjump : 0);
-        if (pp + r >= 2 * d.B.P0) off = -1;   // (P0 >= 32 is required: at most one wrap; defensive)
+        // (P0 >= 16 is required: a slab's 32 rows cross at most two sequence ends)
+        const int wraps = (pp + r >= d.B.P0 ? 1 : 0) + (pp + r >= 2 * d.B.P0 ? 1 : 0);
+        long long off = sob + (long long)offB[q] + (long long)wraps * wrapjump;
+        if (pp + r >= 3 * d.B.P0) off = -1;   // (defensive)
         const unsigned vo = (off >= 0 && off < b_bytes) ? (unsigned)off : 0x80000000u;
         lb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, vo, 0, 0);
       }
@@ -2152,7 +2154,7 @@ void gemm_leanw_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) {
     if (BWIN) {
       p0 += BK;
       kb += BK * rowB;
-      if (p0 >= d.B.P0) {
+      while (p0 >= d.B.P0) {      // (twice for sequences shorter than a slab)
         p0 -= d.B.P0;
         kb += wrapjump;
       }
@@ -2772,9 +2774,9 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       // hide the short K loops better: 92 vs 83).  F2G_LEAN_WGRAD: 0 off, 1 auto (default), 2 always.
       static const int leanw_mode = (getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) ? 0
                                     : (getenv("F2G_LEAN_WGRAD") ? atoi(getenv("F2G_LEAN_WGRAD")) : 1);
-      // (its scalar row walk assumes that a slab crosses at most one sequence end)
+      // (its scalar row walk assumes that a slab crosses at most two sequence ends)
       if (leanw_mode > 0 && d.precision == 0 && d.E.atomic && leanw_ok(d) &&
-          (host_plain(d.B) || d.B.P0 >= 32) && (leanw_mode > 1 || K / split >= 4096))
+          (host_plain(d.B) || d.B.P0 >= 16) && (leanw_mode > 1 || K / split >= 4096))
         return launch_leanw(d, M, N, K, split, st);
     }
     int am = op_mode(d.A, false), bm = op_mode(d.B, false);

@@ -299,7 +299,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
             d.A, d.B = _x3_operand(A), _x3_operand(Bm)
             d.precision = 3
         if form == 2 and X6_WGRAD and atomic and A.split == 0 and Bm.split == 0 and A.lrelu_src is None \
-                and A.rows >= X6_MIN_K and (Bm.P0 == 1 or Bm.P0 >= 32) and L.lib.f2g_gemm_lean_ok(C.byref(d)):
+                and A.rows >= X6_MIN_K and L.lib.f2g_gemm_lean_ok(C.byref(d)):
             d.precision = 3       # weight gradient: gemm_leanw6_kernel splits the fp32 operands itself
         if x3_out:
             # the three-piece image of `out` for the next GEMM, written by this one's epilogue (every
