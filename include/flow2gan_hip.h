@@ -59,7 +59,11 @@ typedef struct {
   int32_t step0, pad0, unit, L0u;
   int64_t seq_stride, line_stride;
   int32_t reflect;
-  /* 3: `base` is a f2g_split_bf16x3 image of the plain (rows, cols) matrix (precision 3 only);
+  /* 3: `base` is a f2g_split_bf16x3 image (precision 3, form 0 only): of the plain (rows, cols) matrix, or
+   *    -- for single-segment windows that never leave their sequences (halo maps) -- the flat image of the
+   *    contiguous buffer the windows address, `base` moved to the image of the same element (element e of
+   *    a contiguous buffer sits at (e / 32) * 192 + piece * 64 + (e % 32) * 2 bytes of its image; every
+   *    stride / offset of the descriptor stays in elements and must be a multiple of 32);
    * 1: `base` holds the split-bf16 image written by f2g_split_bf16 (same addressing);
    * 2: `base` is a TRUE bf16 tensor (f2g_to_bf16 or a bf16 producer): strides / offsets stay in
    *    elements, the reduction needs whole 64-element slabs (precision 2, lean kernel only) */
@@ -143,7 +147,10 @@ typedef struct {
    * relative error <= ~2^-16, i.e. ~100x tighter than plain bf16), ~3-5x the throughput;
    * 2 = plain bf16 operands (hi part only, one MFMA per product), fp32 accumulation: the
    * throughput mode of BASELINE config 2 (inference), not a parity mode;
-   * 3 = three-piece images (f2g_split_bf16x3), six MFMAs per product: fp32-class accuracy. */
+   * 3 = fp32-CLASS products on the bf16 pipe: three bf16 pieces per operand, six MFMAs per product.
+   *     form 0: both operands as three-piece images (f2g_split_bf16x3 / E.x3_out of the producing
+   *     GEMM; f2g_gemm_x6_ok); form 2: the fp32 operands themselves -- whatever f2g_gemm_lean_ok accepts
+   *     for form 2, with E.atomic when split_k > 1 -- split into pieces inside the kernel. */
   int32_t precision;
   int32_t _pad3;
 } f2g_gemm_desc;
@@ -171,14 +178,16 @@ int f2g_to_bf16(void* dst, const float* src, int64_t n, f2g_stream_t stream);
  * (f2g_split_bf16x3_bytes(rows, K) = 6 * rows * K bytes) = the (rows, K) row-major fp32 matrix src
  * (row stride ld floats, K % 32 == 0) laid out [row][K / 32][piece][32] bf16: 192 contiguous bytes per
  * row and 32-element slab.  f2g_gemm with precision = 3 takes form 0 descriptors whose operands are BOTH
- * plain matrices given as such images (f2g_operand.split = 3, rows / cols = the logical extents);
+ * given as such images (f2g_operand.split = 3, rows / cols = the logical extents; B a plain matrix, A a
+ * plain matrix or halo-map windows, see f2g_operand.split);
  * f2g_gemm_x6_ok(d) says whether a descriptor over the fp32 tensors would qualify.  All epilogues of the
  * generic kernel apply (bias, residual, PReLU with both outputs, PReLU backward with column sums, ...). */
 int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K);
 int f2g_split_bf16x3(void* dst, const float* src, int64_t ld, int32_t rows, int32_t K, f2g_stream_t stream);
 int f2g_gemm_x6_ok(const f2g_gemm_desc* d);
 /* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
- * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels. */
+ * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels,
+ * 4 the precision-3 kernels. */
 int f2g_gemm_last_path(void);
 
 /* ------------------------------------------------------------------------------------------
