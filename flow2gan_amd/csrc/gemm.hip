@@ -2526,6 +2526,97 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
   }
 }
 
+// The same tile and schedule over the fp32 operands themselves (f2g_operand.split = 0): every thread
+// splits the 4-float chunks it loads into the three pieces on their way into LDS, as gemm_leanw6_kernel
+// does -- 4 bytes per element from L2 instead of 6, no image pass, no producer, 5.5 VALU instructions per
+// element beside the 48 MFMAs per slab and wave.
+__global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                          const x6_rows R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(128, 128, m0, n0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // (here R.seq6 / step6 / off6 / bytes are in units of 4 bytes per element: x6_rows_of(d, 4))
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * 4), 0x00020000);
+  // chunk id = tid + 256 j -> (row of the tile, 16-byte chunk = 4 of the slab's 32 floats)
+  unsigned voA[NJ], voW[NJ];
+  int lo[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int id = tid + 256 * j, row = id >> 3, c = id & 7;
+    const int r = m0 + row, sq = r / R.P0;
+    voA[j] = r < M ? (unsigned)sq * R.seq6 + (unsigned)(r - sq * R.P0) * R.step6 + R.off6 + c * 16 : 0xf0000000u;
+    voW[j] = n0 + row < N ? (unsigned)((long long)(n0 + row) * d.B.seq_stride * 4) + c * 16 : 0xf0000000u;
+    lo[j] = row * PITCH + c * 8;
+  }
+  u32x4 xa[NJ], xw[NJ];
+  auto gload = [&](int t) {
+    const int so = t * 128;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], so, 0);
+      xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], so, 0);
+    }
+  };
+  const unsigned char* rA = smem6 + (wm * 64 + li) * PITCH + h * 16;
+  const unsigned char* rB = smem6 + OPER + (wn * 64 + li) * PITCH + h * 16;
+  const int nt = K / 32;
+  gload(0);
+  for (int t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      u32x2 p0, p1, p2;
+      split3x4(xa[j], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(smem6 + lo[j]) = p0;
+      *reinterpret_cast<u32x2*>(smem6 + lo[j] + 64) = p1;
+      *reinterpret_cast<u32x2*>(smem6 + lo[j] + 128) = p2;
+      split3x4(xw[j], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(smem6 + OPER + lo[j]) = p0;
+      *reinterpret_cast<u32x2*>(smem6 + OPER + lo[j] + 64) = p1;
+      *reinterpret_cast<u32x2*>(smem6 + OPER + lo[j] + 128) = p2;
+    }
+    gload(t + 1 < nt ? t + 1 : 0);       // (past the end: re-read, never used)
+    __syncthreads();
+    bf16x8 fa[2][3][2], fb[2][3][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + i * 32 * PITCH + ks * 32);
+          fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int j = sdeg - i;
+          if (j < 0 || j > 2) continue;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+        }
+  }
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+}
+
 // 1 if a form-0 descriptor over fp32 tensors could run as precision 3 once both operands are handed
 // over as f2g_split_bf16x3 images
 // extent in elements of what the A operand's rows may touch, or 0 if precision 3 cannot read it
@@ -2574,6 +2665,38 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
   R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
   dim3 grid((M + 127) / 128, (N + 127) / 128);
   hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K, R);
+  g_last_path = 4;
+  return f2g_check_launch();
+}
+
+// the same descriptor over the fp32 tensors themselves (split = 0): gemm_x6f_kernel
+static bool x6f_ok(const f2g_gemm_desc& d) {
+  if (d.A.split || d.B.split || d.E.x3_out || !x6_shape_ok(d)) return false;
+  if (!al16(d.A.base) || !al16(d.B.base) || (d.A.seq_stride & 3) || (d.B.seq_stride & 3)) return false;
+  const long long ext = host_plain(d.A) ? (long long)d.A.rows * d.A.seq_stride : x6_a_extent(d.A);
+  return ext * 4 < 0xe0000000ll && (long long)d.B.rows * d.B.seq_stride * 4 < 0xe0000000ll;
+}
+
+static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
+  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
+  constexpr size_t smem = 2 * 128 * 208;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6f_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  x6_rows R;      // (byte strides of the fp32 tensor)
+  if (host_plain(d.A)) {
+    R.P0 = 1, R.seq6 = (unsigned)(d.A.seq_stride * 4), R.step6 = 0, R.off6 = 0;
+    R.bytes = (unsigned)((long long)d.A.rows * d.A.seq_stride * 4);
+  } else {
+    R.P0 = d.A.P0, R.seq6 = (unsigned)(d.A.seq_stride * 4);
+    R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 4), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 4);
+    R.bytes = (unsigned)(x6_a_extent(d.A) * 4);
+  }
+  dim3 grid((M + 127) / 128, (N + 127) / 128);
+  hipLaunchKernelGGL(gemm_x6f_kernel, grid, dim3(256), smem, st, d, M, N, K, R);
   g_last_path = 4;
   return f2g_check_launch();
 }
@@ -2682,6 +2805,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   }
   if (d.precision == 3) {
     // fp32-class products from three-piece images (both operands f2g_split_bf16x3 images: split = 3)
+    if (x6f_ok(d)) return launch_x6f(d, st);       // fp32 operands, split inside the kernel
     if (d.A.split != 3 || d.B.split != 3 || !x6_shape_ok(d)) {
       f2g_set_error("f2g_gemm precision 3: form 0 over plain f2g_split_bf16x3 images (split = 3), K % 32 == 0");
       return F2G_EINVAL;
