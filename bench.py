@@ -251,7 +251,7 @@ def main():
                                   "ms": round(1e3 * v[2], 2),
                                   "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None}
                               for k, v in sorted(fam3.items())}}
-        if args.workload == "gan_stage2":
+        if args.workload in ("gan_stage2", "stage1"):
             # fp32-CLASS products on the bf16 matrix pipe for the GEMMs with long reductions (three bf16
             # pieces per operand, six MFMAs per product; everything else on the exact fp32 MFMA)
             ops.set_gemm_precision("bf16x6")

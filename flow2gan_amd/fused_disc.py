@@ -300,11 +300,13 @@ class MPDLossFn(torch.autograd.Function):
                 """Run `producer(mask, fm, colsum)` -> gradient map landing on acts[l_out], with its
                 leaky-ReLU backward fused (FUSE_LRELU & 1) or as a separate pass."""
                 mk, fk, ck = below(l_out)
-                # (bf16x6 mode: the six-product kernel runs the generic epilogue anyway, and its image
-                # pass must see the final map)
-                if (FUSE_LRELU & 1) or ops.GEMM_PRECISION == 3:
+                # (bf16x6 mode: where the data gradient runs on the six-product kernel -- the 1024-channel
+                # layers, K >= 2048 -- that kernel has the generic epilogue anyway, and the image it
+                # leaves for the next data gradient must be of the final map)
+                if (FUSE_LRELU & 1) or (ops.GEMM_PRECISION == 3 and l_out in (3, 4)):
                     return producer(mk, fk, ck)
                 gm = producer(None, None, None)
+                gm._f2g_x3_bad = True      # (changed in place below: no producer-written image of it)
                 y = acts[l_out]
                 Hp_, C_ = hs[l_out] + 2 * HALO, y.shape[1]
                 n_ = Sx * Hp_ * C_

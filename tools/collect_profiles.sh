@@ -37,6 +37,7 @@ F2G_GEMM_REPORT=60 python bench.py --gemm bf16x6 --steps 3 --warmup 2 --no-cpu-b
   echo "# python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-fast-mode --no-roofline   (exact fp32, same box)"
   python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-fast-mode --no-roofline 2>/dev/null | tail -1 | cut -c1-260 ) > $O/x6_step_variants.txt
 python tools/x6_gemm_bench.py > $O/x6_gemm_bench.txt 2>/dev/null
+bash tools/pmc_x6_step.sh > $O/pmc_x6_step.txt 2>&1
 python tools/conv32_probe.py > $O/conv32_probe.txt 2>/dev/null
 F2G_CONV32_V2=0 python tools/conv32_probe.py 2>/dev/null | grep "all 45" > $O/conv32_probe_round2_kernels.txt
 SWEEP=2,4,8,16 python tools/wgrad_probe.py > $O/wgrad_probe.txt 2>/dev/null

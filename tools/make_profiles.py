@@ -76,10 +76,11 @@ HEAD = {
     "infer4_bf16_timeline_kernels.txt": "# tools/timeline_last.py over the kernel trace of tools/prof_timeline.sh: every kernel of the last graph-replayed bf16 4-step inference (start us, duration us, queue, blocks, kernel)\n",
     "hbm_kernels.txt": "# tools/hbm_kernel_bench.py: the HBM-class ConvNeXt kernels back to back at the mel_24k_base branch shapes (B = 64); algorithmic bytes / HIP-event time against 8 TB/s\n",
     "infer4_bf16_variants.txt": "",
+    "pmc_x6_step.txt": "# tools/pmc_x6_step.sh: rocprofv3 --pmc passes over `bench.py --gemm bf16x6 --steps 1 --warmup 1` (launch lanes off); per-kernel means over the launches of gemm_x6_kernel / gemm_leanw6_kernel\n",
     "infer4_bf16_timeline.txt": "# tools/prof_timeline.sh (rocprofv3 --kernel-trace over the HIP-graph replayed bf16 4-step inference, launch lanes ON): overlap statistics of the last inference in the trace (profiled: ~5-15 % slower than unprofiled)\n",
     "wgrad_probe.txt": "", "conv32_probe.txt": "", "fused_mlp_bench.txt": "", "fused_mlp_lab.txt": "",
 }
-for src, dst in (("lean3_bench.txt", "lean3_bench.txt"), ("conv32_b3_bench.txt", "conv32_split_bench.txt"),
+for src, dst in (("pmc_x6_step.txt", "x6_step_pmc.txt"), ("lean3_bench.txt", "lean3_bench.txt"), ("conv32_b3_bench.txt", "conv32_split_bench.txt"),
                  ("fused_multi.txt", "fused_multi.txt"), ("pmc_multi.txt", "fused_multi_pmc.txt"),
                  ("infer4_bf16_timeline_kernels.txt", "infer4_bf16_timeline_kernels.txt"),
                  ("hbm_kernels.txt", "hbm_kernels.txt"), ("infer4_bf16_variants.txt", "infer4_bf16_variants.txt"),
