@@ -2400,6 +2400,42 @@ __global__ __launch_bounds__(256) void split3_img_kernel(__bf16* __restrict__ ds
   }
 }
 
+// The tile's three-piece image for the next GEMM (f2g_epilogue.x3_out): read back what the block has just
+// stored (L2; the barrier orders the block's own stores before these loads) and write whole 16-byte pieces.
+__device__ __forceinline__ void x3_tile_readback(const f2g_epilogue& E, int M, int N, int m0, int n0, int tid) {
+  __syncthreads();
+  for (int u = tid; u < 128 * 16; u += 256) {
+    const int row = m0 + (u >> 4), col = n0 + (u & 15) * 8;
+    if (row >= M || col >= N) continue;
+    long long off;
+    if (E.P0o > 0) {
+      const int sq = row / E.P0o;
+      off = (long long)sq * E.seq_stride_o + (long long)(row - sq * E.P0o) * E.row_stride_o + E.off_o + col;
+    } else {
+      off = (long long)row * E.ldc + col;
+    }
+    const float4 v0 = *reinterpret_cast<const float4*>(E.C + off);
+    const float4 v1 = *reinterpret_cast<const float4*>(E.C + off + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    unsigned pk[3][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 a = (__bf16)x[e];
+      const float r1 = x[e] - (float)a;
+      const __bf16 b = (__bf16)r1;
+      const __bf16 c = (__bf16)(r1 - (float)b);
+      const unsigned sa = __builtin_bit_cast(unsigned short, a), sb = __builtin_bit_cast(unsigned short, b),
+                     sc = __builtin_bit_cast(unsigned short, c);
+      if (e & 1) pk[0][e >> 1] |= sa << 16, pk[1][e >> 1] |= sb << 16, pk[2][e >> 1] |= sc << 16;
+      else pk[0][e >> 1] = sa, pk[1][e >> 1] = sb, pk[2][e >> 1] = sc;
+    }
+    __bf16* q = reinterpret_cast<__bf16*>(E.x3_out) + (off >> 5) * 96 + (off & 31);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      *reinterpret_cast<uint4*>(q + 32 * pc) = make_uint4(pk[pc][0], pk[pc][1], pk[pc][2], pk[pc][3]);
+  }
+}
+
 // A rows: plain (row r at r * K * 6 bytes of a dense image) or single-segment windows over the flat image
 // of a contiguous buffer (MPD halo maps: row (s, p) at s * seq6 + p * step6 + off6 bytes, K contiguous --
 // element e of a contiguous buffer lives at (e / 32) * 192 + piece * 64 + (e % 32) * 2 whatever its row
@@ -2488,42 +2524,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
         }
   }
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
-  if (d.E.x3_out) {
-    // the tile's three-piece image for the next GEMM: read back what the block has just stored (L2;
-    // the barrier orders the block's own stores before these loads) and write whole 16-byte pieces
-    __syncthreads();
-    const f2g_epilogue& E = d.E;
-    for (int u = tid; u < 128 * 16; u += 256) {
-      const int row = m0 + (u >> 4), col = n0 + (u & 15) * 8;
-      if (row >= M || col >= N) continue;
-      long long off;
-      if (E.P0o > 0) {
-        const int sq = row / E.P0o;
-        off = (long long)sq * E.seq_stride_o + (long long)(row - sq * E.P0o) * E.row_stride_o + E.off_o + col;
-      } else {
-        off = (long long)row * E.ldc + col;
-      }
-      const float4 v0 = *reinterpret_cast<const float4*>(E.C + off);
-      const float4 v1 = *reinterpret_cast<const float4*>(E.C + off + 4);
-      const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      unsigned pk[3][4];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const __bf16 a = (__bf16)x[e];
-        const float r1 = x[e] - (float)a;
-        const __bf16 b = (__bf16)r1;
-        const __bf16 c = (__bf16)(r1 - (float)b);
-        const unsigned sa = __builtin_bit_cast(unsigned short, a), sb = __builtin_bit_cast(unsigned short, b),
-                       sc = __builtin_bit_cast(unsigned short, c);
-        if (e & 1) pk[0][e >> 1] |= sa << 16, pk[1][e >> 1] |= sb << 16, pk[2][e >> 1] |= sc << 16;
-        else pk[0][e >> 1] = sa, pk[1][e >> 1] = sb, pk[2][e >> 1] = sc;
-      }
-      __bf16* q = reinterpret_cast<__bf16*>(E.x3_out) + (off >> 5) * 96 + (off & 31);
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        *reinterpret_cast<uint4*>(q + 32 * pc) = make_uint4(pk[pc][0], pk[pc][1], pk[pc][2], pk[pc][3]);
-    }
-  }
+  if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
 // The same tile and schedule over the fp32 operands themselves (f2g_operand.split = 0): every thread
@@ -2615,6 +2616,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
         }
   }
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
 // 1 if a form-0 descriptor over fp32 tensors could run as precision 3 once both operands are handed
@@ -2671,7 +2673,7 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
 
 // the same descriptor over the fp32 tensors themselves (split = 0): gemm_x6f_kernel
 static bool x6f_ok(const f2g_gemm_desc& d) {
-  if (d.A.split || d.B.split || d.E.x3_out || !x6_shape_ok(d)) return false;
+  if (d.A.split || d.B.split || !x6_shape_ok(d)) return false;
   if (!al16(d.A.base) || !al16(d.B.base) || (d.A.seq_stride & 3) || (d.B.seq_stride & 3)) return false;
   const long long ext = host_plain(d.A) ? (long long)d.A.rows * d.A.seq_stride : x6_a_extent(d.A);
   return ext * 4 < 0xe0000000ll && (long long)d.B.rows * d.B.seq_stride * 4 < 0xe0000000ll;

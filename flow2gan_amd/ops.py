@@ -292,11 +292,15 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     d.precision = GEMM_PRECISION
     if GEMM_PRECISION == 3:
         d.precision = 0       # (what does not qualify below runs on the exact fp32 MFMA)
-        if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS and A.cols >= X6_MIN_K \
-                and not atomic \
+        in_kernel = X6F == 1
+        if X6F == 2 and X6F_MIN_K <= A.cols < X6_MIN_K and Bm.rows >= 512 \
+                and ((A.rows + 127) // 128) * ((Bm.rows + 127) // 128) >= 376:
+            in_kernel = True      # (mid-length reductions on well-filled grids: see X6F)
+        if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS \
+                and (A.cols >= X6_MIN_K or in_kernel) and not atomic \
                 and split_k <= 1 and out.dtype == torch.float32 and _x3_window_ok(A) \
                 and L.lib.f2g_gemm_x6_ok(C.byref(d)):
-            if not X6F:       # (X6F: gemm_x6f_kernel reads the fp32 operands and splits them itself)
+            if not in_kernel:     # (else gemm_x6f_kernel reads the fp32 operands and splits them itself)
                 d.A, d.B = _x3_operand(A), _x3_operand(Bm)
             d.precision = 3
         if form == 2 and X6_WGRAD and atomic and A.split == 0 and Bm.split == 0 and A.lrelu_src is None \
@@ -306,7 +310,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
             # the three-piece image of `out` for the next GEMM, written by this one's epilogue (every
             # writer of the buffer must do so, or the image is dropped: x3_reserve / _x3_operand)
             buf = getattr(out, "_f2g_x3_buf", None)
-            if d.precision == 3 and not X6F and buf is not None and not getattr(out, "_f2g_x3_bad", False) \
+            if d.precision == 3 and X6F != 1 and buf is not None and not getattr(out, "_f2g_x3_bad", False) \
                     and out_offset % 32 == 0 and prelu_out is None:
                 d.E.x3_out = ptr(buf) + (out_offset // 32) * 192
                 out._f2g_x3 = buf
@@ -485,7 +489,7 @@ def x3_reserve(t, halo=None):
     """Storage for the three-piece image of the contiguous fp32 buffer `t` that the GEMMs writing `t`
     fill in their epilogues (gemm(x3_out=True)); halo = (S, Hp, C, top, bottom): those rows of every
     sequence are zero in `t` and are zeroed in the image too.  No-op outside the bf16x6 mode."""
-    if GEMM_PRECISION != 3 or X6F or not X3_PRODUCERS or t.numel() % 32 or not t.is_contiguous():
+    if GEMM_PRECISION != 3 or X6F == 1 or not X3_PRODUCERS or t.numel() % 32 or not t.is_contiguous():
         return t
     img = torch.empty(t.numel() * 3, device=t.device, dtype=torch.bfloat16)
     if halo is not None:
@@ -499,7 +503,13 @@ def x3_reserve(t, halo=None):
 
 X3_PRODUCERS = _os.environ.get("F2G_X3_PRODUCERS", "1") != "0"
 X6_WGRAD = _os.environ.get("F2G_X6_WGRAD", "1") != "0"
-X6F = _os.environ.get("F2G_X6F", "0") != "0"
+# gemm_x6f_kernel (the forward kernel over the fp32 operands, pieces made inside the kernel): 0 never,
+# 1 instead of the image kernel everywhere, 2 (default) where it was measured faster than both the image
+# kernel and the exact-fp32 lean kernel -- reductions of 640 <= K < X6_MIN_K with >= 512 output columns
+# and a tile grid that fills the chip (113920 x 512 x 640: 131 against 114 / 115 TFLOP/s;
+# 12032 x 512 x 1536: 109 : 111 : 95; 6016 x 2304 x 768: 103 : 109 : 96 -- profiles/r03_x6_step.txt)
+X6F = int(_os.environ.get("F2G_X6F", "2"))
+X6F_MIN_K = int(_os.environ.get("F2G_X6F_MIN_K", "640"))
 
 
 def _x3_window_ok(o: Operand) -> bool:

@@ -1068,8 +1068,9 @@ def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
     assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("kernel", ["images", "in-kernel split"])
 @pytest.mark.parametrize("M,N,K", [(6016, 768, 2304), (1500, 200, 96), (4099, 1152, 384)])
-def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K):
+def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, monkeypatch):
     """precision 3 (`bf16x6`): three bf16 pieces per operand, six MFMAs per product.  Against float64 its
     error must be of the class of the exact-fp32 kernel's on the same operands (max over ALL entries of
     |err| / sum |a w| below 1e-6 and within 3x of the fp32 MFMA's; plain bf16 is at 1e-3), on ragged extents, with bias / residual / PReLU epilogues
@@ -1083,6 +1084,8 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K):
     ref = a.double() @ w.double().t()
     mag = a.abs().double() @ w.abs().double().t()
     ad, wd = g(a), torch.nn.Parameter(g(w))
+    # gemm_x6_kernel over f2g_split_bf16x3 images / gemm_x6f_kernel over the fp32 operands themselves
+    monkeypatch.setattr(ops, "X6F", 0 if kernel == "images" else 1)
     was = ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS
     try:
         ops.set_gemm_precision("bf16x6")
@@ -1101,6 +1104,21 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K):
         ops.gemm(ops.mat(ad), ops.mat(wd), out2, bias=g(bias), res=g(res), gamma=g(gam))
         want2 = ref + bias.double() + gam.double() * res.double()
         assert float(((out2.cpu().double() - want2).abs() / (mag + 1)).max()) < 1e-6
+        # the result's own three-piece image, written by the kernel after its epilogue (E.x3_out)
+        monkeypatch.setattr(ops, "X6F", 2 if kernel != "images" else 0)     # (1 = no images anywhere)
+        monkeypatch.setattr(ops, "X6F_MIN_K", 32)
+        if kernel != "images":
+            monkeypatch.setattr(ops, "X6_MIN_K", 1 << 20)                   # every K below it: in-kernel split
+        out3 = ops.x3_reserve(torch.full((M, N), float("nan"), device=DEV))
+        ops.gemm(ops.mat(ad), ops.mat(wd), out3, bias=g(bias), lrelu=0.1, x3_out=True)
+        if kernel == "images" or (N >= 512 and ((M + 127) // 128) * ((N + 127) // 128) >= 376):
+            img = getattr(out3, "_f2g_x3", None)
+            assert img is not None and not getattr(out3, "_f2g_x3_bad", False)
+            assert torch.equal(img.view(torch.int16), ops.x3_flat_image(out3).view(torch.int16))
+        v3 = ref + bias.double()
+        assert float(((out3.cpu().double() - torch.where(v3 > 0, v3, 0.1 * v3)).abs() / (mag + 1)).max()) < 1e-6
+        monkeypatch.setattr(ops, "X6F", 0 if kernel == "images" else 1)
+        monkeypatch.setattr(ops, "X6_MIN_K", 32)
         al = 0.25 + 0.2 * torch.rand(N, generator=gen)
         pre, act = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
         ops.gemm(ops.mat(ad), ops.mat(wd), pre, bias=g(bias), prelu=g(al), prelu_out=act)
