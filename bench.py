@@ -257,12 +257,14 @@ def main():
             ops.set_gemm_precision("bf16x6")
             a6, e6 = timed(1, max(2, args.steps // 2))
             fast["fp32_class"] = {
-                "gemm": "bf16x6: form-0 GEMMs with K >= 2048 (the 512- / 1024-channel MPD layers' forward "
-                        "and data-gradient GEMMs over their halo maps, the 768-channel pwconv2) as six "
-                        "v_mfma_f32_32x32x16_bf16 per product over three-piece operand images that the "
-                        "producing GEMM's epilogue writes (error <= 2^-23 per product: 8e-8 of sum|a w| "
-                        "measured where the fp32 fmaf chain has 7e-8..2e-7); weight gradients, MRD, the "
-                        "other generator GEMMs exact fp32",
+                "gemm": "bf16x6: three bf16 pieces per fp32 operand, six v_mfma_f32_32x32x16_bf16 per product "
+                        "(error <= 2^-23 per product: 8e-8 of sum|a w| measured where the fp32 fmaf chain has "
+                        "7e-8..2e-7) for the form-0 GEMMs with K >= 2048 (the 512- / 1024-channel MPD layers' "
+                        "forward and data-gradient GEMMs over their halo maps, the 768-channel pwconv2; operand "
+                        "images written by the producing GEMM's epilogue), for 640 <= K < 2048 on chip-filling "
+                        "grids (operands split inside the kernel) and for the weight gradients with >= 2048 "
+                        "rows (gemm_leanw6_kernel, operands split inside the kernel); MRD and the short-K "
+                        "generator GEMMs exact fp32",
                 "value": round(world * a6 / e6, 2), "unit": "audio-s/s",
                 "ms_per_step": round(1e3 * e6 / max(2, args.steps // 2), 2),
                 "parity": "every golden parity test passes in this mode at the exact-fp32 tolerances "
