@@ -1922,6 +1922,9 @@ void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
 // transposing ds_read_b64_tr_b16 fragments, and the six products with i + j <= 2 (smallest first).
 // One 48 KB LDS buffer, two blocks per CU:  split + store slab t -> request slab t + 1 -> barrier ->
 // read its 24 fragments -> barrier -> 48 MFMAs.
+// (gemm_x6_kernel raises its waves' priority for the MFMA phase: +2 ... 14 % in the step; the kernels that
+// split operands on the VALU lose with it -- the other block's split is what feeds their next slab)
+#define X6_MFMA_PRIO 1
 __device__ __forceinline__ void split3x4(const u32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
   // (by value first: __builtin_bit_cast applied to a vector-element expression reads element 0)
   const unsigned u0 = v.x, u1 = v.y, u2 = v.z, u3 = v.w;
@@ -2508,6 +2511,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
           fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
         }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(X6_MFMA_PRIO);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -2522,6 +2526,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
             for (int ni = 0; ni < 2; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
         }
+    __builtin_amdgcn_s_setprio(0);
   }
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
   if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
