@@ -2532,6 +2532,128 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
   if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
+// Stride-1 conv windows (the 1024-channel MPD layer and its data gradient: K = 5 taps x 1024 channels):
+// tap-major K order makes the kernel above fetch every map row once per tap.  Here the positions a tile's
+// 128 output rows touch -- a contiguous run of the halo map, the halo rows of the sequence ends inside
+// the tile included -- are staged ONCE per 32-channel slab and the taps walk over them in LDS (a lane's
+// fragment row = its output row's staged position + tap): A traffic from L2 drops to a fifth, the
+// kernel's total by 40 %.  K order = channel slab outer, tap inner (the weights' slab t * C/32 + cs).
+struct x6_tap {
+  int P0, HpIn, offpos, C32;
+  unsigned bytes;
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                          const x6_tap R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int PITCH = 208, LMAX = 160, OPER = LMAX * PITCH, NJA = 8, NJB = 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(128, 128, m0, n0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto posrow = [&](int r) {
+    const int sq = r / R.P0;
+    return sq * R.HpIn + (r - sq * R.P0) + R.offpos;
+  };
+  const int pbase = posrow(m0);
+  const int rlast = m0 + 127 < M ? m0 + 127 : M - 1;
+  const int L = posrow(rlast) - pbase + TAPS;            // staged positions (<= LMAX: host check)
+  const unsigned rowbytesA = (unsigned)R.C32 * 192u;     // one position of the map image
+  const unsigned rowbytesW = (unsigned)(K / 32) * 192u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytesW, 0x00020000);
+  unsigned voA[NJA], voW[NJB];
+#pragma unroll
+  for (int j = 0; j < NJA; ++j) {
+    const int id = tid + 256 * j, q = id / 12, c = id - q * 12;
+    voA[j] = q < L ? (unsigned)(pbase + q) * rowbytesA + c * 16 : 0xf0000000u;
+  }
+#pragma unroll
+  for (int j = 0; j < NJB; ++j) {
+    const int id = tid + 256 * j, row = id / 12, c = id - row * 12;
+    voW[j] = (unsigned)(n0 + row) * rowbytesW + c * 16;
+  }
+  u32x4 xa[NJA], xw[NJB];
+  auto gloadA = [&](int cs) {
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], cs * 192, 0);
+  };
+  auto gloadB = [&](int slab) {
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], slab * 192, 0);
+  };
+  // fragment rows of this lane: output rows wm * 64 + i * 32 + li -> staged position
+  const unsigned char* rA[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = m0 + wm * 64 + i * 32 + li;
+    rA[i] = smem6 + (r < M ? posrow(r) - pbase : 0) * PITCH + h * 16;
+  }
+  const unsigned char* rB = smem6 + OPER + (wn * 64 + li) * PITCH + h * 16;
+  gloadA(0);
+  gloadB(0);
+  for (int cs = 0; cs < R.C32; ++cs) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+      for (int j = 0; j < NJB; ++j) {
+        const int id = tid + 256 * j, row = id / 12, c = id - row * 12;
+        *reinterpret_cast<u32x4*>(smem6 + OPER + row * PITCH + c * 16) = xw[j];
+      }
+      if (t == 0) {
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+          const int id = tid + 256 * j, q = id / 12, c = id - q * 12;
+          if (q < LMAX) *reinterpret_cast<u32x4*>(smem6 + q * PITCH + c * 16) = xa[j];
+        }
+        gloadA(cs + 1 < R.C32 ? cs + 1 : 0);      // (past the end: re-read, never used)
+      }
+      {
+        const int tn = t + 1 < TAPS ? t + 1 : 0, cn = t + 1 < TAPS ? cs : (cs + 1 < R.C32 ? cs + 1 : 0);
+        gloadB(tn * R.C32 + cn);
+      }
+      __syncthreads();
+      bf16x8 fa[2][3][2], fb[2][3][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA[i] + t * PITCH + p * 64 + ks * 32);
+            fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
+          }
+      __syncthreads();
+      __builtin_amdgcn_s_setprio(X6_MFMA_PRIO);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int j = sdeg - i;
+            if (j < 0 || j > 2) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
+}
+
 // The same tile and schedule over the fp32 operands themselves (f2g_operand.split = 0): every thread
 // splits the 4-float chunks it loads into the three pieces on their way into LDS, as gemm_leanw6_kernel
 // does -- 4 bytes per element from L2 instead of 6, no image pass, no producer, 5.5 VALU instructions per
@@ -2653,7 +2775,42 @@ static bool x6_shape_ok(const f2g_gemm_desc& d) {
   return true;
 }
 
+// stride-1 conv windows of TAPS positions x C channels over a halo map image (gemm_x6t_kernel)
+static bool x6_tap_ok(const f2g_gemm_desc& d, int taps) {
+  const f2g_operand& A = d.A;
+  static const bool on = !(getenv("F2G_X6_TAP") && atoi(getenv("F2G_X6_TAP")) == 0);
+  if (!on || host_plain(A) || A.P1 != 1 || A.step0 != 1 || A.unit < 32 || (A.unit % 32)) return false;
+  if (A.cols != taps * A.unit || A.seglen < A.cols || (A.seq_stride % A.unit) || (A.pad0 > 0)) return false;
+  const int HpIn = (int)(A.seq_stride / A.unit);
+  if (A.P0 < 8 || HpIn < A.P0) return false;
+  // staged positions of a tile: its rows, the taps' overhang, the extra positions of every sequence end inside
+  return 128 + taps - 1 + (HpIn - A.P0) * (128 / A.P0 + 1) <= 160;
+}
+
+static int launch_x6t(const f2g_gemm_desc& d, int taps, hipStream_t st) {
+  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
+  constexpr size_t smem = (160 + 128) * 208;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t_kernel<5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  x6_tap R;
+  R.P0 = d.A.P0, R.HpIn = (int)(d.A.seq_stride / d.A.unit), R.offpos = -d.A.pad0, R.C32 = d.A.unit / 32;
+  R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
+  dim3 grid((M + 127) / 128, (N + 127) / 128);
+  if (taps == 5) hipLaunchKernelGGL(gemm_x6t_kernel<5>, grid, dim3(256), smem, st, d, M, N, K, R);
+  else hipLaunchKernelGGL(gemm_x6t_kernel<2>, grid, dim3(256), smem, st, d, M, N, K, R);
+  g_last_path = 4;
+  return f2g_check_launch();
+}
+
 static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
+  if (x6_tap_ok(d, 5)) return launch_x6t(d, 5, st);
+  if (x6_tap_ok(d, 2)) return launch_x6t(d, 2, st);     // (the stride-3 layers' residue data gradients)
   const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
   constexpr size_t smem = 2 * 128 * 208;
   static bool attr_done = false;
