@@ -2865,7 +2865,11 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
   return f2g_check_launch();
 }
 
-extern "C" int f2g_gemm_x6_ok(const f2g_gemm_desc* d) { return d && x6_shape_ok(*d) ? 1 : 0; }
+// 0 no; 1 yes; 3 yes, on a tap-walking instance (stride-1 conv windows of 5 or 2 positions)
+extern "C" int f2g_gemm_x6_ok(const f2g_gemm_desc* d) {
+  if (!d || !x6_shape_ok(*d)) return 0;
+  return (x6_tap_ok(*d, 5) || x6_tap_ok(*d, 2)) ? 3 : 1;
+}
 
 extern "C" int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K) { return (int64_t)rows * K * 6; }
 

@@ -761,6 +761,8 @@ class GemmTimer:
         e.record()
         self.records.append((s, e, flops))
         self.paths.append(("generic", "lean", "lean-streamk", "narrow", "x6")[L.lib.f2g_gemm_last_path()])
+        if self.paths[-1] == "x6" and form == 0 and d.A.split == 3 and L.lib.f2g_gemm_x6_ok(C.byref(d)) == 3:
+            self.x6_tap = getattr(self, "x6_tap", 0) + 1      # (launches on the tap-walking instance)
         nn = Bm.rows if form == 0 else Bm.cols
         mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
         self.shapes.append((form, mm, nn, kk))

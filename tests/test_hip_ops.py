@@ -1182,6 +1182,9 @@ def test_fp32_class_gemm_over_halo_windows_and_producer_images(ops, B2, T, p):
         finally:
             ops.GEMM_TIMER = None
         assert timer.paths.count("x6") == 4, timer.paths      # layers 1..4 (layer 0 and conv_post are HBM streams)
+        # the stride-1 layer 4 runs on the tap-walking instance where a tile's positions fit its LDS
+        # window (13-row sequences at p = 11: 172 positions, the plain instance)
+        assert getattr(timer, "x6_tap", 0) == (0 if p == 11 else 1), getattr(timer, "x6_tap", 0)
         nimg = 0
         for l, (y, yr) in enumerate(zip(st["acts"], ref["acts"])):
             scale = float(yr.abs().max())
