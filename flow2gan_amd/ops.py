@@ -293,8 +293,9 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
     if GEMM_PRECISION == 3:
         d.precision = 0       # (what does not qualify below runs on the exact fp32 MFMA)
         in_kernel = X6F == 1
-        if X6F == 2 and X6F_MIN_K <= A.cols < X6_MIN_K and Bm.rows >= 512 \
-                and ((A.rows + 127) // 128) * ((Bm.rows + 127) // 128) >= 376:
+        if X6F == 2 and X6F_MIN_K <= A.cols < X6_MIN_K and (
+                (Bm.rows >= X6F_MIN_N and ((A.rows + 127) // 128) * ((Bm.rows + 127) // 128) >= 376)
+                or (A.rows >= X6F_TALL_ROWS and Bm.rows >= 128)):
             in_kernel = True      # (mid-length reductions on well-filled grids: see X6F)
         if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS \
                 and (A.cols >= X6_MIN_K or in_kernel) and not atomic \
@@ -507,9 +508,12 @@ X6_WGRAD = _os.environ.get("F2G_X6_WGRAD", "1") != "0"
 # 1 instead of the image kernel everywhere, 2 (default) where it was measured faster than both the image
 # kernel and the exact-fp32 lean kernel -- reductions of 640 <= K < X6_MIN_K with >= 512 output columns
 # and a tile grid that fills the chip (113920 x 512 x 640: 131 against 114 / 115 TFLOP/s;
-# 12032 x 512 x 1536: 109 : 111 : 95; 6016 x 2304 x 768: 103 : 109 : 96 -- profiles/r03_x6_step.txt)
+# 12032 x 512 x 1536: 109 : 111 : 95; 6016 x 2304 x 768: 103 : 109 : 96 -- profiles/r03_x6_step.txt),
+# or very tall GEMMs from 128 columns on (113920 x 128 x 1024: 129 against 98; 24064 x 384 x 1152 loses: 88 : 95)
 X6F = int(_os.environ.get("F2G_X6F", "2"))
 X6F_MIN_K = int(_os.environ.get("F2G_X6F_MIN_K", "640"))
+X6F_MIN_N = int(_os.environ.get("F2G_X6F_MIN_N", "512"))
+X6F_TALL_ROWS = int(_os.environ.get("F2G_X6F_TALL_ROWS", "65536"))
 
 
 def _x3_window_ok(o: Operand) -> bool:
