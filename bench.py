@@ -140,21 +140,24 @@ def main():
     # reducer.prepare() zeroes the gradients (views into flat arenas when there is an exchange); a
     # Fourier branch's / period discriminator's bucket starts its all-reduce when its launch lane has
     # finished its backward, the rest from autograd hooks while backward is still running
+    COMM = [0, 0]       # bytes handed to the all-reduce, steps
+
     def step():
+        COMM[1] += 1
         if args.workload == "gan_stage2":
             # discriminator step on its batch
             reducer.prepare(d_params, groups=d_groups)
             cond = logmel(audio_d)
             mp, mr = gan(cond, audio_d, lens, nts, True)
             (D_WEIGHTS[0] * mp + D_WEIGHTS[1] * mr).backward()
-            reducer.finish()
+            COMM[0] += reducer.finish()
             optimize(opt_d, sch_d)
             # generator step on a new batch
             reducer.prepare(g_params, groups=g_groups)
             cond = logmel(audio_g)
             ls = gan(cond, audio_g, lens, nts, False)
             sum(w * l for w, l in zip(G_WEIGHTS, ls)).backward()
-            reducer.finish()
+            COMM[0] += reducer.finish()
             optimize(opt_g, sch_g)
             return 2 * B * (T / sr)
         if args.workload == "stage1":
@@ -162,7 +165,7 @@ def main():
             reducer.prepare(g_params, groups=g_groups)
             cond = logmel(audio_g)
             gen(cond, audio_g, lens).backward()
-            reducer.finish()
+            COMM[0] += reducer.finish()
             optimize(opt_g, sch_g)
             return B * (T / sr)
         gen.eval()
@@ -196,6 +199,8 @@ def main():
             step()
         barrier()
         torch.cuda.synchronize()
+        reducer.exposed_comm_ms()       # (drop the warm-up's wait events)
+        COMM[0] = COMM[1] = 0
         t0 = time.perf_counter()
         done = 0.0
         for _ in range(nsteps):
@@ -214,8 +219,23 @@ def main():
 
     # headline: exact-fp32 GEMMs (the reference's arithmetic), unless --gemm says otherwise
     ops.set_gemm_precision(args.gemm)
+    reducer.measure = world > 1 or force_dist
     audio_s, elapsed = timed(args.warmup, args.steps)
     value = world * audio_s / elapsed
+    comm = None
+    if world > 1 or force_dist:
+        # what makes the N > 1 line checkable on its own: the ranks that took part (counted by an
+        # all-reduce, not read from the environment), the backend, the bytes every rank handed to
+        # the gradient all-reduce per step, and how long the compute stream had to WAIT for the
+        # exchange at the end of a backward (event pair around finish()'s wait; max over ranks)
+        seen = torch.ones(1, device=device)
+        torch.distributed.all_reduce(seen)
+        exposed = torch.tensor([reducer.exposed_comm_ms() / max(1, COMM[1])], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(exposed, op=torch.distributed.ReduceOp.MAX)
+        comm = {"ranks_seen": int(seen.item()), "backend": torch.distributed.get_backend(),
+                "comm_bytes_per_step": int(COMM[0] // max(1, COMM[1])),
+                "exposed_comm_ms": round(float(exposed.item()), 3)}
+    reducer.measure = False
     host_issue_ms = round(1e3 * HOST_ISSUE[0] / max(1, HOST_ISSUE[1]), 2)
     fast = None
     if args.gemm == "fp32" and not args.no_fast_mode:
@@ -313,6 +333,7 @@ def main():
         # dominant kernel = the family with the most time in this pass
         dom = max(fam.items(), key=lambda kv: kv[1][2])
         dn, (dl, dfl, dsec) = dom
+        alg_bytes = timer.algorithmic_bytes(dn) / max(1, dl)
         # the dense MFMA peak of the arithmetic the pass ran in
         peak = PEAK_BF16_MFMA_TFLOPS if args.gemm == "bf16" else PEAK_FP32_MFMA_TFLOPS
         roofline = {"bound": "mfma",
@@ -329,7 +350,11 @@ def main():
                     # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
                     "achieved": round(dfl / dsec / 1e12, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(dfl / dsec / 1e12 / peak, 4),
-                    "traffic": traffic, "launches_per_step": dl,
+                    # traffic: HBM bytes per launch from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+                    # recorded with THIS build of the library, else null); beside it what one launch must
+                    # move at least: both operands read once, the result written once
+                    "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
+                    "launches_per_step": dl,
                     "avg_launch_us": round(1e6 * dsec / dl, 1),
                     "share_of_mfma_class_time": round(dsec / secs, 3),
                     # every MFMA-class launch of the step (all GEMM families + direct convs); the
@@ -395,11 +420,14 @@ def main():
                            "stage1": "flow-matching stage-1 fwd+bwd",
                            "infer4": "4-step Euler inference" + ("" if args.no_graph else
                                                                  " replayed from a captured HIP graph")}[args.workload],
-                       "per_gpu_batch": B, "seconds_per_item": T / sr, "n_timesteps": nts,
+                       "per_gpu_batch": B, "seconds_per_item": T / sr,
+                       "n_timesteps": 4 if args.workload == "infer4" else nts,
                        "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}",
                        "optimizer": "ScaledAdam + Eden2 (fused HIP)" if args.optimizer else "none"},
             "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast,
         }
+        if comm is not None:
+            line.update(comm)
         # RCCL prints its version banner through C stdio (flushed at exit): push it out first so
         # that the JSON line is the last line on stdout
         import ctypes

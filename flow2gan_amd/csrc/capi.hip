@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "version_gen.h"   // F2G_SRC_HASH: digest of the sources (written by the Makefile)
 
 static char g_err[256] = "";
 
@@ -20,5 +21,6 @@ int f2g_check_launch() {
   return F2G_OK;
 }
 
-extern "C" const char* f2g_version(void) { return "flow2gan_hip 0.3.0 gfx950"; }
+// "flow2gan_hip <version> src:<first 12 hex digits of the sha256 over csrc/*.hip, common.h, the header> gfx950"
+extern "C" const char* f2g_version(void) { return "flow2gan_hip 0.4.0 src:" F2G_SRC_HASH " gfx950"; }
 extern "C" const char* f2g_last_error(void) { return g_err; }

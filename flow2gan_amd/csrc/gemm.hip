@@ -2865,10 +2865,14 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
   return f2g_check_launch();
 }
 
-// 0 no; 1 yes; 3 yes, on a tap-walking instance (stride-1 conv windows of 5 or 2 positions)
+// How f2g_gemm would run this form-0 descriptor at precision 3 -- the SAME tests as its dispatch, E.x3_out
+// included (set it before asking).  Bits: 1 = over three-piece images of both operands (split = 3; also
+// reported for the fp32 tensors the images would be made of), 2 = and then on a tap-walking instance
+// (stride-1 conv windows of 5 or 2 positions), 4 = over the fp32 operands as they are handed over
+// (gemm_x6f_kernel: alignment and stride conditions of the in-kernel split).  0 = not at precision 3.
 extern "C" int f2g_gemm_x6_ok(const f2g_gemm_desc* d) {
   if (!d || !x6_shape_ok(*d)) return 0;
-  return (x6_tap_ok(*d, 5) || x6_tap_ok(*d, 2)) ? 3 : 1;
+  return 1 | ((x6_tap_ok(*d, 5) || x6_tap_ok(*d, 2)) ? 2 : 0) | (x6f_ok(*d) ? 4 : 0);
 }
 
 extern "C" int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K) { return (int64_t)rows * K * 6; }

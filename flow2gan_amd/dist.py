@@ -87,6 +87,8 @@ class GradReducer:
         self._plans: dict = {}
         self._hooked: set = set()
         self._active: Optional["_Plan"] = None
+        self.measure = False          # bench.py: time the compute stream's wait in finish()
+        self.wait_events: list = []
 
     def _comm_stream(self, device):
         if device.type != "cuda":
@@ -151,10 +153,21 @@ class GradReducer:
     #                             # moment autograd has accumulated its last gradient
     #   reducer.finish()          # flush the stragglers, make the compute stream wait
     #
-    # Contract: exactly ONE backward() between prepare() and finish() (a second one raises), and
-    # every rank must produce gradients for the same parameters (the reference's DDP has the same
-    # constraint, find_unused_parameters aside): buckets whose parameters got no gradient at all
-    # are skipped on every rank alike; a bucket that fires on one rank only would hang the group.
+    # Contract: exactly ONE backward() between prepare() and finish() (a second one raises).
+    #
+    # What keeps the ranks' collectives matched (RCCL pairs them by issue order, nothing else):
+    # EVERY bucket of the plan is exchanged on EVERY rank in every step, in ONE launch order that
+    # all ranks share.  The first step of a plan sends nothing early: it records the order in which
+    # the buckets became complete, sends them all at finish() in index order, and the ranks agree on
+    # the recorded order with one small all-reduce (identical everywhere -> adopted; otherwise
+    # index order).  From then on bucket k leaves as soon as it is complete AND its predecessors in
+    # that order have left.  A rank on which some parameter gets no gradient in a step (the case
+    # the reference covers with DDP's find_unused_parameters=True, finetune.py:915) therefore
+    # cannot hang the group: its incomplete bucket -- and whatever follows it in the order --
+    # leaves at finish() with zeros for what never arrived, and the other ranks' early sends pair
+    # with those.  Each arena carries one "used" flag per parameter behind the gradients, summed by
+    # the same all-reduce: a parameter that got no gradient locally keeps the ranks' mean when some
+    # rank used it (DDP's semantics) and gets `.grad = None` when nobody did.
     #
     # Buckets are cut in REVERSE parameter order (backward reaches the last layers first): in a
     # D-step the MRD bucket travels while the MPD data-gradient convs still run, in a G-step the
@@ -187,11 +200,19 @@ class GradReducer:
                 if id(p) not in self._hooked:
                     self._hooked.add(id(p))
                     p.register_post_accumulate_grad_hook(self._on_grad)
+                    p.register_hook(lambda g, p=p: self._on_real_grad(p, g))
         world = get_world_size()
         plan.exchange = world > 1 or (self.force and dist.is_initialized())
         plan.arm()
         self._active = plan
         fused.GRAD_SINK = _Sink(self, plan)
+
+    def _on_real_grad(self, p: torch.nn.Parameter, g) -> None:
+        """Tensor hook of a parameter: autograd is about to accumulate `g` into it -- None when the
+        node that owns the parameter returned None for it (its gradient went through the sink)."""
+        plan = self._active
+        if g is not None and plan is not None and id(p) in plan.bucket_of:
+            plan.real.add(id(p))
 
     def _on_grad(self, p: torch.nn.Parameter, from_sink: bool = False) -> None:
         plan = self._active
@@ -200,10 +221,12 @@ class GradReducer:
         b = plan.bucket_of.get(id(p))
         if b is None:
             return
-        if not from_sink and id(p) in plan.echo:
+        if not from_sink and id(p) in plan.echo and id(p) not in plan.real:
             # autograd runs a parameter's AccumulateGrad node -- and this hook -- even when the
             # node that owns it returned None for it (its gradient went through the sink): the
-            # one echo per backward is not a gradient
+            # one echo per backward is not a gradient.  (A parameter that was delivered through
+            # the sink AND reached by autograd in the same backward -- one use with a ticket, one
+            # without -- is in plan.real: its hook is a gradient and falls through to the checks.)
             plan.echo.discard(id(p))
             return
         if b.sent:
@@ -211,16 +234,27 @@ class GradReducer:
             # that has already been averaged and would never be exchanged: ranks would diverge
             # silently.  One backward per prepare(); gradient accumulation needs reduce().
             raise RuntimeError("GradReducer: gradient arrived for a bucket that has already been "
-                               "exchanged -- exactly one backward() per prepare()/finish() pair "
-                               f"(parameter of shape {tuple(p.shape)}, bucket {b.index})")
+                               "exchanged -- exactly one backward() per prepare()/finish() pair, and "
+                               "every use of a parameter that is handed over per group must carry a "
+                               f"ticket (parameter of shape {tuple(p.shape)}, bucket {b.index})")
         b.fired.add(id(p))
         if b.flat.is_cuda:
             # the stream this gradient was accumulated on (a launch lane, or autograd's stream)
             cur = torch.cuda.current_stream(b.flat.device)
             if cur.cuda_stream not in b.streams:
                 b.streams[cur.cuda_stream] = cur
-        if len(b.fired) == len(b.params) and not b.sent:
-            self._send(plan, b)
+        if len(b.fired) == len(b.params) and not b.ready:
+            b.ready = True
+            plan.ready_order.append(b.index)
+            self._pump(plan)
+
+    def _pump(self, plan: "_Plan") -> None:
+        """Send every complete bucket whose predecessors in the agreed order have left."""
+        if plan.order is None:          # first step of this plan: the order is being recorded
+            return
+        while plan.next_pos < len(plan.order) and plan.buckets[plan.order[plan.next_pos]].ready:
+            self._send(plan, plan.buckets[plan.order[plan.next_pos]])
+            plan.next_pos += 1
 
     @torch.no_grad()
     def _send(self, plan: "_Plan", b: "_Bucket") -> None:
@@ -230,39 +264,99 @@ class GradReducer:
             return
         world = get_world_size()
         comm = self._comm_stream(b.flat.device)
-        if comm is None:
+
+        def exchange():
+            # the "used" flags behind the gradients (zeroed by arm())
+            if len(b.fired) == len(b.params):
+                b.flat[b.n:].fill_(1.0)
+            elif b.fired:
+                b.flat[b.n:].copy_(torch.tensor([1.0 if id(p) in b.fired else 0.0 for p in b.params],
+                                                dtype=b.flat.dtype))
             dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
             if world > 1:
-                b.flat.div_(world)
+                b.flat[:b.n].div_(world)
+
+        if comm is None:
+            exchange()
         else:
             comm.wait_stream(torch.cuda.current_stream(b.flat.device))
             for st in b.streams.values():     # every lane that accumulated into this bucket
                 comm.wait_stream(st)
             with torch.cuda.stream(comm):
-                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
-                if world > 1:
-                    b.flat.div_(world)
+                exchange()
         plan.bytes += b.flat.numel() * b.flat.element_size()
 
+    def _agree_on_order(self, plan: "_Plan") -> None:
+        """End of a plan's first step: adopt the recorded completion order if every rank recorded
+        the same one (buckets that never became complete here follow in index order)."""
+        nb = len(plan.buckets)
+        seen = set(plan.ready_order)
+        mine = list(plan.ready_order) + [i for i in range(nb) if i not in seen]
+        if plan.exchange and get_world_size() > 1:
+            dev = plan.buckets[0].flat.device
+            comm = self._comm_stream(dev)
+            v = torch.tensor(mine + [-i for i in mine], dtype=torch.int64)
+            if comm is None:
+                dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+            else:
+                with torch.cuda.stream(comm):
+                    v = v.to(dev)
+                    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+                comm.synchronize()
+            v = v.cpu().tolist()
+            same = all(v[i] == -v[nb + i] for i in range(nb))      # max == min on every position
+            plan.order = [int(x) for x in v[:nb]] if same else list(range(nb))
+        else:
+            plan.order = mine
+
     def finish(self) -> int:
-        """Send what has not left yet, wait for the exchange; parameters that received no
-        gradient in this backward get `.grad = None` back (as without the reducer).  Returns the
-        bytes exchanged."""
+        """Send what has not left yet (every bucket travels in every step), wait for the exchange.
+        A parameter that received no gradient here keeps the ranks' mean if another rank used it and
+        gets `.grad = None` back if nobody did (as without the reducer).  Returns the bytes exchanged."""
         from . import fused
         fused.GRAD_SINK = None
         plan, self._active = self._active, None
         if plan is None:
             return 0
-        for b in plan.buckets:
-            if b.fired and not b.sent:
-                self._send(plan, b)
-            for p in b.params:
-                if id(p) not in b.fired:
-                    p.grad = None
+        learning = plan.order is None
+        for i in (range(len(plan.buckets)) if learning else plan.order[plan.next_pos:]):
+            if not plan.buckets[i].sent:
+                self._send(plan, plan.buckets[i])
+        plan.next_pos = len(plan.buckets)
+        if learning:
+            self._agree_on_order(plan)
         dev = plan.buckets[0].flat.device if plan.buckets else None
-        if dev is not None and dev.type == "cuda" and self._stream is not None:
-            torch.cuda.current_stream(dev).wait_stream(self._stream)
+        cuda = dev is not None and dev.type == "cuda" and self._stream is not None
+        for b in plan.buckets:
+            if len(b.fired) == len(b.params):
+                continue
+            # (rare) some parameter got no gradient on this rank: did any rank use it?
+            if cuda and plan.exchange:
+                self._stream.synchronize()
+            used = b.flat[b.n:].tolist() if plan.exchange else [0.0] * len(b.params)
+            for p, u in zip(b.params, used):
+                if id(p) not in b.fired and u <= 0.0:
+                    p.grad = None
+        if cuda:
+            if self.measure:
+                # exposed communication: how long the compute stream has to wait for the exchange
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                cur = torch.cuda.current_stream(dev)
+                e0.record(cur)
+                cur.wait_stream(self._stream)
+                e1.record(cur)
+                self.wait_events.append((e0, e1))
+            else:
+                torch.cuda.current_stream(dev).wait_stream(self._stream)
         return plan.bytes
+
+    def exposed_comm_ms(self) -> float:
+        """Sum of the measured waits of finish() since the last call (self.measure = True); syncs."""
+        evs, self.wait_events = self.wait_events, []
+        if not evs:
+            return 0.0
+        evs[-1][1].synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in evs))
 
 
 class _Sink:
@@ -319,12 +413,15 @@ class _Bucket:
         self.index = index
         self.streams: dict = {}
         n = sum(p.numel() for p in params)
-        self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.n = n
+        # the gradients, then one "used" flag per parameter (summed over ranks by the same all-reduce)
+        self.flat = torch.zeros(n + len(params), dtype=params[0].dtype, device=params[0].device)
         self.views, off = [], 0
         for p in params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.fired: set = set()
+        self.ready = False
         self.sent = False
 
 
@@ -346,17 +443,25 @@ class _Plan:
         self.sent_order: List[int] = []
         self.touched: set = set()
         self.echo: set = set()
+        self.real: set = set()
+        self.order: Optional[List[int]] = None     # the ranks' common launch order (None: first step)
+        self.ready_order: List[int] = []
+        self.next_pos = 0
 
     @torch.no_grad()
     def arm(self) -> None:
         self.bytes = 0
         self.sent_order = []
+        self.ready_order = []
+        self.next_pos = 0
         self.touched = set()
         self.echo = set()
+        self.real = set()
         for b in self.buckets:
             b.flat.zero_()
             b.fired.clear()
             b.streams = {}
+            b.ready = False
             b.sent = False
             for p, v in zip(b.params, b.views):
                 p.grad = v

@@ -564,15 +564,15 @@ def _branch_pre(bv: _BranchView, meta, x, t, cproj, training, keep, te_pre=None)
         pk = mat(packed, rows, Kc, split=2 if bf16_chain else 0)
     elif bf16_chain:
         packed = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16)
-        gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1)
+        gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1, true_n=Cin)
         pk = mat(packed, rows, Kc, split=2)
     else:
         packed = ops.empty(rows, ldp, device=dev)
-        gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1)   # bit-reproducible
+        gemm(ops.stft_frames(x, N, hop, F), mat(_pad_rows(Wd, Kc)), packed, split_k=1, true_n=Cin)   # bit-reproducible
         pk = mat(packed, rows, Kc)
     h0 = ops.empty(rows, Cc, device=dev)
     # (never split, as before the padding: the forward stays bit-reproducible from run to run)
-    gemm(pk, mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), h0, bias=bv.b_in, split_k=1)
+    gemm(pk, mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), h0, bias=bv.b_in, split_k=1, true_k=Cin)
     flags = [_limit_draw(training)]
     xcur = ops.empty(rows, Cc, device=dev)
     ops.biasnorm_fwd(h0, xcur, rows, Cc, bv.beta_in, bv.ls_in.reshape(1))
@@ -603,14 +603,14 @@ def _branch_post(st, bv: _BranchView, meta, x_shape, wbranch_row, wscale, pred, 
     ybf = st["bf16_chain"] and lens_f is None       # (the inverse FFT reads bf16 spectra as well)
     yspec = torch.empty(rows, ldp, device=dev, dtype=torch.bfloat16) if ybf else ops.empty(rows, ldp, device=dev)
     gemm(mat(xcur, rows, Cc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), yspec,
-         bias=_pad_vec(bv.b_out, Kc), split_k=1)
+         bias=_pad_vec(bv.b_out, Kc), split_k=1, true_n=Cin)
     if lens_f is not None:
         ops.mask_rows(yspec, B, F, Cin, lens_f)
     frames = ops.empty(rows, N, device=dev)
     if ifft:
         ops.istft_fft(yspec, N, F, frames)
     else:
-        gemm(mat(yspec, rows, Kc, split=2 if ybf else 0), mat(_pad_cols(Wi, Kc)), frames, split_k=1)
+        gemm(mat(yspec, rows, Kc, split=2 if ybf else 0), mat(_pad_cols(Wi, Kc)), frames, split_k=1, true_k=Cin)
     if not ola:
         return frames
     if lanes is not None:
@@ -725,7 +725,7 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
         ops.istft_fft_adjoint(gfr, N, F, gy, zero_pad=True)             # (pad columns written as zeros)
     else:
         gy = ops.empty(rows, ldp, device=dev)
-        gemm(mat(gfr, rows, N), mat(_pad_cols(Wi, Kc)), gy, form=1)      # pad columns come out zero
+        gemm(mat(gfr, rows, N), mat(_pad_cols(Wi, Kc)), gy, form=1, true_n=Cin)      # pad columns come out zero
     if lens_f is not None:
         ops.mask_rows(gy, B, F, Cin, lens_f)
     g_wout = ops.zeros(Cin, Cc, device=dev)
@@ -734,7 +734,7 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
     x_last = sv["x_last"]
     ops.wgrad(gy, Cin, ldp, mat(x_last, rows, Cc), g_wout)
     g = ops.empty(rows, Cc, device=dev)
-    gemm(mat(gy, rows, Kc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), g, form=1)
+    gemm(mat(gy, rows, Kc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), g, form=1, true_k=Cin)
     g_te_all = ops.zeros(B, NC, device=dev)
     block_grads = [None] * bv.nblk
     flags = sv["flags"]
@@ -758,12 +758,12 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
     ops.wgrad(gh0, Cc, gh0.stride(0), mat(sv["packed"], rows, Cin), g_win)
     if need_gx:
         gpacked = ops.empty(rows, ldp, device=dev)
-        gemm(mat(gh0, rows, Cc), mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), gpacked, form=1)
+        gemm(mat(gh0, rows, Cc), mat(_pad_cols(bv.w_in.reshape(Cc, Cin), Kc)), gpacked, form=1, true_n=Cin)
         gxf = ops.empty(rows, N, device=dev)
         if ops.fft_applies(N):
             ops.stft_fft_adjoint(gpacked, N, F, gxf)
         else:
-            gemm(mat(gpacked, rows, Kc), mat(_pad_rows(Wd, Kc)), gxf, form=1)
+            gemm(mat(gpacked, rows, Kc), mat(_pad_rows(Wd, Kc)), gxf, form=1, true_k=Cin)
         if lanes is not None:
             lanes.chain_enter()  # g_x is accumulated branch after branch
         ops.frames_fold(gxf, g_x, B, F, N, hop, T, accumulate_gx)

@@ -107,7 +107,9 @@ def _derived(t, tag, build):
             e.pop(oid, None)
         ent = (weakref.ref(owner, _gone), {})
         _DERIVED[oid] = ent
-        _OWNER_EPOCH.pop(oid, None)       # a recycled id: the epoch of a dead tensor
+        # (the epoch of a dead tensor whose id was recycled is dropped by ITS weakref callback above;
+        # nothing is reset here: the optimizer may have bumped this owner before its first copy was
+        # asked for, and weights_signature() needs the counter to never run backwards)
     slot = ent[1]
     key = (tag, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
     stamp = _stamp(owner)
@@ -243,8 +245,11 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
          res=None, ldres: Optional[int] = None, gamma=None, aux=None, ldaux: Optional[int] = None,
          alpha_n=None, colsum_alpha=None, colsum=None, lrelu: float = 0.0, scale: float = 0.0,
          accumulate: bool = False, atomic: bool = False, split_k: int = 0, out_offset: int = 0,
-         rowmap=None, prelu=None, prelu_out=None, mask=None, fm=None, x3_out: bool = False):
+         rowmap=None, prelu=None, prelu_out=None, mask=None, fm=None, x3_out: bool = False,
+         true_k: Optional[int] = None, true_n: Optional[int] = None):
     """Launch f2g_gemm.  rowmap = (P0o, seq_stride_o, row_stride_o, off_o) or None.
+    true_k / true_n: the reduction length / output width WITHOUT zero padding (the spectrum rows are
+    padded to whole K slabs): what bench.py's FLOP count uses; the launch itself ignores them.
     split_k: 0 = let the library decide (forms 0/1: split-K onto a zeroed output when the tile
     grid would leave most of the last wave of CUs idle), 1 = off, > 1 = as given."""
     if form == 1 and LEAN_DGRAD:
@@ -299,22 +304,37 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
             in_kernel = True      # (mid-length reductions on well-filled grids: see X6F)
         if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS \
                 and (A.cols >= X6_MIN_K or in_kernel) and not atomic \
-                and split_k <= 1 and out.dtype == torch.float32 and _x3_window_ok(A) \
-                and L.lib.f2g_gemm_x6_ok(C.byref(d)):
-            if not in_kernel:     # (else gemm_x6f_kernel reads the fp32 operands and splits them itself)
-                d.A, d.B = _x3_operand(A), _x3_operand(Bm)
-            d.precision = 3
+                and split_k <= 1 and out.dtype == torch.float32 and _x3_window_ok(A):
+            # the three-piece image of `out` for the next GEMM, written by this one's epilogue (every
+            # writer of the buffer must do so, or the image is dropped: x3_reserve / _x3_operand).  The
+            # library is asked with the descriptor as it will be launched (f2g_gemm_x6_ok applies the
+            # tests of f2g_gemm's own dispatch, E.x3_out included)
+            buf = getattr(out, "_f2g_x3_buf", None) if x3_out else None
+            if buf is not None and X6F != 1 and not getattr(out, "_f2g_x3_bad", False) \
+                    and out_offset % 32 == 0 and prelu_out is None:
+                d.E.x3_out = ptr(buf) + (out_offset // 32) * 192
+            how = L.lib.f2g_gemm_x6_ok(C.byref(d))
+            if not how and d.E.x3_out:      # (the image's alignment conditions: the GEMM alone may still go)
+                d.E.x3_out = None
+                how = L.lib.f2g_gemm_x6_ok(C.byref(d))
+            if how:
+                if in_kernel and not (how & 4):
+                    # the in-kernel split cannot read these views (alignment / strides): the image
+                    # kernel where the reduction is long enough for it, else the exact fp32 MFMA
+                    in_kernel = False
+                    how = how if A.cols >= X6_MIN_K else 0
+                if how:
+                    if not in_kernel:   # (else gemm_x6f_kernel reads the fp32 operands and splits them itself)
+                        d.A, d.B = _x3_operand(A), _x3_operand(Bm)
+                    d.precision = 3
+            if d.precision != 3:
+                d.E.x3_out = None
         if form == 2 and X6_WGRAD and atomic and A.split == 0 and Bm.split == 0 and A.lrelu_src is None \
                 and A.rows >= X6_MIN_K and L.lib.f2g_gemm_lean_ok(C.byref(d)):
             d.precision = 3       # weight gradient: gemm_leanw6_kernel splits the fp32 operands itself
         if x3_out:
-            # the three-piece image of `out` for the next GEMM, written by this one's epilogue (every
-            # writer of the buffer must do so, or the image is dropped: x3_reserve / _x3_operand)
-            buf = getattr(out, "_f2g_x3_buf", None)
-            if d.precision == 3 and X6F != 1 and buf is not None and not getattr(out, "_f2g_x3_bad", False) \
-                    and out_offset % 32 == 0 and prelu_out is None:
-                d.E.x3_out = ptr(buf) + (out_offset // 32) * 192
-                out._f2g_x3 = buf
+            if d.E.x3_out:
+                out._f2g_x3 = out._f2g_x3_buf
             else:
                 out._f2g_x3_bad = True
     if ((GEMM_PRECISION == 1 and form in (0, 2)) or (GEMM_PRECISION == 2 and form == 0)) and LEAN_SPLIT:
@@ -328,7 +348,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
             # the K loop); weights come from the derived-weight cache, activations are split here
             d.A, d.B = _split_operand(A), _split_operand(Bm)
     if GEMM_TIMER is not None:
-        GEMM_TIMER.launch(d, A, Bm, form)
+        GEMM_TIMER.launch(d, A, Bm, form, true_k, true_n)
     else:
         call("f2g_gemm", C.byref(d))
     return out
@@ -741,6 +761,12 @@ class GemmTimer:
             a[2] += s.elapsed_time(e) * 1e-3
         return out
 
+    def algorithmic_bytes(self, path: str) -> float:
+        """Sum over a family's launches of the bytes the implicit GEMM must move once: both operands
+        read, the result written (4 bytes per element; im2col windows counted as the rows they gather)."""
+        return float(sum(4.0 * (m * k + n * k + m * n)
+                         for (f, m, n, k), pth in zip(self.shapes, self.paths) if pth == path))
+
     def hbm_summary(self):
         """{kernel: (launches, algorithmic bytes, seconds)} -- after a device synchronise."""
         out = {}
@@ -751,13 +777,13 @@ class GemmTimer:
             a[2] += s.elapsed_time(e) * 1e-3
         return out
 
-    def launch(self, d, A, Bm, form):
-        if form == 2:
-            flops = 2.0 * A.rows * A.cols * Bm.cols
-        elif form == 1:
-            flops = 2.0 * A.rows * A.cols * Bm.cols
-        else:
-            flops = 2.0 * A.rows * A.cols * Bm.rows
+    def launch(self, d, A, Bm, form, true_k=None, true_n=None):
+        # the implicit GEMM (M, N, K) this launch stands for, zero padding of the operands not counted
+        nn = Bm.rows if form == 0 else Bm.cols
+        mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
+        kk = min(kk, true_k) if true_k else kk
+        nn = min(nn, true_n) if true_n else nn
+        flops = 2.0 * mm * nn * kk
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
@@ -765,10 +791,8 @@ class GemmTimer:
         e.record()
         self.records.append((s, e, flops))
         self.paths.append(("generic", "lean", "lean-streamk", "narrow", "x6")[L.lib.f2g_gemm_last_path()])
-        if self.paths[-1] == "x6" and form == 0 and d.A.split == 3 and L.lib.f2g_gemm_x6_ok(C.byref(d)) == 3:
+        if self.paths[-1] == "x6" and form == 0 and d.A.split == 3 and (L.lib.f2g_gemm_x6_ok(C.byref(d)) & 2):
             self.x6_tap = getattr(self, "x6_tap", 0) + 1      # (launches on the tap-walking instance)
-        nn = Bm.rows if form == 0 else Bm.cols
-        mm, kk = (A.cols, A.rows) if form == 2 else (A.rows, A.cols)
         self.shapes.append((form, mm, nn, kk))
 
     def time(self, fn, flops: float, shape, path: str = "direct-conv"):

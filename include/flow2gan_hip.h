@@ -180,9 +180,13 @@ int f2g_to_bf16(void* dst, const float* src, int64_t n, f2g_stream_t stream);
  * row and 32-element slab.  f2g_gemm with precision = 3 takes form 0 descriptors whose operands are BOTH
  * given as such images (f2g_operand.split = 3, rows / cols = the logical extents; B a plain matrix, A a
  * plain matrix or halo-map windows, see f2g_operand.split);
- * f2g_gemm_x6_ok(d) says whether a descriptor over the fp32 tensors would qualify (1; 3 when the image
- * kernel's tap-walking instance applies: stride-1 conv windows of 5 or 2 positions over a halo map, whose
- * positions a tile stages once per 32-channel slab).  All epilogues of the
+ * f2g_gemm_x6_ok(d) applies the tests of f2g_gemm's own precision-3 dispatch to a form-0 descriptor
+ * (E.x3_out included: set it before asking) and returns a bit mask, 0 = not at precision 3: bit 0 = over
+ * three-piece images of both operands (also reported for the fp32 tensors the images would be made
+ * of), bit 1 = and then on the image kernel's tap-walking instance (stride-1 conv windows of 5 or 2
+ * positions over a halo map, whose positions a tile stages once per 32-channel slab), bit 2 = over the
+ * fp32 operands exactly as handed over (split = 0: the instance that splits inside the kernel; its
+ * alignment / stride conditions hold).  All epilogues of the
  * generic kernel apply (bias, residual, PReLU with both outputs, PReLU backward with column sums, ...). */
 int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K);
 int f2g_split_bf16x3(void* dst, const float* src, int64_t ld, int32_t rows, int32_t K, f2g_stream_t stream);

@@ -82,11 +82,15 @@ def golden():
     return load
 
 
-# The golden parity modules (generator, GAN stage) run twice: with exact-fp32 GEMMs (the headline
-# mode) and with the split-bf16 fast mode (F2G_GEMM=bf16x3: pre-split operands, 3 bf16 MFMAs per
-# product), so that the driver's single run covers both.  An explicit F2G_GEMM in the environment
-# pins the whole run to that mode instead.
-_GEMM_MODES = [os.environ["F2G_GEMM"]] if os.environ.get("F2G_GEMM") else ["fp32", "bf16x3"]
+# The golden parity modules (generator, GAN stage) run three times: with exact-fp32 GEMMs (the
+# headline mode), with the fp32-CLASS mode (F2G_GEMM=bf16x6: three bf16 pieces per operand, six bf16
+# MFMAs per product -- held to the SAME tolerances as exact fp32) and with the split-bf16 fast mode
+# (F2G_GEMM=bf16x3: two pieces, 3 MFMAs per product; looser gradient bounds, written in the tests),
+# so that the driver's single run covers all of them.  An explicit F2G_GEMM in the environment pins
+# the whole run to that mode instead.
+_GEMM_MODES = [os.environ["F2G_GEMM"]] if os.environ.get("F2G_GEMM") else ["fp32", "bf16x6", "bf16x3"]
+# the modes that claim the exact-fp32 tolerances (tests/test_hip_round3.py: trajectory, full test mel)
+_EXACT_MODES = [m for m in _GEMM_MODES if m in ("fp32", "bf16x6", "3")] or _GEMM_MODES[:1]
 
 
 @pytest.fixture(params=_GEMM_MODES)
@@ -95,6 +99,19 @@ def gemm_mode(request):
 
     was = ops.GEMM_PRECISION
     ops.set_gemm_precision({"split": "bf16x3", "1": "bf16x3", "2": "bf16", "3": "bf16x6"}.get(request.param, request.param))
+    try:
+        yield request.param
+    finally:
+        ops.GEMM_PRECISION = was
+
+
+@pytest.fixture(params=_EXACT_MODES)
+def gemm_mode_exact(request):
+    """exact fp32 and the fp32-class bf16x6 mode: both are held to the exact-fp32 tolerances."""
+    from flow2gan_amd import ops
+
+    was = ops.GEMM_PRECISION
+    ops.set_gemm_precision({"3": "bf16x6"}.get(request.param, request.param))
     try:
         yield request.param
     finally:

@@ -241,14 +241,17 @@ def test_concurrent_lanes_match_serial_launch_order(f2g, golden, monkeypatch):
                 assert relerr(got[key][k], v) < 2e-4, (key, k, relerr(got[key][k], v))
 
 
-@pytest.mark.parametrize("model_name,Tn,rep", [("mel_24k_base", 24000, 32),
-                                               ("mel_44k_128band_512x_base", 44100, 16)],
-                         ids=["24k_B64_T24000", "44k_B32_T44100"])
-def test_full_width_gan_steps_vs_oracle_then_full_batch(f2g, monkeypatch, model_name, Tn, rep):
+@pytest.mark.parametrize("model_name,Tn,rep,nts", [("mel_24k_base", 24000, 32, 1),
+                                                   ("mel_44k_128band_512x_base", 44100, 16, 1),
+                                                   ("mel_24k_base", 24000, 0, 4)],
+                         ids=["24k_B64_T24000", "44k_B32_T44100", "24k_B2_T24000_n4"])
+def test_full_width_gan_steps_vs_oracle_then_full_batch(f2g, monkeypatch, model_name, Tn, rep, nts):
     """Full-width GAN stage: D-step and G-step losses + selected gradients against the CPU oracle
     at B=2, then at the BASELINE batch (B=64 x 1 s for mel_24k_base = config 4's per-GPU shape;
     B=32 x 1 s of 44.1 kHz audio for mel_44k_128band_512x_base = config 5) as copies of that batch: every loss is a batch mean and
-    every sample is independent, so losses and gradients must not move."""
+    every sample is independent, so losses and gradients must not move.  The third case unrolls
+    n_timesteps = 4 Euler steps inside both steps (gan.py:138-143: the G-step backpropagates through
+    all four model evaluations; SURVEY 8d config 4 names n in {1, 4}) at B = 2 against the oracle."""
     import flow2gan_oracle as O
     from flow2gan_amd.models.config import get_generator_config
     from flow2gan_amd.models.gan import GAN
@@ -277,11 +280,11 @@ def test_full_width_gan_steps_vs_oracle_then_full_batch(f2g, monkeypatch, model_
                "estimators.2.decoder.out_proj.weight"]
     # oracle
     ogan.zero_grad()
-    od = ogan(mel, audio, lens, 1, True, noise=noise)
+    od = ogan(mel, audio, lens, nts, True, noise=noise)
     (od[0] + 0.1 * od[1]).backward()
     od_g = {k: dict(ogan.discriminator.named_parameters())[k].grad.clone() for k in d_names}
     ogan.zero_grad()
-    ogl = ogan(mel, audio, lens, 1, False, noise=noise)
+    ogl = ogan(mel, audio, lens, nts, False, noise=noise)
     sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ogl)).backward()
     og_g = {k: dict(ogan.generator.named_parameters())[k].grad.clone() for k in g_names}
 
@@ -289,11 +292,11 @@ def test_full_width_gan_steps_vs_oracle_then_full_batch(f2g, monkeypatch, model_
         a, m_, n_, ln = (audio.to(DEV).repeat(rep, 1), mel.to(DEV).repeat(rep, 1, 1),
                          noise.to(DEV).repeat(rep, 1), lens.repeat(rep))
         gan.zero_grad()
-        d = gan(m_, a, ln, 1, True, noise=n_)
+        d = gan(m_, a, ln, nts, True, noise=n_)
         (d[0] + 0.1 * d[1]).backward()
         dg = {k: dict(gan.discriminator.named_parameters())[k].grad.detach().cpu().clone() for k in d_names}
         gan.zero_grad()
-        ls = gan(m_, a, ln, 1, False, noise=n_)
+        ls = gan(m_, a, ln, nts, False, noise=n_)
         sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ls)).backward()
         gg = {k: dict(gan.generator.named_parameters())[k].grad.detach().cpu().clone() for k in g_names}
         return [float(v.detach()) for v in d], [float(v.detach()) for v in ls], dg, gg
@@ -311,6 +314,8 @@ def test_full_width_gan_steps_vs_oracle_then_full_batch(f2g, monkeypatch, model_
         assert near(dg2[k], od_g[k], gtol), ("D", k, relerr(dg2[k], od_g[k]))
     for k in g_names:
         assert near(gg2[k], og_g[k], gtol), ("G", k, relerr(gg2[k], og_g[k]))
+    if not rep:
+        return
     d64, l64, dg64, gg64 = run(rep)   # the BASELINE batch
     assert np.allclose(d64, d2, rtol=2e-5, atol=1e-6), (d64, d2)
     assert np.allclose(l64, l2, rtol=5e-5, atol=1e-6), (l64, l2)

@@ -161,7 +161,7 @@ def _overlap_worker(rank, world, port, out):
     sent_during_backward = []
     red = fdist.GradReducer(bucket_mb=0.012)  # ~3 buckets
     ok = True
-    for it in range(2):  # second pass re-uses the arenas and must not accumulate stale values
+    for it in range(3):  # later passes re-use the arenas and must not accumulate stale values
         red.prepare(params)
         loss = net(xs[rank]).pow(2).mean()
         loss.backward()
@@ -169,10 +169,15 @@ def _overlap_worker(rank, world, port, out):
         moved = red.finish()
         ok = ok and all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7)
                         for p, w in zip(net.parameters(), want))
-        ok = ok and unused.grad is None
-        ok = ok and moved == 4 * sum(p.numel() for p in params)  # arenas travel whole
-    ok = ok and len(red._plans) == 1 and len(next(iter(red._plans.values())).buckets) >= 3
-    ok = ok and all(n >= 2 for n in sent_during_backward)  # left from the autograd hooks
+        ok = ok and unused.grad is None          # used by no rank: None, as without the reducer
+        # arenas travel whole: the gradients + one "used" flag per parameter
+        ok = ok and moved == 4 * (sum(p.numel() for p in params) + len(params))
+    plan = next(iter(red._plans.values()))
+    ok = ok and len(red._plans) == 1 and len(plan.buckets) >= 3
+    # the first step of a plan records the completion order and sends at finish(); from then on
+    # the buckets leave from the autograd hooks, in the order the ranks agreed on
+    ok = ok and sent_during_backward[0] == 0 and all(n >= 2 for n in sent_during_backward[1:])
+    ok = ok and plan.order is not None and sorted(plan.order) == list(range(len(plan.buckets)))
     # a second backward inside one prepare()/finish() pair must fail loudly, not diverge silently
     red.prepare(params)
     net(xs[rank]).pow(2).mean().backward()
@@ -210,7 +215,7 @@ def _sink_worker(rank, world, port, out):
     params = rest + [p for b in branches for p in b]          # model order: rest first
     red = fdist.GradReducer(bucket_mb=1.0)
     ok = True
-    for it in range(2):
+    for it in range(3):
         red.prepare(params, groups=branches)
         sink = fused.GRAD_SINK
         ok = ok and sink is not None
@@ -233,10 +238,15 @@ def _sink_worker(rank, world, port, out):
         red.finish()
         ok = ok and fused.GRAD_SINK is None
         b_of = lambda p: plan.bucket_of[id(p)].index
-        ok = ok and sent_before_second_use == [b_of(branches[2][0]), b_of(branches[1][0])]
-        ok = ok and sent_by_branches == sent_before_second_use + [b_of(branches[0][0])]
-        ok = ok and order[-1] == b_of(rest[0]) and len(order) == 4
-        ok = ok and len({b_of(p) for b in branches for p in b} | {b_of(rest[0])}) == 4
+        want_order = [b_of(branches[2][0]), b_of(branches[1][0]), b_of(branches[0][0]), b_of(rest[0])]
+        if it == 0:
+            # a plan's first step only records the order (and the ranks agree on it at finish())
+            ok = ok and order == [] and plan.order == want_order
+        else:
+            ok = ok and sent_before_second_use == want_order[:2]
+            ok = ok and sent_by_branches == want_order[:3]
+            ok = ok and order == want_order
+        ok = ok and len(set(want_order)) == 4 and len(plan.sent_order) == 4
         for i, b in enumerate(branches):
             want = 1.5 * (3.0 if i == 0 else 1.0)     # mean over ranks of (rank+1) * sum of uses
             ok = ok and all(torch.allclose(p.grad, torch.full_like(p, want)) for p in b)
@@ -249,6 +259,68 @@ def test_branch_buckets_leave_before_the_rest_world_size_2_gloo(tmp_path):
     from _mp import run_workers
     run_workers("test_host_side", "_sink_worker", 2, str(tmp_path), timeout=120.0)
     assert torch.load(tmp_path / "sink0.pt") and torch.load(tmp_path / "sink1.pt")
+
+
+def _unused_worker(rank, world, port, out):
+    """The case the reference covers with DDP's find_unused_parameters=True (finetune.py:915): in one
+    step a whole group gets no gradient on ONE rank only.  Nothing may hang; every bucket still travels
+    on both ranks in the agreed order; the rank without the gradient ends with the ranks' mean (its own
+    contribution being zero), and a parameter no rank used comes back as None on both."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from flow2gan_amd import dist as fdist
+    from flow2gan_amd import fused
+    fdist.setup_dist(rank, world, backend="gloo")
+    torch.manual_seed(0)
+    branches = [[torch.nn.Parameter(torch.randn(n)) for n in sizes] for sizes in ((40, 7), (30,), (20, 5))]
+    rest = [torch.nn.Parameter(torch.randn(9)), torch.nn.Parameter(torch.randn(4))]
+    nobody = torch.nn.Parameter(torch.randn(3))
+    params = rest + [nobody] + [p for b in branches for p in b]
+    red = fdist.GradReducer(bucket_mb=1.0)
+    ok = True
+    for it in range(4):
+        skip = {1} if (it == 2 and rank == 1) else set()      # step 2: rank 1 never runs branch 1
+        if it == 3 and rank == 0:
+            skip = {0, 2}                                      # step 3: rank 0 runs branch 1 only
+        red.prepare(params, groups=branches)
+        sink = fused.GRAD_SINK
+        plan = red._active
+        keys = {i: sink.add_use(branches[i]) for i in range(3) if i not in skip}
+        for i in (2, 1, 0):
+            if i not in skip:
+                sink.deliver(keys[i], branches[i], [torch.full_like(p, float(rank + 1)) for p in branches[i]])
+        sum((p * float(rank + 1)).sum() for p in rest).backward()
+        moved = red.finish()
+        ok = ok and len(plan.sent_order) == len(plan.buckets)           # every bucket, every step
+        ok = ok and moved == 4 * (sum(p.numel() for p in params) + len(params))
+        ok = ok and nobody.grad is None
+        for i, b in enumerate(branches):
+            ranks_with = [r for r in range(world)
+                          if not ((it == 2 and r == 1 and i == 1) or (it == 3 and r == 0 and i in (0, 2)))]
+            want = sum(float(r + 1) for r in ranks_with) / world
+            ok = ok and all(p.grad is not None and torch.allclose(p.grad, torch.full_like(p, want)) for p in b)
+        ok = ok and all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in rest)
+    # one use with a ticket and one that reaches the parameter through autograd, in one backward:
+    # the group's bucket has left when autograd's gradient arrives -- that must fail loudly
+    red.prepare(params, groups=branches)
+    sink = fused.GRAD_SINK
+    keys = [sink.add_use(b) for b in branches]
+    for i in (2, 1, 0):
+        sink.deliver(keys[i], branches[i], [torch.full_like(p, 1.0) for p in branches[i]])
+    try:
+        (sum(p.sum() for p in rest) + branches[2][0].sum()).backward()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "ticket" in str(e)
+    red.finish()
+    torch.save(ok, os.path.join(out, f"unused{rank}.pt"))
+    fdist.cleanup_dist()
+
+
+def test_group_without_gradient_on_one_rank_world_size_2_gloo(tmp_path):
+    from _mp import run_workers
+    run_workers("test_host_side", "_unused_worker", 2, str(tmp_path), timeout=120.0)
+    assert torch.load(tmp_path / "unused0.pt") and torch.load(tmp_path / "unused1.pt")
 
 
 def test_gan_stepper_schedule_matches_reference():

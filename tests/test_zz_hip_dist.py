@@ -133,6 +133,9 @@ def test_bench_step_under_torchrun_with_two_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    # the N > 1 line checks itself: ranks counted by an all-reduce, backend, bytes per step, exposed wait
+    assert d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["comm_bytes_per_step"] > 4 * 100e6 and d["exposed_comm_ms"] >= 0.0   # D 170 MB + G 316 MB
     # whole-job aggregate: both ranks' audio over the max-over-ranks time
     assert abs(d["value"] - 2 * 2 * 4 * 1.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
 
@@ -173,10 +176,15 @@ def _rccl_single(rank, world, port, outdir):
     gan, logmel = _build()
     plain = _steps(gan, logmel, 0, fdist.GradReducer())            # world 1, not forced: no exchange
     spy = _SpyReducer(bucket_mb=8.0, force=True)
-    got = _steps(gan, logmel, 0, spy)
+    first = _steps(gan, logmel, 0, spy)       # a plan's first step records the completion order and
+    got = _steps(gan, logmel, 0, spy)         # sends at finish(); from the second on buckets leave early
     torch.cuda.synchronize()
     assert fused.GRAD_SINK is None
-    (d_order, d_n, d_plan), (g_order, g_n, g_plan) = spy.log
+    assert spy.log[0][0] == [] and spy.log[1][0] == [], spy.log[:2]
+    for name in ("D", "G"):
+        for k, v in got[name].items():
+            assert float((v - first[name][k]).abs().max()) <= 2e-4 * (float(v.abs().max()) + 1e-9), (name, k)
+    (d_order, d_n, d_plan), (g_order, g_n, g_plan) = spy.log[2:]
     # every bucket had left before finish(): from a lane's hand-over or an autograd hook
     assert sorted(d_order) == list(range(d_n)) and sorted(g_order) == list(range(g_n)), (d_order, g_order)
     assert d_n >= 6 and g_n >= 4

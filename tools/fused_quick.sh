@@ -1,4 +1,6 @@
+#!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
 cd $R
 python3 tools/fused_multi_bench.py 2>&1 | grep -v amdgpu.ids
 python3 tools/fused_mlp_bench.py 2>&1 | grep -v amdgpu.ids | head -8

@@ -1,5 +1,7 @@
+#!/bin/bash
 # tile heights of the fused block kernel: single launches (F2G_MLP_RT) and the multi-branch launch
 R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
 cd $R
 {
 for rt in 0 1 2 3 4; do echo "## F2G_MLP_RT=$rt"; F2G_MLP_RT=$rt python3 tools/fused_multi_bench.py 2>&1 | grep -v amdgpu.ids | grep "alone\|serial"; done

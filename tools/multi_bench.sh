@@ -1,6 +1,8 @@
+#!/bin/bash
 # bf16 4-step inference: layer-synchronous multi-branch block launches / time paths computed ahead
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
+mkdir -p $R/gpurun_out
 cd $R
 run() { echo "# $*"; env "$@" python3 bench.py $BA --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-fast-mode 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['value'])"; }
 {
