@@ -188,21 +188,47 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, 
     assert np.allclose([float(v) for v in ls], want, rtol=5e-5, atol=2e-5), ([float(v) for v in ls], want)
     total = sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ls))
     total.backward()
-    worst = []
+    from flow2gan_amd import ops as _ops
+    worst, refs = [], {}
     for k, p in gan.generator.named_parameters():
         ref = T(g[f"{tag}/G/g/{k}"])
         assert p.grad is not None, k
+        refs[k] = ref
         worst.append((relerr(p.grad, ref), k))
     worst.sort(reverse=True)
-    from flow2gan_amd import ops as _ops
-    # exact-fp32 GEMMs: 5e-3 of each gradient's max.  The opt-in split-bf16 mode perturbs activations
-    # by ~1e-5, which flips some sign() terms of the L1 / hinge / leaky-ReLU gradients (they are
-    # discontinuous), so its G-step gradients are only held to 1e-1 of their max.
-    # (a flipped pixel on the generated input's path reaches every generator gradient)
-    # (n = 2 at 44.1 kHz: 0.26 - 0.37 on a BiasNorm log_scale scalar, a sum of such sign terms --
-    # which pixels flip depends on the order of the atomic accumulations, i.e. on the run)
-    g_tol = 5e-1 if _ops.GEMM_PRECISION == 1 else (5e-2 if flips["fake"] else 5e-3)
-    assert worst[0][0] < g_tol, (worst[:8], sorted(flips["fake"]))
+    if _ops.GEMM_PRECISION != 1:
+        # exact-fp32 and fp32-class (bf16x6) GEMMs: 5e-3 of each gradient's max (5e-2 when a pixel of
+        # the generated input's path sits on a leaky-ReLU kink: it reaches every generator gradient)
+        g_tol = 5e-2 if flips["fake"] else 5e-3
+        assert worst[0][0] < g_tol, (worst[:8], sorted(flips["fake"]))
+        return
+    # The opt-in split-bf16 mode perturbs the generated waveform by ~1e-5, which flips sign() terms of
+    # the L1 / hinge / leaky-ReLU gradients (they are discontinuous).  What a flipped pixel adds to a
+    # parameter's gradient is small against the gradients of that KIND of parameter, but it can be
+    # large against a gradient that is itself the small remainder of cancelling terms (a BiasNorm
+    # log_scale scalar: 0.31 of its own value in the 44.1 kHz n = 2 case, 0.02 of the largest
+    # log_scale gradient; tools/dbg/g_grad_split.py, deterministic from run to run).  So the bound is
+    # kink-aware in what it normalises by -- every tensor to 0.15 of the largest gradient among the
+    # tensors of its kind (measured worst: 0.083; 0.005 in the three other cases), all generator
+    # gradients together to 0.12 in relative L2 (measured 0.066 / 2e-3 / 6e-4 / 5e-5), and as a
+    # backstop each tensor to 0.5 of its own maximum: a sign error or a broken layer on a tensor
+    # that matters fails the first two, on any tensor the third.
+    def kind(k):
+        return k.split(".")[-2] + ".scale" if k.endswith("scale") else k.split(".")[-1]
+    kind_max = {}
+    for k, ref in refs.items():
+        kind_max[kind(k)] = max(kind_max.get(kind(k), 0.0), float(ref.abs().max()))
+    err2 = ref2 = 0.0
+    by_kind = []
+    for k, p in gan.generator.named_parameters():
+        dlt = p.grad.detach().cpu().double() - refs[k].double()
+        err2 += float(dlt.pow(2).sum())
+        ref2 += float(refs[k].double().pow(2).sum())
+        by_kind.append((float(dlt.abs().max()) / (kind_max[kind(k)] + 1e-12), k))
+    by_kind.sort(reverse=True)
+    assert by_kind[0][0] < 0.15, (by_kind[:8], sorted(flips["fake"]))
+    assert (err2 / ref2) ** 0.5 < 0.12, ((err2 / ref2) ** 0.5, worst[:8])
+    assert worst[0][0] < 0.5, (worst[:8], sorted(flips["fake"]))
 
 
 def test_concurrent_lanes_match_serial_launch_order(f2g, golden, monkeypatch):
