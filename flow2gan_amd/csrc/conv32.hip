@@ -797,6 +797,166 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_wgrad_kernel(const f2g_conv3
   }
 }
 
+// ---- weight gradient, double-buffered (round 4; exact fp32) ----------------------------------------
+// conv32_s2_wgrad_kernel above keeps the matrix pipe 64 % busy (PMC, profiles/r04_pmc_lean_fp32.txt):
+// a block stages a tile with nothing to overlap it but the CU's other block -- launched in the same
+// phase -- and two barriers bracket every tile.  Same decomposition here (wave w owns taps w, w + 8,
+// w + 16 over the whole tile and tile row w of taps 24..26; single-float fragment reads at per-lane bases +
+// immediate offsets), but ONE block of 8 waves per CU with TWO staged tiles in its 147 KB of LDS: the
+// next tile's rows (9 x 16 bytes per thread) are requested before the current tile's 216 MFMAs per wave
+// and stored into the other buffer behind them; one barrier per tile.  (Four waves with seven taps each
+// and two blocks per CU -- no shared taps at all -- need 112 accumulator + 68 staging registers: spills.)
+template <int TH_, int TW_>
+__global__ __launch_bounds__(512, 1) void conv32_s2_wgrad_p_kernel(const f2g_conv32_desc d, float* gw,
+                                                                   int tiles_h, int tiles_w,
+                                                                   int tiles_per_block) {
+  // tiles of 8 x 16 or 16 x 8 output pixels (the launcher takes the shape that wastes fewer columns of
+  // the band); a k step = two neighbouring columns of a tile row in both
+  constexpr int IHv = TH_ + KH - 1, IWv = TW_ + (KW - 1) / 2, XW = 2 * IWv - 1;
+  constexpr int SUBv = IHv * IWv * PITCH + 16;
+  constexpr int XCH = (IHv * XW * (C / 4) + 511) / 512;    // 7 patch chunks per thread
+  constexpr int GCH = TH_ * TW_ * (C / 4) / 512;           // 2 gradient chunks per thread
+  constexpr int BUF = 2 * SUBv + GT;                       // floats of one staged tile
+  static_assert(TH_ * TW_ == 128 && (XW == 39 || XW == 23), "tile shapes of the magic divisions below");
+  auto pxo = [](int px) { return ((px / TW_) * IWv + (px % TW_)) * PITCH; };   // patch offset of tile pixel px
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int c4 = tid & 7, px0 = tid >> 3;
+  const int ntiles = d.S * tiles_h * tiles_w;
+  f32x16 acc[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  int tb[3], ts[3];               // per-lane patch offsets of the owned / shared taps (k slot hh = pixel parity)
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int t = wave + 8 * a;
+    int dh = t / KW, j = t - dh * KW;
+    tb[a] = (j & 1) * SUBv + (dh * IWv + (j >> 1)) * PITCH + li + hh * PITCH;
+    t = 24 + a;
+    dh = t / KW;
+    j = t - dh * KW;
+    ts[a] = (j & 1) * SUBv + (dh * IWv + (j >> 1)) * PITCH + li + hh * PITCH;
+  }
+  const int gb = 2 * SUBv + hh * C + li;
+  auto tile_pos = [&](int ti, int& s, int& h0, int& w0) {
+    s = ti / (tiles_h * tiles_w);
+    const int rem = ti - s * (tiles_h * tiles_w);
+    const int th = rem / tiles_w;
+    h0 = th * TH_;
+    w0 = (rem - th * tiles_w) * TW_;
+  };
+  // chunk q of this thread: patch pixel px0 + 64 q = (row r, column xr), recomputed per tile
+  auto load_tile = [&](int ti, f32x4 (&pxr)[XCH], f32x4 (&pgr)[GCH]) {
+    int s, h0, w0;
+    tile_pos(ti, s, h0, w0);
+    const int x0 = 2 * w0 - (KW - 1) / 2;
+    const float* org = d.x + (long long)s * d.x_seq + (long long)(h0 - 1) * d.x_line + (long long)x0 * C + c4 * 4;
+#pragma unroll
+    for (int q = 0; q < XCH; ++q) {
+      const int px = px0 + 64 * q;
+      const int r = (px * (XW == 39 ? 1681 : 2850)) >> 16, xr = px - r * XW;     // px / XW for px < 512
+      const int h = h0 - 1 + r, x = x0 + xr;
+      const bool ok = px < IHv * XW && h >= 0 && h < d.H && x >= 0 && x < d.Win;
+      pxr[q] = *reinterpret_cast<const f32x4*>(ok ? org + (long long)r * d.x_line + xr * C : c32_zero);
+    }
+    const float* gs = d.y + (long long)s * d.y_seq + c4 * 4;
+#pragma unroll
+    for (int q = 0; q < GCH; ++q) {
+      const int px = px0 + 64 * q;
+      const int h = h0 + px / TW_, w = w0 + px % TW_;
+      const bool ok = h < d.H && w < d.Wout;
+      pgr[q] = *reinterpret_cast<const f32x4*>(ok ? gs + (long long)h * d.y_line + (long long)w * C : c32_zero);
+    }
+  };
+  auto store_tile = [&](float* buf, const f32x4 (&pxr)[XCH], const f32x4 (&pgr)[GCH]) {
+#pragma unroll
+    for (int q = 0; q < XCH; ++q) {
+      const int px = px0 + 64 * q;
+      const int r = (px * (XW == 39 ? 1681 : 2850)) >> 16, xr = px - r * XW;
+      if (px < IHv * XW)
+        *reinterpret_cast<f32x4*>(buf + (xr & 1) * SUBv + (r * IWv + (xr >> 1)) * PITCH + c4 * 4) = pxr[q];
+    }
+#pragma unroll
+    for (int q = 0; q < GCH; ++q)
+      *reinterpret_cast<f32x4*>(buf + 2 * SUBv + (px0 + 64 * q) * C + c4 * 4) = pgr[q];
+  };
+  const int t0 = blockIdx.x * tiles_per_block;
+  int tend = t0 + tiles_per_block;
+  if (tend > ntiles) tend = ntiles;
+  if (t0 >= tend) return;
+  {
+    f32x4 pxr[XCH], pgr[GCH];
+    load_tile(t0, pxr, pgr);
+    store_tile(sm, pxr, pgr);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int ti = t0; ti < tend; ++ti) {
+    const bool more = ti + 1 < tend;
+    const float* T = sm + cur * BUF;
+    f32x4 pxr[XCH], pgr[GCH];
+    load_tile(more ? ti + 1 : ti, pxr, pgr);      // (the last tile re-requests its own: never stored)
+    // taps owned over the whole tile: 64 k steps of two pixels
+#pragma unroll
+    for (int st = 0; st < TH_ * TW_ / 2; ++st) {
+      const float a = T[gb + st * 2 * C];
+      const int po = pxo(2 * st);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, T[tb[q] + po], acc[q], 0, 0, 0);
+    }
+    // taps 24..26: this wave's 16 pixels (8 k steps); pixel index = 16*wave + 2*st + hh
+    {
+      const float* Gw = T + gb + wave * 16 * C;
+      const int pbase = pxo(16 * wave);        // the wave's 16 pixels: tile row `wave`, or rows 2 wave, 2 wave + 1
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const float a = Gw[st * 2 * C];
+        const int po = pbase + pxo(2 * st);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          acc[3 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, T[ts[q] + po], acc[3 + q], 0, 0, 0);
+      }
+    }
+    // the other buffer was last read in the previous iteration, which every wave left through the barrier below
+    if (more) store_tile(sm + (cur ^ 1) * BUF, pxr, pgr);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- flush: taps owned by one wave go straight out; the three shared taps are summed over the
+  // waves through LDS first
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int t = wave + 8 * q;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+      atomicAdd(gw + co * (KH * KW * C) + t * C + li, acc[q][e]);
+    }
+  }
+  float* red = sm;   // [8 waves][16][64]
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[3 + q][e];
+    __syncthreads();
+    if (wave == q) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += red[(w8 * 16 + e) * 64 + lane];
+        const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        atomicAdd(gw + co * (KH * KW * C) + (24 + q) * C + li, v);
+      }
+    }
+  }
+}
+
 // ---- weight gradient, split-bf16 ---------------------------------------------------------------
 // Same decomposition as conv32_s2_wgrad_kernel (MFMA rows = co, columns = ci, reduction = the pixels
 // of an 8 x 16 output tile; wave w owns taps w, w+8, w+16 over the whole tile and tile row w of taps
@@ -955,13 +1115,19 @@ __global__ __launch_bounds__(512, 2) void conv32_s2_wgrad3_kernel(const f2g_conv
 
 }  // namespace
 
+// precision 3 (fp32-class products on the bf16 pipe): conv32x6.hip
+int f2g_conv32_fwd6_launch(const f2g_conv32_desc* d, hipStream_t st);
+int f2g_conv32_dgrad6_launch(const f2g_conv32_desc* d, hipStream_t st);
+int f2g_conv32_wgrad6_launch(const f2g_conv32_desc* d, float* gw, hipStream_t st);
+
 extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
   if (!d || !d->x || !d->w || !d->y) return F2G_EINVAL;
   if (d->S <= 0 || d->H <= 0 || d->Wout <= 0) return F2G_OK;
   if (d->Wout != (d->Win + 8 - 9) / 2 + 1) return F2G_EINVAL;
-  if (d->precision != 0 && d->precision != 1) return F2G_EINVAL;
+  if (d->precision != 0 && d->precision != 1 && d->precision != 3) return F2G_EINVAL;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
+  if (d->precision == 3) return f2g_conv32_fwd6_launch(d, (hipStream_t)stream);   // w = f2g_split_bf16x3 image
   const size_t smem = (size_t)(2 * SUB + 2 * TG * WB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1018,7 +1184,8 @@ extern "C" int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream
   if (d->Wout != (d->Win + 8 - 9) / 2 + 1) return F2G_EINVAL;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
-  if (d->precision != 0 && d->precision != 1) return F2G_EINVAL;
+  if (d->precision != 0 && d->precision != 1 && d->precision != 3) return F2G_EINVAL;
+  if (d->precision == 3) return f2g_conv32_dgrad6_launch(d, (hipStream_t)stream);  // w = image of wT (864 x 32)
   const size_t smem = (size_t)(GSUB + 2 * TG * WB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1076,6 +1243,7 @@ extern "C" int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stre
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->y) || (d->x_line & 3) || (d->x_seq & 3) || (d->y_line & 3) || (d->y_seq & 3))
     return F2G_EINVAL;
+  if (d->precision == 3) return f2g_conv32_wgrad6_launch(d, gw, (hipStream_t)stream);   // operands split while staged
   const int tiles_h = (d->H + TH - 1) / TH, tiles_w = (d->Wout + TW - 1) / TW;
   const int ntiles = d->S * tiles_h * tiles_w;
   int per = (ntiles + 511) / 512;   // <= 512 blocks (two per CU): bounds the atomics
@@ -1099,6 +1267,38 @@ extern "C" int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stre
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_wgrad_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
+  }
+  static const bool persistent = !(getenv("F2G_CONV32_WGRAD_V2") && atoi(getenv("F2G_CONV32_WGRAD_V2")) == 0);
+  if (persistent && d->x_line < (1ll << 24)) {
+    auto waste = [&](int th, int tw) {
+      return (long long)((d->H + th - 1) / th * th) * ((d->Wout + tw - 1) / tw * tw);
+    };
+    const bool tall = waste(16, 8) < waste(8, 16);
+    const int th = tall ? 16 : 8, tw = tall ? 8 : 16;
+    const int th_n = (d->H + th - 1) / th, tw_n = (d->Wout + tw - 1) / tw;
+    const long long nt = (long long)d->S * th_n * tw_n;
+    if (nt < (1ll << 30)) {
+      int per1 = (int)((nt + 255) / 256);          // <= 256 blocks: one per CU
+      if (per1 < 1) per1 = 1;
+      const size_t sm8 = (size_t)2 * (2 * ((8 + 2) * (16 + 4) * PITCH + 16) + GT) * sizeof(float);
+      const size_t sm16 = (size_t)2 * (2 * ((16 + 2) * (8 + 4) * PITCH + 16) + GT) * sizeof(float);
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_wgrad_p_kernel<8, 16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_wgrad_p_kernel<16, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm16);
+        attr2 = true;
+      }
+      const unsigned grid = (unsigned)((nt + per1 - 1) / per1);
+      if (tall)
+        hipLaunchKernelGGL((conv32_s2_wgrad_p_kernel<16, 8>), dim3(grid), dim3(512), sm16, (hipStream_t)stream,
+                           *d, gw, th_n, tw_n, per1);
+      else
+        hipLaunchKernelGGL((conv32_s2_wgrad_p_kernel<8, 16>), dim3(grid), dim3(512), sm8, (hipStream_t)stream,
+                           *d, gw, th_n, tw_n, per1);
+      return f2g_check_launch();
+    }
   }
   hipLaunchKernelGGL(conv32_s2_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(512), smem,
                      (hipStream_t)stream, *d, gw, tiles_h, tiles_w, per);

@@ -416,6 +416,9 @@ DIRECT_CONV32 = _os.environ.get("F2G_DIRECT_CONV", "1") != "0"
 # the HBM-bound passes overlap with other lanes' MFMA work, while masking in the epilogue (two more
 # loads per element, strided by the row map) holds an MFMA wave's registers and LDS idle.  Default 0.
 FUSE_LRELU = int(_os.environ.get("F2G_FUSE_LRELU", "0"))
+# the five frequency bands of a resolution as nested launch lanes (their conv stacks are independent
+# until conv_post; the narrow bands' launches fill a fraction of the chip): 0 = one after the other
+BAND_LANES = _os.environ.get("F2G_BAND_LANES", "0") != "0"
 
 
 def _band_edges(n_fft: int):
@@ -451,7 +454,14 @@ def _mrd_forward_one(x2, win: int, prm: list):
     cat = ops.empty(S * Ft * Wcat, MRD_CH, device=dev)
     acts = []
     foff = 0
+    foffs = []
+    for bi in range(len(bands)):
+        foffs.append(foff)
+        foff += widths[bi][5]
+    blanes = ops.Lanes(dev, len(bands) if BAND_LANES else 1, "mrd_band%d" % win)
     for bi, (lo, hi) in enumerate(bands):
+      with blanes.lane(bi if BAND_LANES else 0):
+        foff = foffs[bi]
         ws = widths[bi]
         layer_out = []
         x, x_is_spec = packed, True
@@ -483,7 +493,7 @@ def _mrd_forward_one(x2, win: int, prm: list):
             layer_out.append(y)
             x, x_is_spec = y, False
         acts.append(layer_out)
-        foff += ws[5]
+    blanes.join()
     wpost, bpost = prm[50], prm[51]
     scores = ops.empty(S * Ft * Wcat, 1, device=dev)
     w9 = ops.derived(wpost, "pack", pack_conv_weight)      # (1, 9*32): [tap][ci]
@@ -632,9 +642,16 @@ class MRDLossFn(torch.autograd.Function):
             g_packed = None
             if not train_disc:
                 g_packed = ops.empty(B * Ft, ldp, device=dev)
-            foff = 0
             ldc = Wcat * C
+            foffs, foff = [], 0
+            for bi in range(len(st["bands"])):
+                foffs.append(foff)
+                foff += st["widths"][bi][5]
+            # (the bands' stacks are independent: disjoint slices of gcat / g_packed, their own maps)
+            blanes = ops.Lanes(dev, len(st["bands"]) if BAND_LANES else 1, "mrd_band%d" % win)
             for bi, (lo, hi) in enumerate(st["bands"]):
+              with blanes.lane(bi if BAND_LANES else 0):
+                foff = foffs[bi]
                 ws = st["widths"][bi]
                 # ---- layer 4 (its output is a strided slice of cat / gcat)
                 W4 = ws[5]
@@ -723,7 +740,7 @@ class MRDLossFn(torch.autograd.Function):
                     elif not train_disc:
                         _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, g_packed, g_line=dy_line,
                                       g_seq=dy_seq, g_off=dy_off, x_line=ldp, x_off=lo * 2)
-                foff += W4
+            blanes.join()
             if not train_disc:
                 gfr = ops.empty(B * Ft, win, device=dev)
                 if ops.fft_applies(win):

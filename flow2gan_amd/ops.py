@@ -602,6 +602,19 @@ def _split_operand(o: Operand) -> Operand:
     return n
 
 
+CONV32_X6 = _os.environ.get("F2G_CONV32_X6", "1") != "0"    # bf16x6 mode: fp32-class direct MRD convs
+
+
+def x3_image(t2d):
+    """f2g_split_bf16x3 image of a contiguous (rows, K) fp32 matrix, K % 32 == 0 (cached for weights)."""
+    def build(t):
+        rows, K = t.shape
+        img = torch.empty(rows * K * 3, device=t.device, dtype=torch.bfloat16)
+        call("f2g_split_bf16x3", ptr(img), ptr(t), K, rows, K)
+        return img
+    return derived(t2d, "x3img", build) if _is_const(t2d) else build(t2d)
+
+
 def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope: float, y):
     """Conv2d(32, 32, (3, 9), stride (1, 2), padding (1, 4)) + bias + leaky ReLU on channels-last
     images x (S*H*Win, 32) -> y (S*H*Wout, 32); w_packed = (32, 27*32) as pack_conv_weight gives."""
@@ -611,6 +624,11 @@ def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope:
     if GEMM_PRECISION == 1 and CONV32_SPLIT:
         w_packed = derived(w_packed, "split", split_bf16)
         d.precision = 1
+        d._keep = w_packed
+    elif GEMM_PRECISION == 3 and CONV32_X6:
+        # fp32-class products on the bf16 pipe (conv32x6.hip): three-piece image of the packed weights
+        w_packed = x3_image(w_packed)
+        d.precision = 3
         d._keep = w_packed
     d.w, d.bias, d.lrelu_slope = ptr(w_packed), ptr(bias), slope
     d.y, d.y_seq, d.y_line = ptr(y), H * Wout * 32, Wout * 32
@@ -634,6 +652,10 @@ def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, 
     if GEMM_PRECISION == 1 and CONV32_SPLIT:
         wT = derived(wT, "split", split_bf16)
         d.precision = 1
+        d._keep = wT
+    elif GEMM_PRECISION == 3 and CONV32_X6:
+        wT = x3_image(wT.view(27 * 32, 32))      # rows (tap, ci), reduction over co
+        d.precision = 3
         d._keep = wT
     d.w, d.bias, d.lrelu_slope = ptr(wT), None, 0.0
     d.y, d.y_seq, d.y_line = ptr(gx), H * Win * 32, Win * 32
@@ -661,6 +683,8 @@ def conv32_s2_wgrad(x, g, S: int, H: int, Win: int, Wout: int, gw):
     d.y, d.y_seq, d.y_line = ptr(g), H * Wout * 32, Wout * 32
     if GEMM_PRECISION == 1 and CONV32_SPLIT:
         d.precision = 1
+    elif GEMM_PRECISION == 3 and CONV32_X6:
+        d.precision = 3
     if GEMM_TIMER is not None:
         GEMM_TIMER.time(lambda: call("f2g_conv32_s2_wgrad", C.byref(d), ptr(gw)),
                         2.0 * S * H * Wout * 32 * 27 * 32, (2, 32, 27 * 32, S * H * Wout))

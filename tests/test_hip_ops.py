@@ -946,6 +946,62 @@ def test_direct_conv32_split_bf16(ops, S, H, Win):
     close(gx, xd.grad.permute(0, 2, 3, 1).reshape(S * H * Win, 32), rtol=3e-5, name="conv32 dgrad split-bf16")
 
 
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 21, 51), (1, 5, 2), (2, 8, 64), (5, 17, 26), (2, 9, 1),
+                                     (40, 47, 39), (24, 94, 77), (300, 19, 33)])
+def test_direct_conv32_fp32_class(ops, S, H, Win):
+    """conv32x6.hip: the direct MRD convs with fp32-CLASS products on the bf16 pipe (three bf16 pieces
+    per value, six MFMAs per product; f2g_conv32_desc.precision = 3) -- forward, data gradient
+    (both column parities from one staged patch) and weight gradient (bf16 planes of the three pieces,
+    transposing fragment reads) at the EXACT-fp32 tolerances against float64, and no
+    further from it than three times the exact-fp32 kernels' own error.  The large cases have more
+    tiles than the persistent kernels have blocks (prefetched patches, the weight double buffer
+    flipping from tile to tile), one per tile shape."""
+    Wout = (Win - 1) // 2 + 1
+    x = rnd(S * H * Win, 32, seed=1)
+    w = rnd(32, 32, 3, 9, seed=2, scale=0.05)
+    b = rnd(32, seed=3)
+    gy = rnd(S * H * Wout, 32, seed=4)
+    wp = w.permute(0, 2, 3, 1).reshape(32, 27 * 32).contiguous()
+    wT = w.permute(2, 3, 1, 0).reshape(27, 32, 32).contiguous()
+    xd = x.reshape(S, H, Win, 32).permute(0, 3, 1, 2).double().requires_grad_(True)
+    pre = torch.nn.functional.conv2d(xd, w.double(), b.double(), stride=(1, 2), padding=(1, 4))
+    ref = torch.nn.functional.leaky_relu(pre, 0.1).permute(0, 2, 3, 1).reshape(S * H * Wout, 32).detach()
+    pre.backward(gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
+    gref = xd.grad.permute(0, 2, 3, 1).reshape(S * H * Win, 32)
+    yact = rnd(S * H * Win, 32, seed=5)
+    yact = torch.where(yact > 0, yact, 0.1 * yact)
+    was = ops.GEMM_PRECISION
+    out = {}
+    try:
+        for mode in ("fp32", "bf16x6"):
+            ops.set_gemm_precision(mode)
+            y = torch.full((S * H * Wout, 32), 7.0, device=DEV)
+            ops.conv32_s2_fwd(g(x), S, H, Win, Wout, g(wp), g(b), 0.1, y)
+            gx = torch.full((S * H * Win, 32), 7.0, device=DEV)
+            ops.conv32_s2_dgrad(g(gy), S, H, Win, Wout, g(wT), gx)
+            gm = torch.full((S * H * Win, 32), 7.0, device=DEV)
+            cs = torch.zeros(32, device=DEV)
+            ops.conv32_s2_dgrad(g(gy), S, H, Win, Wout, g(wT), gm, mask=(g(yact), 0, 0.1), colsum=cs)
+            gw = torch.zeros(32, 27 * 32, device=DEV)
+            ops.conv32_s2_wgrad(g(x), g(gy), S, H, Win, Wout, gw)
+            out[mode] = (y.cpu().double(), gx.cpu().double(), gm.cpu().double(), gw.cpu().double(), cs.cpu().double())
+    finally:
+        ops.GEMM_PRECISION = was
+    want_m = gref * torch.where(yact > 0, 1.0, 0.1).double()
+    wd = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd.detach(), wd, None, stride=(1, 2), padding=(1, 4)).backward(
+        gy.reshape(S, H, Wout, 32).permute(0, 3, 1, 2).double())
+    want_w = wd.grad.permute(0, 2, 3, 1).reshape(32, 27 * 32)
+    for i, (want, name, tol) in enumerate(((ref, "forward", 2e-5), (gref, "data gradient", 2e-5),
+                                           (want_m, "masked data gradient", 2e-5),
+                                           (want_w, "weight gradient", 1e-4))):
+        close(out["bf16x6"][i], want, rtol=tol, name=f"conv32 fp32-class {name}")
+        e6 = float((out["bf16x6"][i] - want).abs().max())
+        e0 = float((out["fp32"][i] - want).abs().max())
+        assert e6 <= 3.0 * e0 + 1e-7 * float(want.abs().max()), (name, e6, e0)
+    close(out["bf16x6"][4], want_m.sum(0), rtol=1e-4, name="column sums")
+
+
 @pytest.mark.parametrize("S,H,W,lo,Wtot", [(2, 11, 34, 7, 50), (3, 8, 32, 0, 32), (1, 5, 3, 2, 9), (2, 21, 77, 10, 100)])
 def test_conv2ch_direct_kernels_match_autograd(ops, S, H, W, lo, Wtot):
     """conv2ch.hip (first MRD layer, 2 -> 32 channels on a band of the interleaved spectrogram):
