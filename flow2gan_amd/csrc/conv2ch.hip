@@ -10,6 +10,8 @@
 // with ONE tap per instruction (its two k slots are the two input channels), the data gradient is
 // a VALU kernel (two outputs per pixel).  All three are bound by the 32-channel side of the layer
 // in HBM (128 B per pixel), not by arithmetic.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -80,6 +82,92 @@ __global__ __launch_bounds__(256) void conv2ch_fwd_kernel(const f2g_conv2ch_desc
   }
 }
 
+// ---- forward, persistent over the rows of a column tile (round 4) --------------------------------
+// conv2ch_fwd_kernel spends a block on 8 x 32 pixels: 27 weight loads per lane, a patch and a launch for
+// 54 MFMAs per wave (PMC: matrix pipe 37 % busy, 2.4 TB/s on the 32-channel side).  Here a block owns a
+// column tile of ONE sequence and walks down all its rows, 8 at a time: weights and bias are loaded once,
+// the next 10 x 40 patch is requested (2 x 8 bytes per thread) before the current rows' MFMAs and stored
+// into the other LDS buffer behind them -- one barrier per 8 rows.
+__global__ __launch_bounds__(256) void conv2ch_fwd_p_kernel(const f2g_conv2ch_desc d) {
+  __shared__ float plane[2][2 * FPH * PW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int s = blockIdx.y, w0 = blockIdx.x * TW;
+  const float* xs = d.x + (long long)s * d.x_seq;
+  float bw[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) bw[t] = d.w[li * (NTAP * 2) + t * 2 + h];
+  const float bias = d.bias ? d.bias[li] : 0.f;
+  // this thread's two patch pixels (row r, column c) of a 10 x 40 patch: i = tid, tid + 256
+  constexpr int NP = (FPH * PW + 255) / 256;
+  int pr[NP], pc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int i = tid + 256 * q;
+    pr[q] = i / PW;
+    pc[q] = i - pr[q] * PW;
+  }
+  auto load_patch = [&](int h0, float2 (&v)[NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int hh = h0 - 1 + pr[q], ww = w0 - 4 + pc[q];
+      const bool ok = tid + 256 * q < FPH * PW && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W;
+      v[q] = ok ? *reinterpret_cast<const float2*>(xs + (long long)hh * d.x_line + (long long)ww * 2)
+                : make_float2(0.f, 0.f);
+    }
+  };
+  auto store_patch = [&](float* pl, const float2 (&v)[NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int i = tid + 256 * q;
+      if (i < FPH * PW) {
+        pl[i] = v[q].x;
+        pl[FPH * PW + i] = v[q].y;
+      }
+    }
+  };
+  {
+    float2 v[NP];
+    load_patch(0, v);
+    store_patch(plane[0], v);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int h0 = 0; h0 < d.H; h0 += FTH) {
+    const bool more = h0 + FTH < d.H;
+    float2 nv[NP];
+    load_patch(more ? h0 + FTH : h0, nv);
+    const float* pl = plane[cur] + h * (FPH * PW);
+#pragma unroll
+    for (int rr = 0; rr < FTH / 4; ++rr) {
+      const int row = wave + 4 * rr;              // tile row of this wave
+      if (h0 + row < d.H) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = bias;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          const int dh = t / KW, j = t - dh * KW;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pl[(row + dh) * PW + li + j], bw[t], acc, 0, 0, 0);
+        }
+        float* yrow = d.y + ((long long)s * d.H + h0 + row) * (long long)d.W * CO;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int col = w0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (col < d.W) {
+            float v = acc[e];
+            if (d.lrelu_slope != 0.f) v = v > 0.f ? v : d.lrelu_slope * v;
+            yrow[(long long)col * CO + li] = v;
+          }
+        }
+      }
+    }
+    if (more) store_patch(plane[cur ^ 1], nv);   // (its last readers left through the previous barrier)
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // ---- weight gradient: gw[co][tap*2+ci] += sum_px g[px][co] x[px + tap][ci] -----------------------
 // MFMA rows = co, columns = the 54 (tap, ci) pairs (two 32-column tiles), reduction = pixels: the A
 // fragment (g[px][co]) comes from the gradient tile staged in LDS with 16-byte loads (read as single
@@ -140,6 +228,115 @@ __global__ __launch_bounds__(256) void conv2ch_wgrad_kernel(const f2g_conv2ch_de
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
       }
     }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = li + 32 * nt;
+    if (n >= NTAP * 2) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+      atomicAdd(d.gw + co * (NTAP * 2) + n, acc[nt][e]);
+    }
+  }
+}
+
+// The same with the NEXT tile's gradient rows (8 x 16 bytes per thread) and patch requested before the
+// current tile's 64 MFMAs per wave and written to LDS after them (round 4: conv2ch_wgrad_kernel's blocks
+// wait a full memory round trip per tile; PMC: matrix pipe 21 % busy, 1.2 TB/s on the gradient map).
+__global__ __launch_bounds__(256) void conv2ch_wgrad_p_kernel(const f2g_conv2ch_desc d, int tiles_h,
+                                                              int tiles_w, int tiles_per_block) {
+  __shared__ float plane[2 * FPH * PW];
+  __shared__ __attribute__((aligned(16))) float gt[FTH * TW * CO];   // gradient tile [row][col][co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int ntiles = d.S * tiles_h * tiles_w;
+  int boff[2];
+  bool bok[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = li + 32 * nt;
+    bok[nt] = n < NTAP * 2;
+    const int t = bok[nt] ? n >> 1 : 0, ci = n & 1;
+    const int dh = t / KW, j = t - dh * KW;
+    boff[nt] = ci * (FPH * PW) + dh * PW + j;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+  constexpr int NP = (FPH * PW + 255) / 256, NG = FTH * TW * (CO / 4) / 256;
+  const int c4 = tid & 7;
+  auto load_tile = [&](int ti, float2 (&pv)[NP], float4 (&gv)[NG]) {
+    const int s = ti / (tiles_h * tiles_w), rem = ti - s * (tiles_h * tiles_w);
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int h0 = th * FTH, w0 = tw * TW;
+    const float* xs = d.x + (long long)s * d.x_seq;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int i = tid + 256 * q, r = i / PW, c = i - r * PW;
+      const int hh = h0 - 1 + r, ww = w0 - 4 + c;
+      const bool ok = i < FPH * PW && hh >= 0 && hh < d.H && ww >= 0 && ww < d.W;
+      pv[q] = ok ? *reinterpret_cast<const float2*>(xs + (long long)hh * d.x_line + (long long)ww * 2)
+                 : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const int px = (tid >> 3) + 32 * q;
+      const int row = px / TW, col = px - row * TW;
+      const bool ok = h0 + row < d.H && w0 + col < d.W;
+      gv[q] = ok ? *reinterpret_cast<const float4*>(d.y + (((long long)s * d.H + h0 + row) * (long long)d.W + w0 + col) * CO + c4 * 4)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](const float2 (&pv)[NP], const float4 (&gv)[NG]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int i = tid + 256 * q;
+      if (i < FPH * PW) {
+        plane[i] = pv[q].x;
+        plane[FPH * PW + i] = pv[q].y;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+      *reinterpret_cast<float4*>(gt + ((tid >> 3) + 32 * q) * CO + c4 * 4) = gv[q];
+  };
+  const int t0 = blockIdx.x * tiles_per_block;
+  int tend = t0 + tiles_per_block;
+  if (tend > ntiles) tend = ntiles;
+  if (t0 >= tend) return;
+  {
+    float2 pv[NP];
+    float4 gv[NG];
+    load_tile(t0, pv, gv);
+    store_tile(pv, gv);
+  }
+  __syncthreads();
+  for (int ti = t0; ti < tend; ++ti) {
+    const bool more = ti + 1 < tend;
+    float2 pv[NP];
+    float4 gv[NG];
+    load_tile(more ? ti + 1 : ti, pv, gv);
+    // (rows beyond the image hold zero gradients: no row test needed)
+#pragma unroll
+    for (int rr = 0; rr < FTH / 4; ++rr) {
+      const int row = wave + 4 * rr;
+      const float* grow = gt + row * TW * CO + li;
+#pragma unroll
+      for (int st = 0; st < TW / 2; ++st) {
+        const int col = 2 * st + h;                  // k slot h of step st = tile column
+        const float a = grow[col * CO];
+        const float b0 = bok[0] ? plane[boff[0] + row * PW + col] : 0.f;
+        const float b1 = bok[1] ? plane[boff[1] + row * PW + col] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) store_tile(pv, gv);
+    __syncthreads();
   }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -233,20 +430,26 @@ __global__ __launch_bounds__(256) void convpost_fwd_kernel(const f2g_conv2ch_des
   const int tw = blockIdx.x % tiles_w, th = blockIdx.x / tiles_w;
   const int s = blockIdx.y;
   const int h0 = th * QTH, w0 = tw * QTW;
+  // the 288 weights through LDS (every lane reads the same address: a broadcast) -- as uniform global
+  // operands they took 288 scalar registers: 224 of them spilled, one wave per SIMD (round 4)
+  __shared__ __attribute__((aligned(16))) float wl[9 * CO];
+  for (int i = tid; i < 9 * CO; i += 256) wl[i] = d.w[i];
   stage32(patch, d.x + (long long)s * d.H * d.W * CO, d.H, d.W, h0, w0, tid);
   __syncthreads();
   const int pw = tid & 31, ph = tid >> 5;
   float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {       // (not unrolled: all 72 weight quads live at once spill)
     const float* x0 = patch + ((ph + t / 3) * QPW + pw + t % 3) * GP;
-    const float* wt = d.w + t * CO;                      // [tap][ci], uniform
+    const float* wt = wl + t * CO;                       // [tap][ci]
 #pragma unroll
     for (int c4 = 0; c4 < CO / 4; c4 += 2) {
       const float4 u = *reinterpret_cast<const float4*>(x0 + c4 * 4);
       const float4 v = *reinterpret_cast<const float4*>(x0 + c4 * 4 + 4);
-      a0 += u.x * wt[c4 * 4] + u.y * wt[c4 * 4 + 1] + u.z * wt[c4 * 4 + 2] + u.w * wt[c4 * 4 + 3];
-      a1 += v.x * wt[c4 * 4 + 4] + v.y * wt[c4 * 4 + 5] + v.z * wt[c4 * 4 + 6] + v.w * wt[c4 * 4 + 7];
+      const float4 wu = *reinterpret_cast<const float4*>(wt + c4 * 4);
+      const float4 wv = *reinterpret_cast<const float4*>(wt + c4 * 4 + 4);
+      a0 += u.x * wu.x + u.y * wu.y + u.z * wu.z + u.w * wu.w;
+      a1 += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
     }
   }
   const int hh = h0 + ph, ww = w0 + pw;
@@ -327,6 +530,11 @@ static bool conv2ch_ok(const f2g_conv2ch_desc* d) {
 extern "C" int f2g_conv2ch_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
   if (!d || !d->x || !d->w || !d->y || (d->x_line & 1) || (d->x_seq & 1)) return F2G_EINVAL;
   if (!conv2ch_ok(d)) return F2G_OK;
+  static const bool persistent = !(getenv("F2G_CONV2CH_V2") && atoi(getenv("F2G_CONV2CH_V2")) == 0);
+  if (persistent && (long long)((d->W + TW - 1) / TW) * d->S >= 256) {   // column tiles x sequences fill the chip
+    hipLaunchKernelGGL(conv2ch_fwd_p_kernel, dim3((d->W + TW - 1) / TW, d->S), dim3(256), 0, ST, *d);
+    return f2g_check_launch();
+  }
   const int tiles = ((d->H + FTH - 1) / FTH) * ((d->W + TW - 1) / TW);
   hipLaunchKernelGGL(conv2ch_fwd_kernel, dim3(tiles, d->S), dim3(256), 0, ST, *d);
   return f2g_check_launch();
@@ -340,8 +548,13 @@ extern "C" int f2g_conv2ch_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream)
   const int ntiles = d->S * tiles_h * tiles_w;
   int per = (ntiles + 511) / 512;        // <= 512 blocks: 0.9 M atomics on 1728 addresses per launch
   if (per < 1) per = 1;
-  hipLaunchKernelGGL(conv2ch_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(256), 0, ST, *d,
-                     tiles_h, tiles_w, per);
+  static const bool persistent = !(getenv("F2G_CONV2CH_V2") && atoi(getenv("F2G_CONV2CH_V2")) == 0);
+  if (persistent)
+    hipLaunchKernelGGL(conv2ch_wgrad_p_kernel, dim3((ntiles + per - 1) / per), dim3(256), 0, ST, *d,
+                       tiles_h, tiles_w, per);
+  else
+    hipLaunchKernelGGL(conv2ch_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(256), 0, ST, *d,
+                       tiles_h, tiles_w, per);
   return f2g_check_launch();
 }
 

@@ -2405,9 +2405,10 @@ __global__ __launch_bounds__(256) void split3_img_kernel(__bf16* __restrict__ ds
 
 // The tile's three-piece image for the next GEMM (f2g_epilogue.x3_out): read back what the block has just
 // stored (L2; the barrier orders the block's own stores before these loads) and write whole 16-byte pieces.
+template <int ROWS = 128, int NTHR = 256>
 __device__ __forceinline__ void x3_tile_readback(const f2g_epilogue& E, int M, int N, int m0, int n0, int tid) {
   __syncthreads();
-  for (int u = tid; u < 128 * 16; u += 256) {
+  for (int u = tid; u < ROWS * 16; u += NTHR) {
     const int row = m0 + (u >> 4), col = n0 + (u & 15) * 8;
     if (row >= M || col >= N) continue;
     long long off;
@@ -2654,6 +2655,144 @@ __global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d,
   if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
+// ---- the tap-walking instance on a 256 x 128 tile (round 4) -------------------------------------------
+// gemm_x6t_kernel keeps the matrix pipe ~45 % busy: two blocks per CU whose store / barrier / read /
+// barrier phases meet at random, 31 KB from L2 per 128 x 128 x 32 tap (6 TB/s over the chip at 210 TFLOP/s
+// equivalent).  Here ONE block of 8 waves per CU owns 256 output rows: the weight slab of a tap is
+// double-buffered in LDS (stored behind the fragment reads of the tap before, into the buffer nobody
+// reads), the staged map positions are exchanged once per 32-channel slab, so a tap costs ONE barrier;
+// L2 -> LDS traffic per product drops by 40 % (the weight slab serves twice the rows).
+template <int TAPS>
+__global__ __launch_bounds__(512, 1) void gemm_x6t8_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                           const x6_tap R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int PITCH = 208, LMAX = 304, OPERA = LMAX * PITCH, OPERB = 128 * PITCH;
+  constexpr int NJA = (LMAX * 12 + 511) / 512, NJB = 128 * 12 / 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(256, 128, m0, n0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto posrow = [&](int r) {
+    const int sq = r / R.P0;
+    return sq * R.HpIn + (r - sq * R.P0) + R.offpos;
+  };
+  const int pbase = posrow(m0);
+  const int rlast = m0 + 255 < M ? m0 + 255 : M - 1;
+  const int L = posrow(rlast) - pbase + TAPS;            // staged positions (<= LMAX: host check)
+  const unsigned rowbytesA = (unsigned)R.C32 * 192u;     // one position of the map image
+  const unsigned rowbytesW = (unsigned)(K / 32) * 192u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytesW, 0x00020000);
+  unsigned voA[NJA], voW[NJB];
+  int loA[NJA], loW[NJB];
+#pragma unroll
+  for (int j = 0; j < NJA; ++j) {
+    const int id = tid + 512 * j, q = id / 12, c = id - q * 12;
+    voA[j] = q < L ? (unsigned)(pbase + q) * rowbytesA + c * 16 : 0xf0000000u;
+    loA[j] = q < LMAX ? q * PITCH + c * 16 : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < NJB; ++j) {
+    const int id = tid + 512 * j, row = id / 12, c = id - row * 12;
+    voW[j] = (unsigned)(n0 + row) * rowbytesW + c * 16;
+    loW[j] = OPERA + row * PITCH + c * 16;
+  }
+  u32x4 xa[NJA], xw[NJB];
+  auto gloadA = [&](int cs) {
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], cs * 192, 0);
+  };
+  auto gloadB = [&](int slab) {
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], slab * 192, 0);
+  };
+  auto storeA = [&]() {
+#pragma unroll
+    for (int j = 0; j < NJA; ++j)
+      if (loA[j] >= 0) *reinterpret_cast<u32x4*>(smem6 + loA[j]) = xa[j];
+  };
+  auto storeB = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) *reinterpret_cast<u32x4*>(smem6 + buf * OPERB + loW[j]) = xw[j];
+  };
+  // fragment rows of this lane: output rows wm * 64 + i * 32 + li -> staged position
+  const unsigned char* rA[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = m0 + wm * 64 + i * 32 + li;
+    rA[i] = smem6 + (r < M ? posrow(r) - pbase : 0) * PITCH + h * 16;
+  }
+  const unsigned char* rB = smem6 + OPERA + (wn * 64 + li) * PITCH + h * 16;
+  // weight slab of step s = (cs, t): K order = channel slab outer, tap inner -> image slab t * C32 + cs
+  const int nsteps = R.C32 * TAPS;
+  gloadA(0);
+  gloadB(0);
+  storeA();
+  storeB(0);
+  gloadA(1 < R.C32 ? 1 : 0);
+  gloadB(TAPS > 1 ? R.C32 : (1 < R.C32 ? 1 : 0));          // step 1
+  __syncthreads();
+  // (Measured and dropped: a software pipeline over half slabs -- the fragments of one k step requested under
+  // the MFMAs of the other, the barrier between the two halves: 187 against 211 TFLOP/s equivalent.)
+  int step = 0;
+  for (int cs = 0; cs < R.C32; ++cs) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t, ++step) {
+      const int buf = step & 1;
+      bf16x8 fa[2][3][2], fb[2][3][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA[i] + t * PITCH + p * 64 + ks * 32);
+            fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + buf * OPERB + p * 64 + i * 32 * PITCH + ks * 32);
+          }
+      // the next step's weight slab goes into the buffer nobody reads (its readers left through the barrier
+      // that closed the step before); then the slab after it is requested
+      storeB(buf ^ 1);
+      {
+        const int s2 = step + 2 < nsteps ? step + 2 : 0;       // (past the end: re-read, never used)
+        const int c2 = s2 / TAPS, t2 = s2 - c2 * TAPS;
+        gloadB(t2 * R.C32 + c2);
+      }
+      if (t == TAPS - 1) {
+        // last tap of this channel slab: once every wave has its fragments, the staged positions are replaced
+        __syncthreads();
+        storeA();
+        gloadA(cs + 2 < R.C32 ? cs + 2 : 0);
+      }
+      __builtin_amdgcn_s_setprio(X6_MFMA_PRIO);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int j = sdeg - i;
+            if (j < 0 || j > 2) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();
+    }
+  }
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (d.E.x3_out) x3_tile_readback<256, 512>(d.E, M, N, m0, n0, tid);
+}
+
 // The same tile and schedule over the fp32 operands themselves (f2g_operand.split = 0): every thread
 // splits the 4-float chunks it loads into the three pieces on their way into LDS, as gemm_leanw6_kernel
 // does -- 4 bytes per element from L2 instead of 6, no image pass, no producer, 5.5 VALU instructions per
@@ -2808,7 +2947,46 @@ static int launch_x6t(const f2g_gemm_desc& d, int taps, hipStream_t st) {
   return f2g_check_launch();
 }
 
+// the 256-row instance: the same windows, the staged run of a 256-row tile within 304 positions, and a
+// tile grid that still gives every CU a block (F2G_X6_TAP8=0: off)
+static bool x6_tap8_ok(const f2g_gemm_desc& d, int taps) {
+  // F2G_X6_TAP8: 0 off, 1 (default) where the taller grid still gives every CU a block, 2 wherever the
+  // geometry allows (tests; read per call so that a test can switch it)
+  const char* ev = getenv("F2G_X6_TAP8");
+  const int mode = ev ? atoi(ev) : 1;
+  if (mode == 0 || !x6_tap_ok(d, taps)) return false;
+  const f2g_operand& A = d.A;
+  const int HpIn = (int)(A.seq_stride / A.unit);
+  if (256 + taps - 1 + (HpIn - A.P0) * (256 / A.P0 + 1) > 304) return false;
+  if (d.A.unit / 32 < 2) return false;
+  const long long tiles = (long long)((d.A.rows + 255) / 256) * ((d.B.rows + 127) / 128);
+  return mode >= 2 || tiles >= 256;
+}
+
+static int launch_x6t8(const f2g_gemm_desc& d, int taps, hipStream_t st) {
+  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
+  constexpr size_t smem = (size_t)(304 + 2 * 128) * 208;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t8_kernel<5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t8_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  x6_tap R;
+  R.P0 = d.A.P0, R.HpIn = (int)(d.A.seq_stride / d.A.unit), R.offpos = -d.A.pad0, R.C32 = d.A.unit / 32;
+  R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
+  dim3 grid((M + 255) / 256, (N + 127) / 128);
+  if (taps == 5) hipLaunchKernelGGL(gemm_x6t8_kernel<5>, grid, dim3(512), smem, st, d, M, N, K, R);
+  else hipLaunchKernelGGL(gemm_x6t8_kernel<2>, grid, dim3(512), smem, st, d, M, N, K, R);
+  g_last_path = 4;
+  return f2g_check_launch();
+}
+
 static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
+  if (x6_tap8_ok(d, 5)) return launch_x6t8(d, 5, st);
+  if (x6_tap8_ok(d, 2)) return launch_x6t8(d, 2, st);
   if (x6_tap_ok(d, 5)) return launch_x6t(d, 5, st);
   if (x6_tap_ok(d, 2)) return launch_x6t(d, 2, st);     // (the stride-3 layers' residue data gradients)
   const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
