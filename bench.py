@@ -277,6 +277,23 @@ def main():
             # pieces per operand, six MFMAs per product; everything else on the exact fp32 MFMA)
             ops.set_gemm_precision("bf16x6")
             a6, e6 = timed(1, max(2, args.steps // 2))
+            fam6 = None
+            if not args.no_roofline:
+                torch.cuda.synchronize()
+                tm6 = ops.GEMM_TIMER = ops.GemmTimer()
+                step()
+                torch.cuda.synchronize()
+                ops.GEMM_TIMER = None
+                n6, fl6, sec6 = tm6.summary()
+                fam6 = {"launches_per_step": n6, "ms_per_step_serialised": round(1e3 * sec6, 2),
+                        "achieved_fp32_equivalent_TFLOPs": round(fl6 / sec6 / 1e12, 2),
+                        # six bf16 MFMAs per product against the dense bf16 peak (the exact-fp32 families of
+                        # this mode -- short-K generator GEMMs, thin layers -- counted at six as well)
+                        "bf16_mfma_frac": round(6.0 * fl6 / sec6 / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "by_family": {k: {"launches": v[0], "tflop": round(v[1] / 1e12, 3),
+                                          "ms": round(1e3 * v[2], 2),
+                                          "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None}
+                                      for k, v in sorted(tm6.by_path().items())}}
             fast["fp32_class"] = {
                 "gemm": "bf16x6: three bf16 pieces per fp32 operand, six v_mfma_f32_32x32x16_bf16 per product "
                         "(error <= 2^-23 per product: 8e-8 of sum|a w| measured where the fp32 fmaf chain has "
@@ -284,10 +301,13 @@ def main():
                         "forward and data-gradient GEMMs over their halo maps, the 768-channel pwconv2; operand "
                         "images written by the producing GEMM's epilogue), for 640 <= K < 2048 on chip-filling "
                         "grids (operands split inside the kernel) and for the weight gradients with >= 2048 "
-                        "rows (gemm_leanw6_kernel, operands split inside the kernel); MRD and the short-K "
-                        "generator GEMMs exact fp32",
+                        "rows (gemm_leanw6_kernel, operands split inside the kernel), and for the direct MRD band "
+                        "convolutions (conv32x6.hip: patch and gradient tiles split into three pieces while they "
+                        "are staged, forward / data gradient / weight gradient); the short-K generator GEMMs and "
+                        "the thin first / last layers exact fp32",
                 "value": round(world * a6 / e6, 2), "unit": "audio-s/s",
                 "ms_per_step": round(1e3 * e6 / max(2, args.steps // 2), 2),
+                "mfma_class": fam6,
                 "parity": "the golden parity modules run in this mode in the default `pytest -m gpu` run "
                           "(tests/conftest.py: fp32, bf16x6, bf16x3) at the exact-fp32 tolerances"}
         if args.workload == "infer4":

@@ -277,15 +277,12 @@ class CondEncoderFn(GradAwareFunction):
             fn, fs = ctx.flags[1 + i]
             g, gb = block_bwd(blks[i], x, z, a, g, B, Fm, None, fn, fs)
             grads_blocks[i] = gb
-        g_beta = ops.zeros(Cc, device=dev)
-        g_ls = ops.zeros(1, device=dev)
+        g_beta, g_ls, g_bin, g_wp = ops.zeros_many([(Cc,), (1,), (Cc,), (Cc, 3 * nm)], dev)   # (one fill)
         gh0 = ops.empty(rows, Cc, device=dev)
         ops.biasnorm_bwd(h0, g, gh0, rows, Cc, beta_in, ls_in.reshape(1), g_beta, g_ls)
         if ctx.flags[0]:
             ops.limit_grad(g_ls, ls_in.reshape(1), -1.5, 1.5)
-        g_bin = ops.zeros(Cc, device=dev)
         ops.colsum(g_bin, gh0, rows, Cc)
-        g_wp = ops.zeros(Cc, 3 * nm, device=dev)
         ops.wgrad(gh0, Cc, gh0.stride(0), win1d(melr, B, Fm, nm, Fm, 1, 1, 3), g_wp)
         g_win = ops.empty(Cc, nm, 3, device=dev)
         ops.permute4(g_win, g_wp, (Cc, nm, 3, 1), (3 * nm, 1, nm, 0))
@@ -384,21 +381,17 @@ class CondPathFn(GradAwareFunction):
         rows = B * Fce
         g = g.contiguous()
         NC = nblk * Cc
-        g_wstack = ops.zeros(NC, Dc, device=dev)
-        g_bstack = ops.zeros(NC, device=dev)
+        # every gradient accumulator of this node from ONE zeroed allocation (one fill launch)
+        g_wstack, g_bstack, g_b2, g_w2, g_alpha, g_b0, g_w0 = ops.zeros_many(
+            [(NC, Dc), (NC,), (Dc,), (Dc, Hc), (Hc,), (Hc,), (Hc, Dc)], dev)
         ops.colsum(g_bstack, g, rows, NC)
         ops.wgrad(g, NC, g.stride(0), mat(cm, rows, Dc), g_wstack)
         g_cm = ops.empty(rows, Dc, device=dev)
         gemm(mat(g, rows, NC), mat(wstack), g_cm, form=1)
-        g_b2 = ops.zeros(Dc, device=dev)
         ops.colsum(g_b2, g_cm, rows, Dc)
-        g_w2 = ops.zeros(Dc, Hc, device=dev)
         ops.wgrad(g_cm, Dc, g_cm.stride(0), mat(pact, rows, Hc), g_w2)
-        g_alpha = ops.zeros(Hc, device=dev)
-        g_b0 = ops.zeros(Hc, device=dev)
         gemm(mat(g_cm, rows, Dc), mat(w2.reshape(Dc, Hc)), a, form=1, aux=a, alpha_n=alpha,
              colsum_alpha=g_alpha, colsum=g_b0)
-        g_w0 = ops.zeros(Hc, Dc, device=dev)
         ops.wgrad(a, Hc, a.stride(0), mat(cext, rows, Dc), g_w0)
         g_cond = None
         if ctx.needs_input_grad[0]:
@@ -728,14 +721,16 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
         gemm(mat(gfr, rows, N), mat(_pad_cols(Wi, Kc)), gy, form=1, true_n=Cin)      # pad columns come out zero
     if lens_f is not None:
         ops.mask_rows(gy, B, F, Cin, lens_f)
-    g_wout = ops.zeros(Cin, Cc, device=dev)
-    g_bout = ops.zeros(Cin, device=dev)
+    # every gradient accumulator of the branch outside its blocks from ONE zeroed allocation (one fill)
+    Dt, Ht = bv.Dt, bv.Ht
+    (g_wout, g_bout, g_te_all, g_beta, g_ls, g_bin, g_win, g_tew, g_teb, g_tb2, g_tw2, g_tb0,
+     g_tw0) = ops.zeros_many([(Cin, Cc), (Cin,), (B, NC), (Cc,), (1,), (Cc,), (Cc, Cin), (NC, Dt), (NC,), (Dt,),
+                              (Dt, Ht), (Ht,), (Ht, Dt)], dev)
     ops.colsum(g_bout, gy, rows, Cin)
     x_last = sv["x_last"]
     ops.wgrad(gy, Cin, ldp, mat(x_last, rows, Cc), g_wout)
     g = ops.empty(rows, Cc, device=dev)
     gemm(mat(gy, rows, Kc), mat(_pad_rows(bv.w_out.reshape(Cin, Cc), Kc)), g, form=1, true_k=Cin)
-    g_te_all = ops.zeros(B, NC, device=dev)
     block_grads = [None] * bv.nblk
     flags = sv["flags"]
     for j in reversed(range(bv.nblk)):
@@ -746,15 +741,11 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
                           g_cproj_store=True)   # g_cp is zero-filled, block j owns columns j*C..
         block_grads[j] = gb
     # in_norm / in_proj / STFT
-    g_beta = ops.zeros(Cc, device=dev)
-    g_ls = ops.zeros(1, device=dev)
     gh0 = ops.empty(rows, Cc, device=dev)
     ops.biasnorm_bwd(sv["h0"], g, gh0, rows, Cc, bv.beta_in, bv.ls_in.reshape(1), g_beta, g_ls)
     if flags[0]:
         ops.limit_grad(g_ls, bv.ls_in.reshape(1), -1.5, 1.5)
-    g_bin = ops.zeros(Cc, device=dev)
     ops.colsum(g_bin, gh0, rows, Cc)
-    g_win = ops.zeros(Cc, Cin, device=dev)
     ops.wgrad(gh0, Cc, gh0.stride(0), mat(sv["packed"], rows, Cin), g_win)
     if need_gx:
         gpacked = ops.empty(rows, ldp, device=dev)
@@ -770,24 +761,17 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
         if lanes is not None:
             lanes.chain_leave()
     # time path
-    Dt, Ht = bv.Dt, bv.Ht
-    g_tew = ops.zeros(NC, Dt, device=dev)
-    g_teb = ops.zeros(NC, device=dev)
     ops.colsum(g_teb, g_te_all, B, NC)
     ops.wgrad(g_te_all, NC, NC, mat(sv["te"], B, Dt), g_tew)
     g_te = ops.empty(B, Dt, device=dev)
     gemm(mat(g_te_all, B, NC), mat(sv["tew"]), g_te, form=1)
-    g_tb2 = ops.zeros(Dt, device=dev)
     ops.colsum(g_tb2, g_te, B, Dt)
-    g_tw2 = ops.zeros(Dt, Ht, device=dev)
     ops.wgrad(g_te, Dt, Dt, mat(sv["ts"], B, Ht), g_tw2)
     g_ts = ops.empty(B, Ht, device=dev)
     gemm(mat(g_te, B, Dt), mat(bv.tw2), g_ts, form=1)
     g_th = ops.empty(B, Ht, device=dev)
     ops.silu_bwd(g_th, g_ts, sv["th"])
-    g_tb0 = ops.zeros(Ht, device=dev)
     ops.colsum(g_tb0, g_th, B, Ht)
-    g_tw0 = ops.zeros(Ht, Dt, device=dev)
     ops.wgrad(g_th, Ht, Ht, mat(sv["emb"], B, Dt), g_tw0)
     out = [g_win.reshape(Cc, Cin, 1), g_bin, g_ls.reshape(()), g_beta, g_tw0, g_tb0, g_tw2, g_tb2,
            g_wout.reshape(Cin, Cc, 1), g_bout]

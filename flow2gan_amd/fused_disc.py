@@ -666,7 +666,12 @@ class MRDLossFn(torch.autograd.Function):
                 g = None
                 # bias-gradient accumulators of the band (layers 0..3 get theirs as column sums from
                 # the data-gradient epilogue that lands on their output)
-                gbs = ops.zeros_many([(C,)] * 4, dev) if train_disc else [None] * 4
+                if train_disc:   # every accumulator of the band's five layers from one zeroed allocation
+                    zs = ops.zeros_many([(C,)] * 5 + [(C, 3 * kw_ * (2 if l_ == 0 else C))
+                                                      for l_, (kw_, _sw) in enumerate(MRD_LAYERS)], dev)
+                    gbs, gb4, gwps = zs[:4], zs[4], zs[5:]
+                else:
+                    gbs = [None] * 4
                 for l in reversed(range(5)):
                     kw, sw = MRD_LAYERS[l]
                     w = prm[(bi * 5 + l) * 2]
@@ -686,7 +691,7 @@ class MRDLossFn(torch.autograd.Function):
                                       line_stride=ldp, seq_stride=Ft * ldp, offset=lo * 2)
                         else:
                             X = win2d(x_in, S, Ft, Win, Cin, Wout, 3, kw, sw, 1, kw // 2)
-                        gwp = ops.zeros(C, 3 * kw * Cin, device=dev)
+                        gwp = gwps[l]
                         if l == 4:
                             dY = win1d(gcat, S * Ft, Wcat, C, W4, 1, -foff, 1)
                         else:
@@ -701,7 +706,7 @@ class MRDLossFn(torch.autograd.Function):
                                  split_k=ops.split_for(X.rows, tiles))
                         grads_w[(bi * 5 + l) * 2] = unpack_conv_grad(gwp, w.shape)
                         if l == 4:
-                            gb = ops.zeros(C, device=dev)
+                            gb = gb4
                             _colsum_strided(gb, gcat, S * Ft, W4, C, ldc, foff * C)
                         else:
                             gb = gbs[l]

@@ -2,7 +2,7 @@
 (ROUND=r02 by default)."""
 import csv, json, re, os, sys
 G, P = "gpurun_out", "profiles"
-R = os.environ.get("ROUND", "r02")
+R = os.environ.get("ROUND", "r04")
 sys.path.insert(0, os.getcwd())
 
 
@@ -78,9 +78,14 @@ HEAD = {
     "infer4_bf16_variants.txt": "",
     "pmc_x6_step.txt": "# tools/pmc_x6_step.sh: rocprofv3 --pmc passes over `bench.py --gemm bf16x6 --steps 1 --warmup 1` (launch lanes off); per-kernel means over the launches of gemm_x6_kernel / gemm_leanw6_kernel\n",
     "infer4_bf16_timeline.txt": "# tools/prof_timeline.sh (rocprofv3 --kernel-trace over the HIP-graph replayed bf16 4-step inference, launch lanes ON): overlap statistics of the last inference in the trace (profiled: ~5-15 % slower than unprofiled)\n",
-    "wgrad_probe.txt": "", "conv32_probe.txt": "", "fused_mlp_bench.txt": "", "fused_mlp_lab.txt": "",
+    "wgrad_probe.txt": "", "fused_mlp_bench.txt": "", "fused_mlp_lab.txt": "",
+    "conv32_probe.txt": "# tools/conv32_probe.py: direct 32 -> 32 (3,9)/(1,2) MRD band convs at the 45 band shapes of a pass (B = 64: S = 128 forward / weight gradient, S = 64 data gradient); MODE=fp32: exact (persistent forward / data-gradient kernels of round 3, double-buffered weight gradient of round 4), MODE=bf16x6: fp32-class instances on the bf16 pipe (conv32x6.hip, round 4)\n",
+    "knockout.txt": "# tools/knockout.py: the laned stage-2 step (B = 64) with components knocked out -- what MPD / MRD / the mel-recon term / the generator cost in the real schedule (step(full) - step(without)); fp32 = exact, bf16x6 = fp32-class mode\n",
+    "pmc_lean_fp32.txt": "# tools/pmc_lean_fp32.sh: rocprofv3 --pmc passes over `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode` (exact fp32, launch lanes off)\n",
 }
-for src, dst in (("pmc_x6_step.txt", "x6_step_pmc.txt"), ("lean3_bench.txt", "lean3_bench.txt"), ("conv32_b3_bench.txt", "conv32_split_bench.txt"),
+for src, dst in (("conv32_probe.txt", "conv32_probe.txt"), ("knockout.txt", "knockout.txt"),
+                 ("pmc_lean_fp32.txt", "pmc_lean_fp32.txt"),
+                 ("pmc_x6_step.txt", "x6_step_pmc.txt"), ("lean3_bench.txt", "lean3_bench.txt"), ("conv32_b3_bench.txt", "conv32_split_bench.txt"),
                  ("fused_multi.txt", "fused_multi.txt"), ("pmc_multi.txt", "fused_multi_pmc.txt"),
                  ("infer4_bf16_timeline_kernels.txt", "infer4_bf16_timeline_kernels.txt"),
                  ("hbm_kernels.txt", "hbm_kernels.txt"), ("infer4_bf16_variants.txt", "infer4_bf16_variants.txt"),
