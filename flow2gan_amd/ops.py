@@ -1125,8 +1125,13 @@ def dwnorm_bwd(x, gz, du, B, F, Cc, K, lens, w_dw, b_dw, beta, log_scale, cproj=
     ws = torch.empty(L.lib.f2g_dwnorm_bwd_workspace(B, F, Cc, up if cproj is not None else 1),
                      device=x.device, dtype=torch.float32)
     d.partials = ptr(ws)
-    if GEMM_TIMER is not None:   # read x, gz; write du
-        GEMM_TIMER.time_hbm(lambda: call("f2g_dwnorm_bwd", C.byref(d)), 12.0 * B * F * Cc, "dwnorm_bwd")
+    if GEMM_TIMER is not None:
+        # algorithmic bytes: read x and gz, write du; with a condition input its rows are read and its
+        # gradient rows written once per `up` frames (the gradient is consumed by the condition path's
+        # backward GEMM: required traffic, as the forward kernel's condition read is)
+        nb = 4.0 * B * F * Cc * (3.0 + ((1.0 / up if cproj is not None else 0.0)
+                                      + (1.0 / up if g_cproj is not None else 0.0)))
+        GEMM_TIMER.time_hbm(lambda: call("f2g_dwnorm_bwd", C.byref(d)), nb, "dwnorm_bwd")
     else:
         call("f2g_dwnorm_bwd", C.byref(d))
     return du

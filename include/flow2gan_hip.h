@@ -528,7 +528,12 @@ typedef struct {
   /* fwd / dgrad: 0 = exact fp32 MFMA; 1 = split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulation):
    * `w` is then the f2g_split_bf16 image of the same weight matrix, the patch is split while it
    * is staged in LDS; wgrad splits both staged operands (bf16 planes read with
-   * ds_read_b64_tr_b16: its reduction runs over pixels). */
+   * ds_read_b64_tr_b16: its reduction runs over pixels).
+   * 3 = fp32-CLASS products on the bf16 pipe (three bf16 pieces per value, six MFMAs per product, error
+   * <= ~2^-23 per product: f2g_gemm_desc.precision 3; conv32x6.hip): `w` is the f2g_split_bf16x3 image
+   * of the weight matrix -- fwd: of the packed (32, 27*32) matrix (ld = K = 864); dgrad: of the 27
+   * transposed tiles as an (864, 32) matrix (ld = K = 32) --, patch / gradient tiles are split while they
+   * are staged; wgrad takes the fp32 operands as they are. */
   int32_t precision;
   float* y;
   int64_t y_seq, y_line;
