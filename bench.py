@@ -363,7 +363,7 @@ def main():
                                             "hidden activation on chip)",
                                "lean": "gemm_lean_kernel (fp32 MFMA, zero-VALU K loop)",
                                "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
-                               "direct-conv": "conv32 / conv2ch direct kernels",
+                               "direct-conv": "conv32 direct kernels (the 32 -> 32 channel MRD band layers)",
                                "lean-streamk": "gemm_lean_kernel (stream-K)",
                                "x6": "gemm_x6_kernel (fp32 class on the bf16 pipe: three bf16 pieces per "
                                      "operand, six MFMAs per product)",

@@ -85,13 +85,6 @@ __device__ __forceinline__ void ld6(frag6& f, const unsigned char* p) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) f.v[ks][q] = *reinterpret_cast<const bf16x8*>(p + q * 64 + ks * 32);
 }
-__device__ __forceinline__ void mm6(const frag6& a, const frag6& b, f32x16& acc0, f32x16& acc1);
-__device__ __forceinline__ void tap6(const unsigned char* Ab, const unsigned char* Bb, f32x16& acc0, f32x16& acc1) {
-  frag6 a, b;
-  ld6(a, Ab);
-  ld6(b, Bb);
-  mm6(a, b, acc0, acc1);
-}
 __device__ __forceinline__ void mm6(const frag6& a, const frag6& b, f32x16& acc0, f32x16& acc1) {
 #if F2G_LABVAR & 16
 #pragma unroll
@@ -108,6 +101,12 @@ __device__ __forceinline__ void mm6(const frag6& a, const frag6& b, f32x16& acc0
   F2G_X6_PAIR(2, 0) F2G_X6_PAIR(1, 1) F2G_X6_PAIR(0, 2) F2G_X6_PAIR(1, 0) F2G_X6_PAIR(0, 1) F2G_X6_PAIR(0, 0)
 #undef F2G_X6_PAIR
 #endif
+}
+__device__ __forceinline__ void tap6(const unsigned char* Ab, const unsigned char* Bb, f32x16& acc0, f32x16& acc1) {
+  frag6 a, b;
+  ld6(a, Ab);
+  ld6(b, Bb);
+  mm6(a, b, acc0, acc1);
 }
 
 // x / D for 0 <= x < 512 and the staged widths that occur (39, 23: forward patch columns; 20, 12: gradient patch)

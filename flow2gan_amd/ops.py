@@ -701,11 +701,15 @@ def _conv2ch_desc(x, x_seq, x_line, x_off, S, H, W):
     return d
 
 
-def _timed(name, d, flops, shape):
+def _timed_hbm(name, nbytes, *args):
+    """The thin first / last layers of the discriminators (2 -> 32, 32 -> 1, 1 -> 32, 1024 -> 1 channels):
+    HBM-bound by design (one side of the layer is a 32- / 1024-channel map, the
+    reduction is 5 ... 288 long), so bench.py prices them against the HBM roofline by their algorithmic
+    bytes -- the wide map read or written once, the thin side once -- not against the MFMA peak."""
     if GEMM_TIMER is not None:
-        GEMM_TIMER.time(lambda: call(name, C.byref(d)), flops, shape)
+        GEMM_TIMER.time_hbm(lambda: call(name, *args), float(nbytes), name[4:])
     else:
-        call(name, C.byref(d))
+        call(name, *args)
 
 
 def conv2ch_fwd(x, x_seq, x_line, x_off, S, H, W, w_packed, bias, slope, y):
@@ -713,7 +717,7 @@ def conv2ch_fwd(x, x_seq, x_line, x_off, S, H, W, w_packed, bias, slope, y):
     interleaved spectrogram -> y (S*H*W, 32); w_packed (32, 54) as pack_conv_weight gives."""
     d = _conv2ch_desc(x, x_seq, x_line, x_off, S, H, W)
     d.w, d.bias, d.lrelu_slope, d.y = ptr(w_packed), ptr(bias), slope, ptr(y)
-    _timed("f2g_conv2ch_fwd", d, 2.0 * S * H * W * 32 * 54, (0, S * H * W, 32, 54))
+    _timed_hbm("f2g_conv2ch_fwd", 4.0 * S * H * W * (32 + 2), C.byref(d))      # write 32 channels, read 2
     return y
 
 
@@ -721,7 +725,7 @@ def conv2ch_wgrad(x, x_seq, x_line, x_off, S, H, W, g, gw):
     """gw (32, 54) += weight gradient of that layer; g = (S*H*W, 32) pre-activation gradient."""
     d = _conv2ch_desc(x, x_seq, x_line, x_off, S, H, W)
     d.y, d.gw = ptr(g), ptr(gw)
-    _timed("f2g_conv2ch_wgrad", d, 2.0 * S * H * W * 32 * 54, (2, 32, 54, S * H * W))
+    _timed_hbm("f2g_conv2ch_wgrad", 4.0 * S * H * W * (32 + 2), C.byref(d))
     return gw
 
 
@@ -731,7 +735,7 @@ def conv2ch_dgrad(g, S, H, W, wt, gx, gx_seq, gx_line, gx_off):
     d.y, d.wt = ptr(g), ptr(wt)
     d.gx = ptr(gx) + 4 * gx_off
     d.gx_seq, d.gx_line = gx_seq, gx_line
-    _timed("f2g_conv2ch_dgrad", d, 2.0 * S * H * W * 32 * 54, (1, S * H * W, 2, 864))
+    _timed_hbm("f2g_conv2ch_dgrad", 4.0 * S * H * W * (32 + 2), C.byref(d))
     return gx
 
 
@@ -739,21 +743,21 @@ def convpost_fwd(x, S, H, W, w9, bias, y):
     """Conv2d(32, 1, (3, 3), padding 1): x (S*H*W, 32) -> y (S*H*W); w9 = (9, 32) tap-major."""
     d = _conv2ch_desc(x, 0, 0, 0, S, H, W)
     d.w, d.bias, d.y = ptr(w9), ptr(bias), ptr(y)
-    _timed("f2g_convpost_fwd", d, 2.0 * S * H * W * 288, (0, S * H * W, 1, 288))
+    _timed_hbm("f2g_convpost_fwd", 4.0 * S * H * W * (32 + 1), C.byref(d))
     return y
 
 
 def convpost_wgrad(x, S, H, W, g, gw):
     d = _conv2ch_desc(x, 0, 0, 0, S, H, W)
     d.y, d.gw = ptr(g), ptr(gw)
-    _timed("f2g_convpost_wgrad", d, 2.0 * S * H * W * 288, (2, 1, 288, S * H * W))
+    _timed_hbm("f2g_convpost_wgrad", 4.0 * S * H * W * (32 + 1), C.byref(d))
     return gw
 
 
 def convpost_dgrad(g, S, H, W, w9, gx, g_off=0):
     d = _conv2ch_desc(None, 0, 0, 0, S, H, W)
     d.y, d.w, d.gx = ptr(g) + 4 * g_off, ptr(w9), ptr(gx)
-    _timed("f2g_convpost_dgrad", d, 2.0 * S * H * W * 288, (1, S * H * W, 32, 9))
+    _timed_hbm("f2g_convpost_dgrad", 4.0 * S * H * W * (32 + 1), C.byref(d))
     return gx
 
 
@@ -1365,29 +1369,21 @@ def _mpd0_desc(x, S, H, Hout, halo, w=None, bias=None, slope=0.0, y=None, x_off=
 def mpd0_fwd(x, S, H, Hout, halo, w5, bias, slope, y):
     """y (halo layout (S, Hout + 2*halo, 32)) = lrelu(conv(x (S, H); w5 (32, 5), stride 3, pad 2) + bias)."""
     d = _mpd0_desc(x, S, H, Hout, halo, w5, bias, slope, y)
-    _timed("f2g_mpd0_fwd", d, 2.0 * S * Hout * 32 * 5, (0, S * Hout, 32, 5))
+    _timed_hbm("f2g_mpd0_fwd", 4.0 * S * (Hout * 32 + H), C.byref(d))
     return y
 
 
 def mpd0_wgrad(x, S, H, Hout, halo, g, gw):
     """gw (32, 5) += weight gradient of the first MPD layer; g = gradient map (halo layout)."""
     d = _mpd0_desc(x, S, H, Hout, halo, y=g)
-    if GEMM_TIMER is not None:
-        GEMM_TIMER.time(lambda: call("f2g_mpd0_wgrad", C.byref(d), ptr(gw)), 2.0 * S * Hout * 32 * 5,
-                        (2, 32, 5, S * Hout))
-    else:
-        call("f2g_mpd0_wgrad", C.byref(d), ptr(gw))
+    _timed_hbm("f2g_mpd0_wgrad", 4.0 * S * (Hout * 32 + H), C.byref(d), ptr(gw))
     return gw
 
 
 def mpd0_dgrad(g, S, H, Hout, halo, w5, gx, g_off=0):
     """gx (S*H) = data gradient of the first MPD layer from the gradient map g (halo layout)."""
     d = _mpd0_desc(None, S, H, Hout, halo, w5, None, 0.0, g, y_off=g_off)
-    if GEMM_TIMER is not None:
-        GEMM_TIMER.time(lambda: call("f2g_mpd0_dgrad", C.byref(d), ptr(gx)), 2.0 * S * Hout * 32 * 5,
-                        (1, S * H, 1, 64))
-    else:
-        call("f2g_mpd0_dgrad", C.byref(d), ptr(gx))
+    _timed_hbm("f2g_mpd0_dgrad", 4.0 * S * (Hout * 32 + H), C.byref(d), ptr(gx))
     return gx
 
 
@@ -1402,25 +1398,20 @@ def _mpdpost_desc(y, S, H, halo, w3=None, bias=None, out=None, g=None, g_off=0, 
 
 def mpdpost_fwd(y, S, H, halo, w3, bias, out):
     """out (S*H) = conv_post of an MPD sub-discriminator over the 1024-channel map y (halo layout)."""
-    _timed("f2g_mpdpost_fwd", _mpdpost_desc(y, S, H, halo, w3, bias, out), 2.0 * S * H * 3072, (0, S * H, 1, 3072))
+    _timed_hbm("f2g_mpdpost_fwd", 4.0 * S * H * (1024 + 1), C.byref(_mpdpost_desc(y, S, H, halo, w3, bias, out)))
     return out
 
 
 def mpdpost_dgrad(g, S, H, halo, w3, gy, g_off=0):
     """gy (halo layout (S, H + 2*halo, 1024), halo rows pre-zeroed) = data gradient of conv_post."""
-    _timed("f2g_mpdpost_dgrad", _mpdpost_desc(gy, S, H, halo, w3, None, None, g, g_off), 2.0 * S * H * 3072,
-           (0, S * H, 1024, 3))
+    _timed_hbm("f2g_mpdpost_dgrad", 4.0 * S * H * (1024 + 1), C.byref(_mpdpost_desc(gy, S, H, halo, w3, None, None, g, g_off)))
     return gy
 
 
 def mpdpost_wgrad(y, S, H, halo, g, gw):
     """gw (3*1024, tap-major) += weight gradient of conv_post."""
     d = _mpdpost_desc(y, S, H, halo, None, None, None, g)
-    if GEMM_TIMER is not None:
-        GEMM_TIMER.time(lambda: call("f2g_mpdpost_wgrad", C.byref(d), ptr(gw)), 2.0 * S * H * 3072,
-                        (2, 1, 3072, S * H))
-    else:
-        call("f2g_mpdpost_wgrad", C.byref(d), ptr(gw))
+    _timed_hbm("f2g_mpdpost_wgrad", 4.0 * S * H * (1024 + 1), C.byref(d), ptr(gw))
     return gw
 
 

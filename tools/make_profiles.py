@@ -16,9 +16,9 @@ def stats(path, out, header):
         L.append(f"{n:66s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:9.1f} "
                  f"{float(r['MinNs'])/1e3:8.1f} {float(r['MaxNs'])/1e3:9.1f} {float(r['Percentage']):6.2f}")
     g = [r for r in rows if "gemm_kernel" in r["Name"] or "gemm_lean" in r["Name"] or "narrow_" in r["Name"]
-         or "conv32_" in r["Name"] or "conv2ch_" in r["Name"] or "convpost_" in r["Name"]]
+         or "conv32_" in r["Name"] or "gemm_x6" in r["Name"]]
     gc = sum(int(r["Calls"]) for r in g); gt = sum(float(r["TotalDurationNs"]) for r in g)
-    L.append(f"# all gemm_lean / gemm_kernel<...> / narrow_* / conv32_* / conv2ch_* / convpost_* dispatches (= the f2g_gemm-class launches bench.py times): {gc} calls, {gt/1e6:.1f} ms, average {gt/gc/1e3:.1f} us, "
+    L.append(f"# all gemm_lean / gemm_x6* / gemm_kernel<...> / narrow_* / conv32_* dispatches (= the MFMA-class launches bench.py times; the thin first / last discriminator layers -- conv2ch_*, convpost_*, mpd0_*, mpdpost_* -- are HBM class): {gc} calls, {gt/1e6:.1f} ms, average {gt/gc/1e3:.1f} us, "
              f"{100*gt/tot:.1f} % of kernel time")
     open(out, "w").write("\n".join(L) + "\n")
     print(L[1]); print(L[-1])
