@@ -21,6 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "common.h"
 
@@ -946,9 +949,24 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r,
 // the taps walk over them in LDS (a lane's fragment row = its output row's staged row + tap):
 // 260-320 staged rows instead of 5 x 256 per channel slab, about half the L2 -> CU traffic of
 // the kernel that is bound by exactly that.
-template <bool SK, int EP, int PM, int WM = 2, bool TAP = false>
+// SK: 0 one tile per block, 1 stream-K with atomic seams (linear epilogues, zeroed output),
+// 2 stream-K with seam FIX-UP (any epilogue, deterministic): the tiles are dealt to the XCDs in
+// contiguous runs of whole tiles, an XCD's blocks cut its run's (tile, slab) units into equal
+// consecutive ranges and walk them from the END: a block's last tile -- when it stops short of that
+// tile's final slab -- is computed first, its accumulators written to the block's workspace slot and
+// a flag raised; its first tile comes last, and when earlier slabs of that tile belong to lower
+// blocks it waits for their flags (raised long ago: they started with exactly that tile), adds
+// their partial sums in block order and runs the normal epilogue.  A block only ever waits for
+// lower-numbered blocks of its own XCD (dispatched before it), which never wait for it.
+struct lean_sk_ws {
+  float* ws;          // [grid][128 * 128] partial tiles
+  unsigned* flags;    // [grid], holds the epoch of the launch that last filled the slot
+  unsigned epoch;
+};
+
+template <int SK, int EP, int PM, int WM = 2, bool TAP = false>
 __global__ __launch_bounds__(WM * 128, 4 / WM)
-void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
+void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb, const lean_sk_ws W) {
   constexpr bool P3 = PM == 1 || PM == 2, HI = PM == 2, BF = PM == 3;
   constexpr int BKE = BF ? 64 : BK;   // elements per slab
   constexpr int ES = BF ? 2 : 4;      // bytes per element
@@ -992,7 +1010,21 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   const int nt_all = K / BKE;
   const int tiles_n = (N + BN - 1) / BN;
   int u = 0, u_end = 0;
-  if (SK) {
+  int fx_t0 = 0, fx_ub = 0, fx_upb = 1, fx_slot0 = 0, fx_idx = 0;   // (SK == 2)
+  if (SK == 2) {
+    const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    fx_idx = blockIdx.x >> 3;
+    const long long tiles_all = (long long)((M + BM - 1) / BM) * tiles_n;
+    fx_t0 = (int)(tiles_all * xcd / 8);
+    const int t1 = (int)(tiles_all * (xcd + 1) / 8);
+    const int units = (t1 - fx_t0) * nt_all;
+    fx_upb = (units + per - 1) / per;
+    fx_ub = fx_idx * fx_upb;
+    u_end = fx_ub + fx_upb < units ? fx_ub + fx_upb : units;   // walked downwards
+    fx_slot0 = xcd * per;
+    if (fx_ub >= u_end) return;
+  }
+  if (SK == 1) {
     const int G = gridDim.x;
     const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;  // XCD-contiguous
@@ -1005,6 +1037,23 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   while (more) {
     int m0, n0, s0, nt;
     bool first, partial;
+    bool fx_last = true;
+    int fx_tl = 0;
+    if (SK == 2) {
+      fx_tl = (u_end - 1) / nt_all;
+      const int tstart = fx_tl * nt_all;
+      const int sb = fx_ub > tstart ? fx_ub : tstart;
+      s0 = sb - tstart;
+      nt = u_end - sb;
+      first = s0 == 0;
+      fx_last = u_end == tstart + nt_all;
+      partial = false;
+      const int tg = fx_t0 + fx_tl, tm = tg / tiles_n;
+      m0 = tm * BM;
+      n0 = (tg - tm * tiles_n) * BN;
+      u_end = sb;
+      more = u_end > fx_ub;
+    } else
     if (!SK) {
       tile_of_block(BM, BN, m0, n0);
       const int kbeg = blockIdx.z * kchunk;
@@ -1383,6 +1432,58 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
     }
 
     }
+    if constexpr (SK == 2) {
+      // seam of the fix-up stream-K: 64 accumulators per thread as 16 float4 rows of 256 threads
+      // The partial tiles and the flags move as RELAXED agent-scope accesses: written through to / read
+      // from the level all XCDs share, without the L2 write-back and invalidate of a release / acquire
+      // pair (which would throw the operands of every other block of the XCD out of its L2).  Order:
+      // a wave's stores have completed (s_waitcnt) before it reaches the barrier in front of the flag.
+      if (!fx_last) {
+        float* w = W.ws + (size_t)(fx_slot0 + fx_idx) * (BM * BN) + tid;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              __hip_atomic_store(w + ((mi * 2 + ni) * 16 + e) * 256, acc[mi][ni][e], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0)
+          __hip_atomic_store(W.flags + fx_slot0 + fx_idx, W.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
+      if (!first) {
+        for (int bb = (fx_tl * nt_all) / fx_upb; bb < fx_idx; ++bb) {
+          const unsigned* fl = W.flags + fx_slot0 + bb;
+          if (tid == 0)
+            while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch)
+              __builtin_amdgcn_s_sleep(8);
+          __syncthreads();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const float* w = W.ws + (size_t)(fx_slot0 + bb) * (BM * BN) + tid;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              float v[16];
+#pragma unroll
+              for (int e = 0; e < 16; ++e)
+                v[e] = __hip_atomic_load(w + ((mi * 2 + ni) * 16 + e) * 256, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[mi][ni][e] += v[e];
+            }
+        }
+        first = true;   // the sums are complete: bias (in the accumulators) and residual enter here
+      }
+    }
+    // (SK == 2: the epilogue sits inside the loop over a block's tiles; opaque copies of the lane
+    // coordinates keep its 64 store addresses from being hoisted out of that loop into registers)
+    int li_e = li, h_e = h;
+    if constexpr (SK == 2) asm volatile("" : "+v"(li_e), "+v"(h_e));
     const f2g_epilogue& E = d.E;
     const bool simple = !partial && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
                         !E.atomic && !E.accumulate && E.scale == 0.f && !E.mask_src;
@@ -1392,23 +1493,23 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       const float sl = E.lrelu_slope;
       const bool pre = E.prelu_slope != nullptr, two = pre && E.prelu_out != nullptr;
       const bool cbf = E.c_bf16 != 0;
-      const unsigned coff = (unsigned)(((long long)(4 * h) * E.ldc + li) * 4);
-      const unsigned poff = (unsigned)(((long long)(4 * h) * E.ld_prelu_out + li) * 4);
+      const unsigned coff = (unsigned)(((long long)(4 * h_e) * E.ldc + li_e) * 4);
+      const unsigned poff = (unsigned)(((long long)(4 * h_e) * E.ld_prelu_out + li_e) * 4);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int col0 = n0 + (wn * 2 + ni) * 32;
           const int row0 = m0 + (wm * 2 + mi) * 32;
-          const float ps = (pre && col0 + li < N) ? E.prelu_slope[col0 + li] : 0.f;
+          const float ps = (pre && col0 + li_e < N) ? E.prelu_slope[col0 + li_e] : 0.f;
           const bool hasres = E.res != nullptr;
-          const float gam = (hasres && col0 + li < N) ? (E.gamma ? E.gamma[col0 + li] : 1.f) : 0.f;
+          const float gam = (hasres && col0 + li_e < N) ? (E.gamma ? E.gamma[col0 + li_e] : 1.f) : 0.f;
           if (row0 + 32 <= M && col0 + 32 <= N) {
             char* cb = reinterpret_cast<char*>(E.C + (long long)row0 * E.ldc + col0);
             __bf16* cb16 = reinterpret_cast<__bf16*>(E.C) + (long long)row0 * E.ldc + col0;
             char* pb = reinterpret_cast<char*>(E.prelu_out + (long long)row0 * E.ld_prelu_out + col0);
             const char* rb = reinterpret_cast<const char*>(E.res + (long long)row0 * E.ldres + col0);
-            const unsigned roff = (unsigned)(((long long)(4 * h) * E.ldres + li) * 4);
+            const unsigned roff = (unsigned)(((long long)(4 * h_e) * E.ldres + li_e) * 4);
             float rv[16];
             if (hasres) {   // all 16 residual values requested before any is consumed
 #pragma unroll
@@ -1427,7 +1528,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
                 else v = pv;
               }
               if (cbf)   // C is a bf16 tensor (ldc in elements): the next GEMM's operand as it is
-                cb16[(ro + 4 * h) * E.ldc + li] = (__bf16)v;
+                cb16[(ro + 4 * h_e) * E.ldc + li_e] = (__bf16)v;
               else
                 *reinterpret_cast<float*>(cb + ro * E.ldc * 4 + coff) = v;
             }
@@ -1435,18 +1536,18 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
           } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-              const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              const int row = row0 + (e & 3) + 8 * (e >> 2) + 4 * h_e;
               float v = acc[mi][ni][e];
-              if (hasres && row < M && col0 + li < N) v += gam * E.res[(long long)row * E.ldres + col0 + li];
+              if (hasres && row < M && col0 + li_e < N) v += gam * E.res[(long long)row * E.ldres + col0 + li_e];
               if (sl != 0.f) v = fmaxf(v, 0.f) + sl * fminf(v, 0.f);
-              if (row < M && col0 + li < N) {
+              if (row < M && col0 + li_e < N) {
                 if (pre) {
                   const float pv = fmaxf(v, 0.f) + ps * fminf(v, 0.f);
-                  if (two) E.prelu_out[(long long)row * E.ld_prelu_out + col0 + li] = pv;
+                  if (two) E.prelu_out[(long long)row * E.ld_prelu_out + col0 + li_e] = pv;
                   else v = pv;
                 }
-                if (cbf) reinterpret_cast<__bf16*>(E.C)[(long long)row * E.ldc + col0 + li] = (__bf16)v;
-                else E.C[(long long)row * E.ldc + col0 + li] = v;
+                if (cbf) reinterpret_cast<__bf16*>(E.C)[(long long)row * E.ldc + col0 + li_e] = (__bf16)v;
+                else E.C[(long long)row * E.ldc + col0 + li_e] = v;
               }
             }
           }
@@ -1457,14 +1558,14 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       // plain store (C may alias aux: each element is read before it is written by the same lane)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + (wn * 2 + ni) * 32 + li;
+        const int col = n0 + (wn * 2 + ni) * 32 + li_e;
         const bool cok = col < N;
         const float aln = cok ? E.alpha_n[col] : 0.f;
         float cs = 0.f, csa = 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-          const int row0 = m0 + (wm * 2 + mi) * 32 + 4 * h;
-          const bool full = cok && row0 - 4 * h + 32 <= M;
+          const int row0 = m0 + (wm * 2 + mi) * 32 + 4 * h_e;
+          const bool full = cok && row0 - 4 * h_e + 32 <= M;
           const float* ab = E.aux + (long long)row0 * E.ldaux + col;
           float* cb = E.C + (long long)row0 * E.ldc + col;
 #pragma unroll
@@ -1491,7 +1592,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         if (E.colsum || E.colsum_alpha) {
           cs += __shfl_xor(cs, 32);
           csa += __shfl_xor(csa, 32);
-          if (cok && h == 0) {
+          if (cok && h_e == 0) {
             if (E.colsum) atomicAdd(E.colsum + col, cs);
             if (E.colsum_alpha) atomicAdd(E.colsum_alpha + col, csa);
           }
@@ -1508,14 +1609,14 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
       const float fmw = fm ? E.fm_w * (E.fm_wdev ? E.fm_wdev[0] : 1.f) : 0.f;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + (wn * 2 + ni) * 32 + li;
+        const int col = n0 + (wn * 2 + ni) * 32 + li_e;
         const bool cok = col < N;
         float cs = 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row0 = m0 + (wm * 2 + mi) * 32;
           const int q0 = row0 / E.P0o;                         // uniform
-          const int p0 = row0 - q0 * E.P0o + 4 * h;            // position of this lane's first row
+          const int p0 = row0 - q0 * E.P0o + 4 * h_e;            // position of this lane's first row
           const long long cbase = E.off_o + col;
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
@@ -1527,7 +1628,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
               const int re = 8 * e4 + k;
               int p = p0 + re, q = q0;
               if (p >= E.P0o) { p -= E.P0o; ++q; }
-              ok[k] = cok && row0 + re + 4 * h < M;
+              ok[k] = cok && row0 + re + 4 * h_e < M;
               off[k] = cbase + (long long)q * E.seq_stride_o + (long long)p * E.row_stride_o;
               if (msk) yv[k] = ok[k] ? E.mask_src[off[k]] : 0.f;
               if (fm) rv[k] = ok[k] ? E.fm_ref[off[k]] : 0.f;
@@ -1554,14 +1655,14 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
         }
         if (E.colsum) {
           cs += __shfl_xor(cs, 32);
-          if (cok && h == 0) atomicAdd(E.colsum + col, cs);
+          if (cok && h_e == 0) atomicAdd(E.colsum + col, cs);
         }
       }
     } else {
       f2g_epilogue E2 = E;
       E2.bias = nullptr;   // already in the accumulators
       if (partial) { E2.atomic = 1; E2.accumulate = 0; }
-      gemm_epilogue<2, 2>(E2, acc, M, N, m0, n0, wm, wn, li, h, first);
+      gemm_epilogue<2, 2>(E2, acc, M, N, m0, n0, wm, wn, li_e, h_e, first);
     }
   }
 }
@@ -1611,7 +1712,47 @@ inline bool lean_b_ok(const f2g_operand& S) {
          (long long)S.rows * S.seq_stride * 4 < 0x7ff00000ll;
 }
 
-int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st) {
+// workspace of the fix-up stream-K launches: one per (device, stream) -- launches of a stream run one
+// after the other, launches of different streams must not share partial tiles or flags.  The flags are
+// never reset: every launch raises them to its own epoch.
+struct SkPool {
+  float* ws = nullptr;
+  unsigned* flags = nullptr;
+  unsigned epoch = 0;
+};
+constexpr int SKFIX_GRID = 512;   // two blocks on each of the 256 CUs
+
+inline bool sk_workspace(hipStream_t st, lean_sk_ws& W) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SkPool> pools;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;   // a replayed graph would repeat the epoch
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  SkPool& p = pools[{dev, st}];
+  if (!p.ws) {
+    if (hipMalloc(&p.ws, (size_t)SKFIX_GRID * 128 * 128 * sizeof(float)) != hipSuccess ||
+        hipMalloc(&p.flags, SKFIX_GRID * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(p.flags, 0, SKFIX_GRID * sizeof(unsigned), st) != hipSuccess) {
+      (void)hipGetLastError();
+      p = SkPool();
+      return false;
+    }
+  }
+  if (++p.epoch == 0) ++p.epoch;
+  W.ws = p.ws;
+  W.flags = p.flags;
+  W.epoch = p.epoch;
+  return true;
+}
+
+// skfix: stream-K with seam fix-up on SKFIX_GRID blocks (exact fp32, 128 x 128 tiles) instead of the tile grid
+int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st,
+                bool skfix = false) {
   // operand images: split = 1 -> split-bf16 pairs (precision 1: all three products, 2: high parts),
   // split = 2 -> true bf16 tensors (precision 2 only)
   const int pm = d.A.split == 2 ? 3 : (d.precision == 1 ? 1 : (d.precision == 2 ? 2 : 0));
@@ -1638,10 +1779,13 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
     const long long total = (long long)grid.x * grid.y * (K / bk);
     grid = dim3((unsigned)((total + upb - 1) / upb), 1, 1);
   }
+  lean_sk_ws W = {nullptr, nullptr, 0u};
+  if (skfix && (pm != 0 || upb > 0 || zs != 1 || tall || !sk_workspace(st, W))) skfix = false;
+  if (skfix) grid = dim3(SKFIX_GRID, 1, 1);
   // epilogue instance (see gemm_lean_kernel)
   const f2g_epilogue& E = d.E;
   int ep = 3;
-  if (upb == 0) {
+  if (upb == 0) {   // (the fix-up stream-K instances carry every epilogue)
     const bool plainish = !E.aux && !E.colsum_alpha && !E.atomic && !E.accumulate && E.scale == 0.f;
     if (plainish && !E.colsum && E.P0o == 0 && !E.mask_src) ep = 0;
     else if (E.aux && !E.res && E.P0o == 0 && !E.atomic && !E.accumulate && E.scale == 0.f &&
@@ -1654,7 +1798,11 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   }
   static bool attr_done = false;
   if (!attr_done) {
-    const void* ks[20] = {reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 0>),
+    const void* ks[24] = {reinterpret_cast<const void*>(gemm_lean_kernel<2, 0, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<2, 1, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<2, 2, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<2, 3, 0>),
+                          reinterpret_cast<const void*>(gemm_lean_kernel<false, 0, 0>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 1, 0>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 2, 0>),
                           reinterpret_cast<const void*>(gemm_lean_kernel<false, 3, 0>),
@@ -1692,43 +1840,48 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 320 + 2 * 128) * LDR * 4);
     attr_done = true;
   }
-  g_last_path = upb > 0 ? 2 : 1;
+  g_last_path = (upb > 0 || skfix) ? 2 : 1;
 #define F2G_LEAN(SKV, EPV)                                                                        \
   do {                                                                                            \
     if (pm == 1)                                                                                  \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 1>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb);                                                            \
+                         kchunk, upb, W);                                                         \
     else if (pm == 2)                                                                             \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 2>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb);                                                            \
+                         kchunk, upb, W);                                                         \
     else if (pm == 3)                                                                             \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 3>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb);                                                            \
+                         kchunk, upb, W);                                                         \
     else                                                                                          \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 0>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb);                                                            \
+                         kchunk, upb, W);                                                         \
   } while (0)
 #define F2G_LEAN_T(EPV)                                                                           \
   do {                                                                                            \
     if (pm == 1)                                                                                  \
       hipLaunchKernelGGL((gemm_lean_kernel<false, EPV, 1, 4>), grid, dim3(512), smem, st, d, M,   \
-                         N, K, kchunk, upb);                                                      \
+                         N, K, kchunk, upb, W);                                                   \
     else                                                                                          \
       hipLaunchKernelGGL((gemm_lean_kernel<false, EPV, 3, 4>), grid, dim3(512), smem, st, d, M,   \
-                         N, K, kchunk, upb);                                                      \
+                         N, K, kchunk, upb, W);                                                   \
   } while (0)
   if (tap && (ep == 2 || ep == 3)) {
     if (ep == 2)
       hipLaunchKernelGGL((gemm_lean_kernel<false, 2, 1, 4, true>), grid, dim3(512), smem, st, d, M, N, K,
-                         kchunk, upb);
+                         kchunk, upb, W);
     else
       hipLaunchKernelGGL((gemm_lean_kernel<false, 3, 1, 4, true>), grid, dim3(512), smem, st, d, M, N, K,
-                         kchunk, upb);
+                         kchunk, upb, W);
   } else if (tall) {
     if (ep == 0) F2G_LEAN_T(0);
     else if (ep == 1) F2G_LEAN_T(1);
     else if (ep == 2) F2G_LEAN_T(2);
     else F2G_LEAN_T(3);
+  } else if (skfix) {
+    if (ep == 0) hipLaunchKernelGGL((gemm_lean_kernel<2, 0, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
+    else if (ep == 1) hipLaunchKernelGGL((gemm_lean_kernel<2, 1, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
+    else if (ep == 2) hipLaunchKernelGGL((gemm_lean_kernel<2, 2, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
+    else hipLaunchKernelGGL((gemm_lean_kernel<2, 3, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
   } else
   if (upb > 0) F2G_LEAN(true, 3);
   else if (ep == 0) F2G_LEAN(false, 0);
@@ -2352,6 +2505,32 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
   long long upb = (total + 511) / 512;
   if (upb < 8) upb = 8;                          // at least 8 slabs per block (prologue / epilogue)
   return (int)upb;
+}
+
+// Fix-up stream-K decision (exact fp32 lean kernel, chip-filling grids): the classic grid runs
+// ceil(tiles / 512) rounds of two blocks per CU, and a grid that ends in a nearly empty round (the
+// generator's 564-tile and 282-tile 1x1 convs: 1.1 and 0.55 rounds) pays for a whole one on the CUs that
+// hold the extra blocks.  Dealing the (tile, slab) units evenly costs each block one partial tile
+// written and one read (2 x 64 KB beside the megabytes of operands its range streams).
+// Measured alone on the chip (us, classic -> dealt): 6016 x 768 x 2304 286 -> 184, 24064 x 384 x 1152 246 -> 207,
+// 12032 x 512 x 1536 197 -> 169, 6016 x 2304 x 768 214 -> 188; K = 384 (12 slabs a tile: three seams per
+// 40 slabs) 245 -> 255, and grids of many rounds gain nothing (2376 tiles: the thin last round already runs
+// one block per CU, faster).  So the rule: reductions of >= 16 slabs whose rounds are less than 90 % full.
+// In the training steps it is worth -6 ms with the launch lanes off (stage 2: 258.5 -> 252.5 ms, stage 1
+// 46.9 -> 43.6) and NOTHING with them on (231 +- 0.5 / 40.6 ms either way, gpurun_out/r4_skfix_step.txt):
+// the lanes already fill a ragged round's idle CUs with another lane's blocks, and a kernel that holds all
+// 512 slots for its whole duration leaves them nothing to fill.  Hence off by default.
+// F2G_SKFIX: 0 off (default), 1 that rule (F2G_SKFIX_EFF / F2G_SKFIX_MIN_SLABS move it), 2 every chip-filling grid.
+inline bool lean_sk_fix(int M, int N, int K, int mode) {
+  static const double thr = getenv("F2G_SKFIX_EFF") ? atof(getenv("F2G_SKFIX_EFF")) : 0.90;
+  static const int min_nt = getenv("F2G_SKFIX_MIN_SLABS") ? atoi(getenv("F2G_SKFIX_MIN_SLABS")) : 16;
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const int nt = K / BK;
+  if (tiles * 2 <= 256 || tiles * nt < 512ll * 12) return false;   // (latency regime: lean_stream_k)
+  if (mode > 1) return true;
+  if (nt < min_nt) return false;
+  const double rounds = (double)tiles / 512.0;
+  return rounds / (double)((tiles + 511) / 512) < thr;
 }
 
 }  // namespace
@@ -3202,6 +3381,10 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       // library-chosen work split on the lean kernel: stream-K (same linear-epilogue condition as
       // split-K; F2G_DETERMINISTIC=1 keeps the plain tile grid)
       static const int sk_mode = getenv("F2G_STREAMK") ? atoi(getenv("F2G_STREAMK")) : 1;
+      const char* skfix_env = getenv("F2G_SKFIX");   // (read per call: the tests switch it)
+      const int skfix_mode = skfix_env ? atoi(skfix_env) : 0;
+      if (skfix_mode > 0 && d.precision == 0 && !d.A.split && !d.E.atomic && lean_sk_fix(M, N, K, skfix_mode))
+        return launch_lean(d, M, N, K, 1, 0, st, true);   // (deterministic: F2G_DETERMINISTIC keeps it)
       int upb = 0;
       if (sk_mode > 0 && linear && !no_auto && !d.E.atomic && !d.E.c_bf16)
         upb = lean_stream_k(M, N, bf16img ? K / 2 : K, sk_mode > 1);   // (64-element slabs)

@@ -884,6 +884,10 @@ def set_gemm_precision(name: str) -> None:
 # kernels in isolation) runs the lanes one after the other on the caller's stream.
 CONCURRENT = _os.environ.get("F2G_STREAMS", "1") != "0"
 _SIDE_STREAMS: dict = {}
+# F2G_LANE_CAP="mpd=3,mrd=2": at most that many streams behind the lanes of a pool (lane i -> stream i % cap;
+# a measurement aid: how much concurrency the step wants)
+_LANE_CAP = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in _os.environ.get("F2G_LANE_CAP", "").split(",")
+             if "=" in kv}
 
 
 def _side_streams(device, n: int, pool_name: str):
@@ -892,9 +896,10 @@ def _side_streams(device, n: int, pool_name: str):
     idx = torch.device(device).index
     key = (idx if idx is not None else torch.cuda.current_device(), pool_name)
     pool = _SIDE_STREAMS.setdefault(key, [])
-    while len(pool) < n:
+    cap = max(1, min(n, _LANE_CAP.get(pool_name, n)))
+    while len(pool) < cap:
         pool.append(torch.cuda.Stream(device=device))
-    return pool[:n]
+    return [pool[i % cap] for i in range(n)]
 
 
 class Lanes:

@@ -299,6 +299,70 @@ def test_gemm_dgrad_with_prelu_grad(ops, R, K, N):
     close(auxd, want, name="dgrad-inplace")
 
 
+@pytest.mark.parametrize("R,K,N,force", [(6011, 2304, 768, False), (4100, 1024, 700, True), (9000, 384, 1100, True),
+                                         (24064, 1152, 384, False)])
+def test_lean_streamk_with_seam_fixup(ops, R, K, N, force, monkeypatch):
+    """Exact-fp32 lean GEMM dealt out as equal (tile, slab) ranges over 512 blocks (F2G_SKFIX=1: ragged tile
+    grids such as the generator's 282- and 564-tile 1x1 convs, F2G_SKFIX=2 everywhere): tiles cut between blocks
+    are completed from the lower blocks' partial sums BEFORE the epilogue, so every epilogue stays
+    available -- bias, two-output PReLU, (in-place) residual * gamma, PReLU backward with column sums,
+    row-mapped store with leaky ReLU, accumulate -- and the result does not depend on timing."""
+    if ops.GEMM_PRECISION != 0:
+        pytest.skip("a test of the exact-fp32 kernel (the suite runs under F2G_GEMM=" + str(ops.GEMM_PRECISION) + ")")
+    monkeypatch.setenv("F2G_SKFIX", "2" if force else "1")   # (off by default: the launch lanes make it moot)
+    lib = ops.L.lib
+    A, W, b = rnd(R, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3)
+    res, gam, ps = rnd(R, N, seed=4), rnd(N, seed=5), rnd(N, seed=6) * 0.3
+    Ad, Wd = g(A), g(W)
+    ref = (g(A).double() @ g(W).double().t() + g(b).double()).cpu()
+    out = torch.empty(R, N, device=DEV)
+    ops.gemm(ops.mat(Ad), ops.mat(Wd), out, bias=g(b))
+    assert lib.f2g_gemm_last_path() == 2, "the ragged grid did not take the stream-K instance"
+    close(out, ref, name="skfix plain")
+    again = torch.empty(R, N, device=DEV)
+    ops.gemm(ops.mat(Ad), ops.mat(Wd), again, bias=g(b))
+    assert torch.equal(out, again), "seam fix-up must be deterministic"
+    monkeypatch.setenv("F2G_SKFIX", "0")
+    ops.gemm(ops.mat(Ad), ops.mat(Wd), again, bias=g(b))
+    assert lib.f2g_gemm_last_path() == 1
+    monkeypatch.setenv("F2G_SKFIX", "2" if force else "1")
+    assert float((out - again).abs().max()) <= 2e-5 * float(ref.abs().max())
+    pre, act = torch.empty(R, N, device=DEV), torch.empty(R, N, device=DEV)
+    ops.gemm(ops.mat(Ad), ops.mat(Wd), pre, bias=g(b), prelu=g(ps), prelu_out=act)
+    assert lib.f2g_gemm_last_path() == 2
+    close(pre, ref, name="skfix pre")
+    close(act, torch.where(ref > 0, ref, ref * ps.double()[None]), name="skfix prelu")
+    io = g(res)
+    ops.gemm(ops.mat(Ad), ops.mat(Wd), io, bias=g(b), res=io, gamma=g(gam))
+    assert lib.f2g_gemm_last_path() == 2
+    close(io, ref + gam.double() * res.double(), name="skfix residual in place")
+    # PReLU backward + both column sums (the generator's data gradient through pw2)
+    aux, alpha = rnd(R, N, seed=7), rnd(N, seed=8) * 0.3
+    cs, cs_a = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    dg = torch.empty(R, N, device=DEV)
+    ops.gemm(ops.mat(Ad), ops.mat(Wd), dg, aux=g(aux), alpha_n=g(alpha), colsum=cs, colsum_alpha=cs_a)
+    assert lib.f2g_gemm_last_path() == 2
+    dp = ref - b.double()
+    want = dp * torch.where(aux > 0, torch.ones_like(aux), alpha[None].expand_as(aux)).double()
+    close(dg, want, name="skfix prelu-bwd")
+    close(cs, want.sum(0), rtol=1e-4, name="skfix colsum")
+    close(cs_a, (dp * aux.clamp(max=0).double()).sum(0), rtol=1e-4, name="skfix colsum_alpha")
+    # row-mapped store into a halo layout with leaky ReLU (the MPD maps)
+    P0 = 50 if R % 50 == 0 else 47
+    if R % P0 == 0:
+        S, HALO = R // P0, 2
+        halo = torch.full((S, P0 + 2 * HALO, N), 3.0, device=DEV)
+        ops.gemm(ops.mat(Ad), ops.mat(Wd), halo, bias=g(b), lrelu=0.1,
+                 rowmap=(P0, (P0 + 2 * HALO) * N, N, HALO * N))
+        assert lib.f2g_gemm_last_path() == 2
+        close(halo[:, HALO:HALO + P0].reshape(R, N), F.leaky_relu(ref, 0.1), name="skfix rowmap")
+        assert float(halo[:, :HALO].min()) == 3.0 and float(halo[:, HALO + P0:].max()) == 3.0
+    # accumulate (generic epilogue)
+    acc = g(res)
+    ops.gemm(ops.mat(Ad), ops.mat(Wd), acc, accumulate=True, split_k=0)
+    close(acc, res.double() + dp, name="skfix accumulate")
+
+
 @pytest.mark.parametrize("R,M,N", [(3000, 96, 40), (700, 514, 48), (5000, 32, 864), (130, 1536, 512)])
 def test_gemm_wgrad_splitk(ops, R, M, N):
     dY, X = rnd(R, M, seed=1), rnd(R, N, seed=2)
