@@ -355,8 +355,18 @@ def main():
         dom = max(fam.items(), key=lambda kv: kv[1][2])
         dn, (dl, dfl, dsec) = dom
         alg_bytes = timer.algorithmic_bytes(dn) / max(1, dl)
-        # the dense MFMA peak of the arithmetic the pass ran in
-        peak = PEAK_BF16_MFMA_TFLOPS if args.gemm == "bf16" else PEAK_FP32_MFMA_TFLOPS
+        # the dense MFMA peak of the arithmetic a family ran in.  bf16x6 mode: the six-product families (the
+        # x6 GEMM kernels, the conv32x6 direct convs) run on the bf16 pipe with six MFMAs per product = 2500 / 6
+        # TFLOP/s of fp32-class products; what stays on the exact fp32 MFMA is priced against that pipe
+        def family_peak(name):
+            if args.gemm == "bf16":
+                return PEAK_BF16_MFMA_TFLOPS
+            if args.gemm == "bf16x6" and (name == "x6" or (name == "direct-conv" and ops.CONV32_X6)):
+                return PEAK_BF16_MFMA_TFLOPS / 6.0
+            return PEAK_FP32_MFMA_TFLOPS
+        peak = family_peak(dn)
+        # (mixed pipes: the time the families would need at their peaks over the time they took)
+        class_frac = sum(v[1] / 1e12 / family_peak(k) for k, v in fam.items()) / secs
         roofline = {"bound": "mfma",
                     "kernel": {"fused-mlp": "fused_mlp_kernel (whole ConvNeXt block: dwconv7 + BiasNorm in the "
                                             "prologue, pwconv1 -> PReLU -> pwconv2 on bf16 MFMA, z and the "
@@ -365,28 +375,38 @@ def main():
                                "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
                                "direct-conv": "conv32 direct kernels (the 32 -> 32 channel MRD band layers)",
                                "lean-streamk": "gemm_lean_kernel (stream-K)",
-                               "x6": "gemm_x6_kernel (fp32 class on the bf16 pipe: three bf16 pieces per "
-                                     "operand, six MFMAs per product)",
+                               "x6": "gemm_x6t8 / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
+                                     "pieces per operand, six MFMAs per product)",
                                "narrow": "narrow VALU kernels"}.get(dn, dn),
                     # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
-                    "achieved": round(dfl / dsec / 1e12, 2), "peak": peak,
+                    "achieved": round(dfl / dsec / 1e12, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(dfl / dsec / 1e12 / peak, 4),
+                    "peak_basis": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32-class product"
+                                   if peak == PEAK_BF16_MFMA_TFLOPS / 6.0 else
+                                   "dense bf16 MFMA peak" if peak == PEAK_BF16_MFMA_TFLOPS else
+                                   "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     # traffic: HBM bytes per launch from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
                     # recorded with THIS build of the library, else null); beside it what one launch must
                     # move at least: both operands read once, the result written once
                     "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
+                    # (six-product families only) what a bare stream of these MFMAs sustains on real operand data:
+                    # the spec peak assumes clocks the bf16 pipe does not hold under load
+                    **({"sustained": {"peak": 267.0, "frac": round(dfl / dsec / 1e12 / 267.0, 4),
+                                      "source": "bare six-MFMA stream, tools/micro/mfma_peak.hip (power-limited clocks)"}}
+                       if peak == PEAK_BF16_MFMA_TFLOPS / 6.0 else {}),
                     "launches_per_step": dl,
                     "avg_launch_us": round(1e6 * dsec / dl, 1),
                     "share_of_mfma_class_time": round(dsec / secs, 3),
                     # every MFMA-class launch of the step (all GEMM families + direct convs); the
                     # extra step runs with the launch lanes off (one stream, each kernel alone on the
                     # chip), so these durations sum to more than a laned step
-                    "mfma_class": {"achieved": round(achieved, 2), "frac": round(achieved / peak, 4),
+                    "mfma_class": {"achieved": round(achieved, 2), "frac": round(class_frac, 4),
                                    "launches_per_step": n, "ms_per_step_serialised": round(1e3 * secs, 2),
                                    "algorithmic_tflop_per_step": round(flops / 1e12, 3),
                                    "by_family": {k: {"launches": v[0], "tflop": round(v[1] / 1e12, 3),
                                                      "ms": round(1e3 * v[2], 2),
-                                                     "tflops": round(v[1] / v[2] / 1e12, 1)}
+                                                     "tflops": round(v[1] / v[2] / 1e12, 1),
+                                                     "peak": round(family_peak(k), 1)}
                                                  for k, v in sorted(fam.items())}},
                     # HBM-bound kernel class, in-step: algorithmic bytes / HIP-event
                     # time per kernel, against the 8 TB/s spec peak
@@ -430,7 +450,9 @@ def main():
             "host_issue_ms_per_step": host_issue_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (split-bf16 GEMM, fp32 accumulate)",
-                      "bf16x6": "f32 (three-piece bf16 GEMM for the generator's plain GEMMs, fp32 accumulate)",
+                      "bf16x6": "f32 (fp32-class products on the bf16 matrix pipe for the long reductions and the "
+                                "direct MRD convs: three bf16 pieces per operand, six MFMAs per product, fp32 "
+                                "accumulate; short reductions on the exact fp32 MFMA)",
                       "bf16": "bf16 GEMM operands, fp32 accumulate / activations"}[args.gemm],
             "data": "synthetic (0.1*randn clipped, seeded per rank); seeded random-init weights",
             "config": {"workload": args.model + " " + {
