@@ -343,9 +343,10 @@ def main():
         traffic = None
         import glob
         pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                             "r*_pmc_gemm_traffic.json")))
-        pmc = pmcs[-1] if pmcs else ""            # the newest round's PMC pass
-        if (args.workload == "gan_stage2" and args.gemm == "fp32" and args.model == "mel_24k_base"
+                                             "r*_pmc_x6_traffic.json" if args.gemm == "bf16x6"
+                                             else "r*_pmc_gemm_traffic.json")))
+        pmc = pmcs[-1] if pmcs else ""            # the newest round's PMC pass (of this mode's dominant family)
+        if (args.workload == "gan_stage2" and args.gemm in ("fp32", "bf16x6") and args.model == "mel_24k_base"
                 and B == 64 and nts == 1 and os.path.exists(pmc)):
             with open(pmc) as f:
                 pj = json.load(f)

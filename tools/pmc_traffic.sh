@@ -14,3 +14,11 @@ for set in FETCH_SIZE WRITE_SIZE; do
   find $O/pmcb_$set -type f ! -name "p_counter_collection.csv" -delete
 done
 cd $R && python3 tools/pmc_traffic_json.py $O/r04_pmc_gemm_traffic.json && cat $O/r04_pmc_gemm_traffic.json
+# the same for the bf16x6 mode's dominant family (the six-product GEMM kernels) -> r04_pmc_x6_traffic.json
+cd /tmp
+for set in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmcb_x6_$set
+  F2G_STREAMS=0 timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcb_x6_$set -o p -- $B1 --gemm bf16x6 > /dev/null 2>&1
+  find $O/pmcb_x6_$set -type f ! -name "p_counter_collection.csv" -delete
+done
+cd $R && MODE=bf16x6 python3 tools/pmc_traffic_json.py $O/r04_pmc_x6_traffic.json && cat $O/r04_pmc_x6_traffic.json
