@@ -293,6 +293,14 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
             e.fm_wdev = ptr(fm[3])
     d.E = e
     d.form = form
+    if split_k == -1:
+        # weight gradient, factor chosen here: where the exact-fp32 launch takes the K-major lean kernel anyway
+        # (>= 4096 rows per block with the general rule's factor), its blocks are dealt in rounds of 512
+        tiles = ((A.cols + 127) // 128) * ((Bm.cols + 127) // 128)
+        split_k = split_for(A.rows, tiles)
+        if (WGRAD_SPLIT512 and form == 2 and GEMM_PRECISION == 0 and atomic and A.rows // split_k >= 4096
+                and ((Bm.P0 == 1 and Bm.P1 == 1) or Bm.P0 >= 16) and L.lib.f2g_gemm_lean_ok(C.byref(d))):
+            split_k = split_for(A.rows, tiles, True)
     d.split_k = split_k
     d.precision = GEMM_PRECISION
     if GEMM_PRECISION == 3:
@@ -453,6 +461,7 @@ def _bf16_operand(o: Operand) -> Operand:
     return n
 
 
+WGRAD_SPLIT512 = _os.environ.get("F2G_WGRAD_SPLIT512", "1") != "0"
 X6_MIN_ROWS = int(_os.environ.get("F2G_X6_MIN_ROWS", "1024"))
 # measured in the step (profiles/r03_x6_step.txt): the six-product kernel beats the fp32 lean kernel from
 # reductions of ~2000 on (184 against 131 TFLOP/s at K = 5120, 137 : 121 at 2048) and loses below ~1200
@@ -949,8 +958,14 @@ class Lanes:
             self.main.wait_event(ev)
 
 
-def split_for(reduction_rows: int, out_tiles: int) -> int:
+def split_for(reduction_rows: int, out_tiles: int, two_per_cu: bool = False) -> int:
     """Split-K factor for weight-gradient GEMMs (form 2; 128 x 128 output tiles, atomic accumulation).
+
+    two_per_cu: the launch is known to take the exact-fp32 K-major lean kernel (two blocks per CU, >= 4096
+    rows per block): rounds of 512 instead of 256.  Measured on the MPD's 1024-channel layers
+    (tools/micro/leanw_win_probe.py, 5 sequence heights x 9 factors): 320 tiles x 4 = 1280 blocks = 2.5 rounds
+    runs at 105-132 TFLOP/s depending on the height, x 8 = 2560 = 5 rounds at 128-134 for all of them; 160
+    tiles x 8 at 106-128, x 3 = 480 co-resident blocks at 122-127.
 
     Measured (tools/wgrad_probe.py, 14 shapes x 15 factors): what matters is how the blocks =
     tiles * s fill ROUNDS OF 256 (one block per CU) -- a count just above a multiple of 256 is the
@@ -960,15 +975,19 @@ def split_for(reduction_rows: int, out_tiles: int) -> int:
     fills (fewer atomics); a chunk keeps >= 16 K slabs."""
     slabs = max(1, reduction_rows // 32)
     smax = max(1, min(512, slabs // 16))
+    R = 256
+    if two_per_cu:
+        R = 512
+        smax = max(1, min(smax, reduction_rows // 4096))
     cands = set(range(1, min(smax, 64) + 1))
     for m in range(1, 9):
-        s = (256 * m) // out_tiles
+        s = (R * m) // out_tiles
         if 1 <= s <= smax:
             cands.add(s)
 
     def fill(s):
         b = out_tiles * s
-        return b / (((b + 255) // 256) * 256)
+        return b / (((b + R - 1) // R) * R)
 
     best = max(fill(s) for s in cands)
     pair = [s for s in cands if out_tiles * s <= 512 and fill(s) >= best - 0.05]
@@ -982,9 +1001,7 @@ def wgrad(dY, M: int, ldy: int, X: Operand, g_out, ldg: Optional[int] = None, ou
     """g_out[m, c] += sum_r dY[r, m] * X[r, c]   (atomic split-K; g_out must be initialised)."""
     rows = X.rows
     A = mat(dY, rows, M, ldy, lrelu_src=dy_lrelu_src, slope=slope)
-    tiles = ((M + 127) // 128) * ((X.cols + 127) // 128)
-    gemm(A, X, g_out, form=2, ldc=ldg, atomic=True, split_k=split_for(rows, tiles),
-         out_offset=out_offset)
+    gemm(A, X, g_out, form=2, ldc=ldg, atomic=True, split_k=-1, out_offset=out_offset)   # -1: split_for, in gemm()
 
 
 # ------------------------------------------------------------------ fused pointwise MLP (bf16)
