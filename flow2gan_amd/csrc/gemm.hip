@@ -1019,6 +1019,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
     const int t1 = (int)(tiles_all * (xcd + 1) / 8);
     const int units = (t1 - fx_t0) * nt_all;
     fx_upb = (units + per - 1) / per;
+    if (upb == 1) fx_upb = (fx_upb + nt_all - 1) / nt_all * nt_all;   // (F2G_SKFIX=3: whole tiles per block, no seams)
     fx_ub = fx_idx * fx_upb;
     u_end = fx_ub + fx_upb < units ? fx_ub + fx_upb : units;   // walked downwards
     fx_slot0 = xcd * per;
@@ -1782,6 +1783,7 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   lean_sk_ws W = {nullptr, nullptr, 0u};
   if (skfix && (pm != 0 || upb > 0 || zs != 1 || tall || !sk_workspace(st, W))) skfix = false;
   if (skfix) grid = dim3(SKFIX_GRID, 1, 1);
+  const int fx_whole = skfix && getenv("F2G_SKFIX") && atoi(getenv("F2G_SKFIX")) == 3 ? 1 : 0;
   // epilogue instance (see gemm_lean_kernel)
   const f2g_epilogue& E = d.E;
   int ep = 3;
@@ -1878,10 +1880,10 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
     else if (ep == 2) F2G_LEAN_T(2);
     else F2G_LEAN_T(3);
   } else if (skfix) {
-    if (ep == 0) hipLaunchKernelGGL((gemm_lean_kernel<2, 0, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
-    else if (ep == 1) hipLaunchKernelGGL((gemm_lean_kernel<2, 1, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
-    else if (ep == 2) hipLaunchKernelGGL((gemm_lean_kernel<2, 2, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
-    else hipLaunchKernelGGL((gemm_lean_kernel<2, 3, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, upb, W);
+    if (ep == 0) hipLaunchKernelGGL((gemm_lean_kernel<2, 0, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
+    else if (ep == 1) hipLaunchKernelGGL((gemm_lean_kernel<2, 1, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
+    else if (ep == 2) hipLaunchKernelGGL((gemm_lean_kernel<2, 2, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
+    else hipLaunchKernelGGL((gemm_lean_kernel<2, 3, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
   } else
   if (upb > 0) F2G_LEAN(true, 3);
   else if (ep == 0) F2G_LEAN(false, 0);
@@ -2521,6 +2523,8 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
 // the lanes already fill a ragged round's idle CUs with another lane's blocks, and a kernel that holds all
 // 512 slots for its whole duration leaves them nothing to fill.  Hence off by default.
 // F2G_SKFIX: 0 off (default), 1 that rule (F2G_SKFIX_EFF / F2G_SKFIX_MIN_SLABS move it), 2 every chip-filling grid.
+// (3: as 2 with block ranges rounded up to whole tiles = a persistent tile walk without seams: slower than the
+// classic grid on every shape measured -- the dispatcher's dynamic balance beats the saved block turnover)
 inline bool lean_sk_fix(int M, int N, int K, int mode) {
   static const double thr = getenv("F2G_SKFIX_EFF") ? atof(getenv("F2G_SKFIX_EFF")) : 0.90;
   static const int min_nt = getenv("F2G_SKFIX_MIN_SLABS") ? atoi(getenv("F2G_SKFIX_MIN_SLABS")) : 16;
