@@ -428,3 +428,17 @@ def test_checkpoint_roundtrip_and_model_averaging(tmp_path):
             assert torch.equal(v, ref[k]), k
         ref_plain = rck.average_checkpoints([str(f) for f in files])
         assert all(torch.equal(plain[k], ref_plain[k]) for k in plain)
+
+
+def test_weight_gradient_split_rule():
+    """ops.split_for: blocks = tiles x factor fill rounds of 256 (one block per CU), or of 512 where the
+    launch is known to take the two-blocks-per-CU K-major kernel (>= 4096 rows per block) -- the MPD's
+    1024-channel layers at B = 64 (tools/micro/leanw_win_probe.py), the generator's shapes unchanged."""
+    from flow2gan_amd import ops
+    assert ops.split_for(43648, 320) == 4 and ops.split_for(43648, 320, True) == 8      # 2560 blocks = 5 rounds of 512
+    assert ops.split_for(39168, 160) == 8 and ops.split_for(39168, 160, True) == 3      # 480 co-resident blocks
+    for rows, tiles in ((24064, 27), (6016, 108), (12032, 48), (114048, 20), (341376, 2)):
+        s = ops.split_for(rows, tiles)
+        assert 1 <= s <= 512 and rows // s >= 16 * 32, (rows, tiles, s)                 # a chunk keeps >= 16 slabs
+        s2 = ops.split_for(rows, tiles, True)
+        assert s2 == 1 or rows // s2 >= 4096, (rows, tiles, s2)                          # never below the kernel's rule
