@@ -8,5 +8,7 @@ mkdir -p gpurun_out
 tail -4 gpurun_out/gputest_final.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1
+cp gpurun_out/r04_pmc_gemm_traffic.json gpurun_out/r04_pmc_x6_traffic.json profiles/   # (bench.py reads profiles/)
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+python bench.py --gemm bf16x6 --no-fast-mode > gpurun_out/bench_x6_candidate.json 2>/dev/null
 tail -c 400 gpurun_out/bench_default.json
