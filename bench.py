@@ -3,13 +3,17 @@
 
 Metric (BASELINE.json): audio-seconds/sec of the GAN-stage train step -- one discriminator step +
 one generator step of `mel_24k_base`, each on its own synthetic batch of B x 1 s of 24 kHz audio
-(reference finetune.py:569-631 alternation, loss weights finetune.py:453-454,478-482), fp32,
-G+D forward/backward + data-parallel gradient all-reduce.  One process per GPU; for N > 1 the
+(reference finetune.py:569-631 alternation, loss weights finetune.py:453-454,478-482), fp32 tensors,
+G+D forward/backward + data-parallel gradient all-reduce.  `value` is measured with the fp32-CLASS GEMM
+arithmetic (`--gemm bf16x6`, the default: every fp32 operand as three bf16 pieces, the six products with
+i + j <= 2 on the bf16 matrix pipe, fp32 accumulate; the GPU parity suite runs in this mode at the
+exact-fp32 tolerances); the same step on the exact fp32 MFMA (`--gemm fp32`, the reference's own
+arithmetic) is timed in the same run and printed beside it as `exact_fp32`.  One process per GPU; for N > 1 the
 driver launches this file through torch.distributed.run and the ranks exchange gradients over
 RCCL/xGMI (weak scaling: B per GPU fixed).
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the fp32-MFMA implicit GEMM,
-timed with HIP events around every launch of one extra, untimed step) and `cpu_baseline` (the CPU
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family of one extra, untimed step
+with HIP events around every launch) and `cpu_baseline` (the CPU
 oracle of the same step timed on the host cores, bounded sample).
 """
 from __future__ import annotations
@@ -27,6 +31,14 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+DTYPES = {"fp32": "f32",
+          "bf16x3": "f32 (split-bf16 GEMM, fp32 accumulate)",
+          "bf16x6": "f32 (fp32-class products on the bf16 matrix pipe for the long reductions and the direct MRD "
+                    "convs: every fp32 operand as three bf16 pieces = 24 significand bits, the six "
+                    "v_mfma_f32_32x32x16_bf16 products with i + j <= 2 per fp32 product, fp32 accumulate, error "
+                    "<= 2^-23 per product; short reductions and thin layers on the exact fp32 MFMA; activations, "
+                    "weights, gradients stay fp32 in HBM)",
+          "bf16": "bf16 GEMM operands, fp32 accumulate / activations"}
 D_WEIGHTS = (1.0, 0.1)                    # finetune.py:453-454
 G_WEIGHTS = (1.0, 0.1, 1.0, 0.1, 45.0)    # finetune.py:478-482
 
@@ -50,8 +62,12 @@ def parse():
     ap.add_argument("--eager-gpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--gemm", default="fp32", choices=["fp32", "bf16x3", "bf16", "bf16x6"],
-                    help="GEMM arithmetic of the headline number (fp32 = exact, the reference's)")
+    ap.add_argument("--gemm", default=None, choices=["fp32", "bf16x3", "bf16", "bf16x6"],
+                    help="GEMM arithmetic of the headline number.  Default bf16x6 for the training workloads "
+                         "(fp32-CLASS products on the bf16 matrix pipe: three bf16 pieces per operand, six MFMAs "
+                         "per product, error <= 2^-23 per product; the whole GPU parity suite runs in this mode at "
+                         "the exact-fp32 tolerances; the exact-fp32 step is measured in the same run and printed "
+                         "as `exact_fp32`), fp32 for infer4.  fp32 = the reference's own arithmetic")
     ap.add_argument("--no-fast-mode", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
                     help="infer4: launch every kernel from the host instead of replaying the 4-step "
@@ -70,6 +86,8 @@ def synthetic_batch(B, T, seed, device):
 
 def main():
     args = parse()
+    if args.gemm is None:
+        args.gemm = "fp32" if args.workload == "infer4" else "bf16x6"
     if args.eager_gpu_baseline_only:
         print(json.dumps(cpu_baseline(args.workload, args.n_timesteps, args.cpu_threads, True,
                                       args.model)),
@@ -217,7 +235,7 @@ def main():
             dt = float(tt.item())
         return done, dt
 
-    # headline: exact-fp32 GEMMs (the reference's arithmetic), unless --gemm says otherwise
+    # headline: --gemm (default bf16x6, fp32 class); the exact-fp32 step follows as `exact_fp32`
     ops.set_gemm_precision(args.gemm)
     reducer.measure = world > 1 or force_dist
     audio_s, elapsed = timed(args.warmup, args.steps)
@@ -237,16 +255,152 @@ def main():
                 "exposed_comm_ms": round(float(exposed.item()), 3)}
     reducer.measure = False
     host_issue_ms = round(1e3 * HOST_ISSUE[0] / max(1, HOST_ISSUE[1]), 2)
+    def family_table(fam):
+        return {k: {"launches": v[0], "tflop": round(v[1] / 1e12, 3), "ms": round(1e3 * v[2], 2),
+                    "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None}
+                for k, v in sorted(fam.items())}
+
+    def event_pass():
+        """One extra, untimed step with the launch lanes off and HIP events around every launch."""
+        torch.cuda.synchronize()
+        tm = ops.GEMM_TIMER = ops.GemmTimer()
+        step()
+        torch.cuda.synchronize()
+        ops.GEMM_TIMER = None
+        return tm
+
+    def roofline_of(mode):
+        """`roofline` object of one GEMM mode (the precision is already set): dominant kernel family of a
+        serialised per-launch HIP-event pass, its PMC traffic, the MFMA class by family, the HBM class."""
+        timer = event_pass()
+        n, flops, secs = timer.summary()
+        if os.environ.get("F2G_GEMM_REPORT") and rank == 0 and mode == args.gemm:
+            print(timer.report(int(os.environ["F2G_GEMM_REPORT"])), file=sys.stderr)
+        achieved = flops / secs / 1e12
+        fam = timer.by_path()
+        hbm = timer.hbm_summary()
+        # dominant kernel = the family with the most time in this pass
+        dom = max(fam.items(), key=lambda kv: kv[1][2])
+        dn, (dl, dfl, dsec) = dom
+        # HBM bytes per launch of the dominant kernel come from PMC passes over this same command
+        # (profiles/: counters cannot be read from inside the process).  They are only reported when
+        # the profile was taken with THIS library version AND describes the family that is dominant in
+        # this pass; otherwise null (stale counters would describe different kernels / tiles).
+        traffic = None
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_x6_traffic.json" if mode == "bf16x6"
+                                             else "r*_pmc_gemm_traffic.json")))
+        pmc = pmcs[-1] if pmcs else ""            # the newest round's PMC pass (of this mode's dominant family)
+        if (args.workload == "gan_stage2" and mode in ("fp32", "bf16x6") and args.model == "mel_24k_base"
+                and B == 64 and nts == 1 and os.path.exists(pmc)
+                and dn == {"fp32": "lean", "bf16x6": "x6"}[mode]):
+            with open(pmc) as f:
+                pj = json.load(f)
+            if pj.get("lib_version") == _lib_version() and pj.get("family", dn) == dn:
+                traffic = round(pj["hbm_bytes_per_launch_fetch_x2"])
+        alg_bytes = timer.algorithmic_bytes(dn) / max(1, dl)
+        # the dense MFMA peak of the arithmetic a family ran in.  bf16x6 mode: the six-product families (the
+        # x6 GEMM kernels, the conv32x6 direct convs) run on the bf16 pipe with six MFMAs per product = 2500 / 6
+        # TFLOP/s of fp32-class products; what stays on the exact fp32 MFMA is priced against that pipe
+        def family_peak(name):
+            if mode == "bf16":
+                return PEAK_BF16_MFMA_TFLOPS
+            if mode == "bf16x6" and (name == "x6" or (name == "direct-conv" and ops.CONV32_X6)):
+                return PEAK_BF16_MFMA_TFLOPS / 6.0
+            if mode == "bf16x3":
+                return PEAK_BF16_MFMA_TFLOPS / 3.0
+            return PEAK_FP32_MFMA_TFLOPS
+        peak = family_peak(dn)
+        # (mixed pipes: the time the families would need at their peaks over the time they took)
+        class_frac = sum(v[1] / 1e12 / family_peak(k) for k, v in fam.items()) / secs
+        ft = family_table(fam)
+        for k in ft:
+            ft[k]["peak"] = round(family_peak(k), 1)
+        return {"bound": "mfma",
+                "kernel": {"fused-mlp": "fused_mlp_kernel (whole ConvNeXt block: dwconv7 + BiasNorm in the "
+                                        "prologue, pwconv1 -> PReLU -> pwconv2 on bf16 MFMA, z and the "
+                                        "hidden activation on chip)",
+                           "lean": "gemm_lean_kernel (fp32 MFMA, zero-VALU K loop)",
+                           "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
+                           "direct-conv": "conv32 direct kernels (the 32 -> 32 channel MRD band layers)",
+                           "lean-streamk": "gemm_lean_kernel (stream-K)",
+                           "x6": "gemm_x6t8 / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
+                                 "pieces per operand, six MFMAs per product)",
+                           "narrow": "narrow VALU kernels"}.get(dn, dn),
+                # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
+                "achieved": round(dfl / dsec / 1e12, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(dfl / dsec / 1e12 / peak, 4),
+                "peak_basis": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32-class product"
+                               if peak == PEAK_BF16_MFMA_TFLOPS / 6.0 else
+                               "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per split-bf16 product"
+                               if peak == PEAK_BF16_MFMA_TFLOPS / 3.0 else
+                               "dense bf16 MFMA peak" if peak == PEAK_BF16_MFMA_TFLOPS else
+                               "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                # traffic: HBM bytes per launch from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+                # recorded with THIS build of the library, else null); beside it what one launch must
+                # move at least: both operands read once, the result written once
+                "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
+                # (six-product families only) what a bare stream of these MFMAs sustains on real operand data:
+                # the spec peak assumes clocks the bf16 pipe does not hold under load (DESIGN.md section 3)
+                **({"sustained": {"peak": 267.0, "frac": round(dfl / dsec / 1e12 / 267.0, 4),
+                                  "source": "bare six-MFMA stream, tools/micro/mfma_peak.hip (power-limited clocks)"}}
+                   if peak == PEAK_BF16_MFMA_TFLOPS / 6.0 else {}),
+                "launches_per_step": dl,
+                "avg_launch_us": round(1e6 * dsec / dl, 1),
+                "share_of_mfma_class_time": round(dsec / secs, 3),
+                # every MFMA-class launch of the step (all GEMM families + direct convs); the
+                # extra step runs with the launch lanes off (one stream, each kernel alone on the
+                # chip), so these durations sum to more than a laned step
+                "mfma_class": {"achieved": round(achieved, 2), "frac": round(class_frac, 4),
+                               "launches_per_step": n, "ms_per_step_serialised": round(1e3 * secs, 2),
+                               "algorithmic_tflop_per_step": round(flops / 1e12, 3),
+                               "by_family": ft},
+                # HBM-bound kernel class, in-step: algorithmic bytes (DESIGN.md section 3) / HIP-event
+                # time per kernel, against the 8 TB/s spec peak
+                "hbm_class": {k: {"launches": v[0], "GB": round(v[1] / 1e9, 3), "ms": round(1e3 * v[2], 3),
+                                  "achieved_GBps": round(v[1] / v[2] / 1e9, 1),
+                                  "frac": round(v[1] / v[2] / 8.0e12, 3)}
+                              for k, v in sorted(hbm.items())}}
+
+    roofline = None
+    if not args.no_roofline:
+        roofline = roofline_of(args.gemm)
+        iso = os.path.join(ROOT, "profiles", "hbm_class_isolated.json")
+        if os.path.exists(iso):
+            # the same HBM-class kernels launched back to back on the step's shapes (tools/hbm_kernel_bench.py
+            # on the GPU box; recorded with the library version named inside)
+            with open(iso) as f:
+                ij = json.load(f)
+            if ij.get("lib_version") == _lib_version():
+                roofline["hbm_class_isolated"] = ij["kernels"]
+
+    half = max(2, args.steps // 2)
+    exact = None
     fast = None
-    if args.gemm == "fp32" and not args.no_fast_mode:
+    if not args.no_fast_mode and args.gemm == "bf16x6":
+        # the reference's own arithmetic (exact fp32 MFMA, v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered
+        # fmaf chain) measured in the same run, with its own per-launch roofline pass
+        ops.set_gemm_precision("fp32")
+        a0, e0 = timed(1, half)
+        exact = {"gemm": "exact fp32 MFMA for every GEMM and direct conv",
+                 "value": round(world * a0 / e0, 2), "unit": "audio-s/s",
+                 "ms_per_step": round(1e3 * e0 / half, 2), "dtype": "f32"}
+        if not args.no_roofline:
+            r0 = roofline_of("fp32")
+            exact["roofline"] = {k: r0[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                    "traffic", "algorithmic_bytes_per_launch",
+                                                    "launches_per_step", "avg_launch_us", "mfma_class")}
+        ops.set_gemm_precision(args.gemm)
+    if not args.no_fast_mode and args.gemm in ("fp32", "bf16x6"):
         # also report the split-bf16 GEMM mode (3 bf16 MFMAs per product, fp32 accumulate): same
         # <= 1e-4 RMS waveform parity (tests/test_hip_generator.py passes in both modes), not fp32-exact
         ops.set_gemm_precision("bf16x3")
-        a2, e2 = timed(1, max(2, args.steps // 2))
+        a2, e2 = timed(1, half)
         fast = {"gemm": "split-bf16 (pre-split hi/lo operand images, 3x v_mfma_f32_32x32x16_bf16 per "
-                        "product, fp32 accumulate; lean / K-major weight-gradient / direct-conv kernels)",
+                        "product, fp32 accumulate; lean / K-major weight-gradient / direct-conv kernels): "
+                        "a THROUGHPUT mode, not a parity mode",
                 "value": round(world * a2 / e2, 2), "unit": "audio-s/s",
-                "ms_per_step": round(1e3 * e2 / max(2, args.steps // 2), 2),
+                "ms_per_step": round(1e3 * e2 / half, 2),
                 "parity": "<=1e-4 RMS waveform and losses to 2e-4 vs reference (the golden parity tests "
                           "run in this mode too); per-product error ~2^-16 instead of 2^-24. GRADIENTS "
                           "are held to looser bounds than in exact fp32, because more discriminator "
@@ -255,166 +409,36 @@ def main():
                           "0.12 in relative L2 over all of them (fp32: 5e-3 of each tensor's max), "
                           "full-width B=2 gradients to 0.1 (fp32: 1e-2), tests/test_hip_gan.py"}
         if not args.no_roofline:
-            # the same per-launch HIP-event pass as the headline's roofline, in this mode
-            torch.cuda.synchronize()
-            tm = ops.GEMM_TIMER = ops.GemmTimer()
-            step()
-            torch.cuda.synchronize()
-            ops.GEMM_TIMER = None
+            tm = event_pass()
             n3, fl3, sec3 = tm.summary()
-            fam3 = tm.by_path()
             fast["mfma_class"] = {
                 "launches_per_step": n3, "ms_per_step_serialised": round(1e3 * sec3, 2),
                 "achieved_fp32_equivalent_TFLOPs": round(fl3 / sec3 / 1e12, 2),
                 # three bf16 MFMAs per product against the dense bf16 peak
                 "bf16_mfma_frac": round(3.0 * fl3 / sec3 / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                "by_family": {k: {"launches": v[0], "tflop": round(v[1] / 1e12, 3),
-                                  "ms": round(1e3 * v[2], 2),
-                                  "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None}
-                              for k, v in sorted(fam3.items())}}
-        if args.workload in ("gan_stage2", "stage1"):
-            # fp32-CLASS products on the bf16 matrix pipe for the GEMMs with long reductions (three bf16
-            # pieces per operand, six MFMAs per product; everything else on the exact fp32 MFMA)
+                "by_family": family_table(tm.by_path())}
+        if args.gemm == "fp32" and args.workload in ("gan_stage2", "stage1"):
+            # fp32-CLASS products on the bf16 matrix pipe (the default headline mode), beside an explicit
+            # --gemm fp32 headline
             ops.set_gemm_precision("bf16x6")
-            a6, e6 = timed(1, max(2, args.steps // 2))
-            fam6 = None
+            a6, e6 = timed(1, half)
+            fast["fp32_class"] = {"gemm": DTYPES["bf16x6"], "value": round(world * a6 / e6, 2),
+                                  "unit": "audio-s/s", "ms_per_step": round(1e3 * e6 / half, 2)}
             if not args.no_roofline:
-                torch.cuda.synchronize()
-                tm6 = ops.GEMM_TIMER = ops.GemmTimer()
-                step()
-                torch.cuda.synchronize()
-                ops.GEMM_TIMER = None
-                n6, fl6, sec6 = tm6.summary()
-                fam6 = {"launches_per_step": n6, "ms_per_step_serialised": round(1e3 * sec6, 2),
-                        "achieved_fp32_equivalent_TFLOPs": round(fl6 / sec6 / 1e12, 2),
-                        # six bf16 MFMAs per product against the dense bf16 peak (the exact-fp32 families of
-                        # this mode -- short-K generator GEMMs, thin layers -- counted at six as well)
-                        "bf16_mfma_frac": round(6.0 * fl6 / sec6 / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                        "by_family": {k: {"launches": v[0], "tflop": round(v[1] / 1e12, 3),
-                                          "ms": round(1e3 * v[2], 2),
-                                          "tflops": round(v[1] / v[2] / 1e12, 1) if v[2] > 0 else None}
-                                      for k, v in sorted(tm6.by_path().items())}}
-            fast["fp32_class"] = {
-                "gemm": "bf16x6: three bf16 pieces per fp32 operand, six v_mfma_f32_32x32x16_bf16 per product "
-                        "(error <= 2^-23 per product: 8e-8 of sum|a w| measured where the fp32 fmaf chain has "
-                        "7e-8..2e-7) for the form-0 GEMMs with K >= 2048 (the 512- / 1024-channel MPD layers' "
-                        "forward and data-gradient GEMMs over their halo maps, the 768-channel pwconv2; operand "
-                        "images written by the producing GEMM's epilogue), for 640 <= K < 2048 on chip-filling "
-                        "grids (operands split inside the kernel) and for the weight gradients with >= 2048 "
-                        "rows (gemm_leanw6_kernel, operands split inside the kernel), and for the direct MRD band "
-                        "convolutions (conv32x6.hip: patch and gradient tiles split into three pieces while they "
-                        "are staged, forward / data gradient / weight gradient); the short-K generator GEMMs and "
-                        "the thin first / last layers exact fp32",
-                "value": round(world * a6 / e6, 2), "unit": "audio-s/s",
-                "ms_per_step": round(1e3 * e6 / max(2, args.steps // 2), 2),
-                "mfma_class": fam6,
-                "parity": "the golden parity modules run in this mode in the default `pytest -m gpu` run "
-                          "(tests/conftest.py: fp32, bf16x6, bf16x3) at the exact-fp32 tolerances"}
+                r6 = roofline_of("bf16x6")
+                fast["fp32_class"]["mfma_class"] = r6["mfma_class"]
         if args.workload == "infer4":
             # BASELINE config 2 names bf16 for the generator-only forward: plain bf16 operands,
             # fp32 accumulation and fp32 activations -- a throughput mode, not a parity mode
             ops.set_gemm_precision("bf16")
-            a3, e3 = timed(1, max(2, args.steps // 2))
+            a3, e3 = timed(1, half)
             fast["bf16"] = {"gemm": "plain bf16 (1x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate): "
                                     "z and the hidden activation of every block live in HBM as bf16, "
                                     "written by dwnorm / the pwconv1 epilogue; other operands converted",
                             "value": round(world * a3 / e3, 2), "unit": "audio-s/s",
-                            "ms_per_step": round(1e3 * e3 / max(2, args.steps // 2), 2),
+                            "ms_per_step": round(1e3 * e3 / half, 2),
                             "parity": "~1e-3 RMS waveform vs the fp32 path (tests/test_hip_generator.py)"}
-        ops.set_gemm_precision("fp32")
-
-    roofline = None
-    if not args.no_roofline:
-        torch.cuda.synchronize()
-        timer = ops.GEMM_TIMER = ops.GemmTimer()
-        step()
-        torch.cuda.synchronize()
-        n, flops, secs = timer.summary()
-        if os.environ.get("F2G_GEMM_REPORT") and rank == 0:
-            print(timer.report(int(os.environ["F2G_GEMM_REPORT"])), file=sys.stderr)
-        ops.GEMM_TIMER = None
-        achieved = flops / secs / 1e12
-        fam = timer.by_path()
-        hbm = timer.hbm_summary()
-        # HBM bytes per launch of the dominant kernel come from PMC passes over this same command
-        # (profiles/: counters cannot be read from inside the process).  They are only reported when
-        # the profile was taken with THIS library version; otherwise null (stale counters would
-        # describe different kernels / tiles).
-        traffic = None
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                             "r*_pmc_x6_traffic.json" if args.gemm == "bf16x6"
-                                             else "r*_pmc_gemm_traffic.json")))
-        pmc = pmcs[-1] if pmcs else ""            # the newest round's PMC pass (of this mode's dominant family)
-        if (args.workload == "gan_stage2" and args.gemm in ("fp32", "bf16x6") and args.model == "mel_24k_base"
-                and B == 64 and nts == 1 and os.path.exists(pmc)):
-            with open(pmc) as f:
-                pj = json.load(f)
-            if pj.get("lib_version") == _lib_version():
-                traffic = round(pj["hbm_bytes_per_launch_fetch_x2"])
-        # dominant kernel = the family with the most time in this pass
-        dom = max(fam.items(), key=lambda kv: kv[1][2])
-        dn, (dl, dfl, dsec) = dom
-        alg_bytes = timer.algorithmic_bytes(dn) / max(1, dl)
-        # the dense MFMA peak of the arithmetic a family ran in.  bf16x6 mode: the six-product families (the
-        # x6 GEMM kernels, the conv32x6 direct convs) run on the bf16 pipe with six MFMAs per product = 2500 / 6
-        # TFLOP/s of fp32-class products; what stays on the exact fp32 MFMA is priced against that pipe
-        def family_peak(name):
-            if args.gemm == "bf16":
-                return PEAK_BF16_MFMA_TFLOPS
-            if args.gemm == "bf16x6" and (name == "x6" or (name == "direct-conv" and ops.CONV32_X6)):
-                return PEAK_BF16_MFMA_TFLOPS / 6.0
-            return PEAK_FP32_MFMA_TFLOPS
-        peak = family_peak(dn)
-        # (mixed pipes: the time the families would need at their peaks over the time they took)
-        class_frac = sum(v[1] / 1e12 / family_peak(k) for k, v in fam.items()) / secs
-        roofline = {"bound": "mfma",
-                    "kernel": {"fused-mlp": "fused_mlp_kernel (whole ConvNeXt block: dwconv7 + BiasNorm in the "
-                                            "prologue, pwconv1 -> PReLU -> pwconv2 on bf16 MFMA, z and the "
-                                            "hidden activation on chip)",
-                               "lean": "gemm_lean_kernel (fp32 MFMA, zero-VALU K loop)",
-                               "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
-                               "direct-conv": "conv32 direct kernels (the 32 -> 32 channel MRD band layers)",
-                               "lean-streamk": "gemm_lean_kernel (stream-K)",
-                               "x6": "gemm_x6t8 / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
-                                     "pieces per operand, six MFMAs per product)",
-                               "narrow": "narrow VALU kernels"}.get(dn, dn),
-                    # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
-                    "achieved": round(dfl / dsec / 1e12, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s", "frac": round(dfl / dsec / 1e12 / peak, 4),
-                    "peak_basis": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32-class product"
-                                   if peak == PEAK_BF16_MFMA_TFLOPS / 6.0 else
-                                   "dense bf16 MFMA peak" if peak == PEAK_BF16_MFMA_TFLOPS else
-                                   "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
-                    # traffic: HBM bytes per launch from the PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
-                    # recorded with THIS build of the library, else null); beside it what one launch must
-                    # move at least: both operands read once, the result written once
-                    "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
-                    # (six-product families only) what a bare stream of these MFMAs sustains on real operand data:
-                    # the spec peak assumes clocks the bf16 pipe does not hold under load
-                    **({"sustained": {"peak": 267.0, "frac": round(dfl / dsec / 1e12 / 267.0, 4),
-                                      "source": "bare six-MFMA stream, tools/micro/mfma_peak.hip (power-limited clocks)"}}
-                       if peak == PEAK_BF16_MFMA_TFLOPS / 6.0 else {}),
-                    "launches_per_step": dl,
-                    "avg_launch_us": round(1e6 * dsec / dl, 1),
-                    "share_of_mfma_class_time": round(dsec / secs, 3),
-                    # every MFMA-class launch of the step (all GEMM families + direct convs); the
-                    # extra step runs with the launch lanes off (one stream, each kernel alone on the
-                    # chip), so these durations sum to more than a laned step
-                    "mfma_class": {"achieved": round(achieved, 2), "frac": round(class_frac, 4),
-                                   "launches_per_step": n, "ms_per_step_serialised": round(1e3 * secs, 2),
-                                   "algorithmic_tflop_per_step": round(flops / 1e12, 3),
-                                   "by_family": {k: {"launches": v[0], "tflop": round(v[1] / 1e12, 3),
-                                                     "ms": round(1e3 * v[2], 2),
-                                                     "tflops": round(v[1] / v[2] / 1e12, 1),
-                                                     "peak": round(family_peak(k), 1)}
-                                                 for k, v in sorted(fam.items())}},
-                    # HBM-bound kernel class, in-step: algorithmic bytes / HIP-event
-                    # time per kernel, against the 8 TB/s spec peak
-                    "hbm_class": {k: {"launches": v[0], "GB": round(v[1] / 1e9, 3), "ms": round(1e3 * v[2], 3),
-                                      "achieved_GBps": round(v[1] / v[2] / 1e9, 1),
-                                      "frac": round(v[1] / v[2] / 8.0e12, 3)}
-                                  for k, v in sorted(hbm.items())}}
+        ops.set_gemm_precision(args.gemm)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N = 1 only: ranks must not wait on it
@@ -450,11 +474,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "host_issue_ms_per_step": host_issue_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "f32 (split-bf16 GEMM, fp32 accumulate)",
-                      "bf16x6": "f32 (fp32-class products on the bf16 matrix pipe for the long reductions and the "
-                                "direct MRD convs: three bf16 pieces per operand, six MFMAs per product, fp32 "
-                                "accumulate; short reductions on the exact fp32 MFMA)",
-                      "bf16": "bf16 GEMM operands, fp32 accumulate / activations"}[args.gemm],
+            "dtype": DTYPES[args.gemm],
             "data": "synthetic (0.1*randn clipped, seeded per rank); seeded random-init weights",
             "config": {"workload": args.model + " " + {
                            "gan_stage2": "GAN stage-2 train step: D-step + G-step, "
@@ -468,7 +488,7 @@ def main():
                        "n_timesteps": 4 if args.workload == "infer4" else nts,
                        "gan": "gan_multi_scale_mel_recon", "parallelism": f"dp{world}",
                        "optimizer": "ScaledAdam + Eden2 (fused HIP)" if args.optimizer else "none"},
-            "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast,
+            "roofline": roofline, "exact_fp32": exact, "cpu_baseline": cpu, "fast_mode": fast,
         }
         if comm is not None:
             line.update(comm)
