@@ -11,6 +11,9 @@ int f2g_check_launch();
 // narrow.hip: VALU path for <= 4 output columns / gradient rows; 1 = handled, 0 = not applicable
 int f2g_gemm_narrow(const f2g_gemm_desc& d, hipStream_t st);
 void f2g_set_error(const char* msg);
+// gemm_x6p.hip: ping-pong tap-walking fp32-class GEMM (precision 3 over halo-map images); ok = 1 if taken
+int f2g_x6p_ok(const f2g_gemm_desc& d, int taps);
+int f2g_launch_x6p(const f2g_gemm_desc& d, int taps, long long a_extent, hipStream_t st);
 // elementwise.hip: out[k][c - begin[k]] += sum_r a[r, c] for up to 3 column ranges (null = skip)
 struct f2g_colsegs {
   float* out[3];

@@ -2080,6 +2080,21 @@ void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
 // (gemm_x6_kernel raises its waves' priority for the MFMA phase: +2 ... 14 % in the step; the kernels that
 // split operands on the VALU lose with it -- the other block's split is what feeds their next slab)
 #define X6_MFMA_PRIO 1
+// lab builds (tools/micro/x6lab.sh; timing only): F2G_X6LAB bit 1 = the six-product kernels skip their
+// epilogue, bit 2 = they skip the read-back that writes the result's three-piece image
+#ifndef F2G_X6LAB
+#define F2G_X6LAB 0
+#endif
+#if F2G_X6LAB & 1
+#define X6LAB_EPI if (acc[0][0][0] == 1.2345e30f)
+#else
+#define X6LAB_EPI
+#endif
+#if F2G_X6LAB & 2
+#define X6LAB_X3 acc[0][0][1] == 1.2345e30f &&
+#else
+#define X6LAB_X3
+#endif
 __device__ __forceinline__ void split3x4(const u32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
   // (by value first: __builtin_bit_cast applied to a vector-element expression reads element 0)
   const unsigned u0 = v.x, u1 = v.y, u2 = v.z, u3 = v.w;
@@ -2712,8 +2727,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
         }
     __builtin_amdgcn_s_setprio(0);
   }
-  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
-  if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
+  X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
 // Stride-1 conv windows (the 1024-channel MPD layer and its data gradient: K = 5 taps x 1024 channels):
@@ -2834,8 +2849,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d,
       __builtin_amdgcn_s_setprio(0);
     }
   }
-  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
-  if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
+  X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
 // ---- the tap-walking instance on a 256 x 128 tile (round 4) -------------------------------------------
@@ -2972,8 +2987,8 @@ __global__ __launch_bounds__(512, 1) void gemm_x6t8_kernel(const f2g_gemm_desc d
       __syncthreads();
     }
   }
-  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
-  if (d.E.x3_out) x3_tile_readback<256, 512>(d.E, M, N, m0, n0, tid);
+  X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (X6LAB_X3 d.E.x3_out) x3_tile_readback<256, 512>(d.E, M, N, m0, n0, tid);
 }
 
 // The same tile and schedule over the fp32 operands themselves (f2g_operand.split = 0): every thread
@@ -3064,8 +3079,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
         }
   }
-  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
-  if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
+  X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
 // 1 if a form-0 descriptor over fp32 tensors could run as precision 3 once both operands are handed
@@ -3168,6 +3183,12 @@ static int launch_x6t8(const f2g_gemm_desc& d, int taps, hipStream_t st) {
 }
 
 static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
+  // round 5: ping-pong wave groups + wide epilogue (gemm_x6p.hip) where its epilogue subset applies
+  for (int taps = 5; taps >= 2; taps -= 3)
+    if (x6_tap_ok(d, taps) && f2g_x6p_ok(d, taps)) {
+      g_last_path = 4;
+      return f2g_launch_x6p(d, taps, x6_a_extent(d.A), st);
+    }
   if (x6_tap8_ok(d, 5)) return launch_x6t8(d, 5, st);
   if (x6_tap8_ok(d, 2)) return launch_x6t8(d, 2, st);
   if (x6_tap_ok(d, 5)) return launch_x6t(d, 5, st);

@@ -1,0 +1,362 @@
+// fp32-class GEMM over stride-1 conv windows of a halo-map image (the 1024-channel MPD layer, its data
+// gradient and the residue data gradients of the stride-3 layers; reference discriminators.py:65-76) --
+// round 5 successor of gemm_x6t8_kernel (gemm.hip): the same 256 x 128 tile, operand images and K order
+// (channel slab outer, tap inner; six v_mfma_f32_32x32x16_bf16 with i + j <= 2 per product, smallest terms
+// first), but
+//
+//  * PING-PONG wave groups.  PMC on gemm_x6t8_kernel (profiles/r05_pmc_busy_x6.txt): matrix pipe busy 56 % of
+//    the kernel's life at K = 5120, 29 % at K = 2048 -- its eight waves run in lockstep (all read their 24
+//    fragments, barrier, all issue their 48 MFMAs, barrier), so the pipe idles through every read phase.  Here
+//    the block's waves form two groups of four (one wave per SIMD each): group 0 owns rows 0..127 of the tile,
+//    group 1 rows 128..255, and group 1 runs HALF A STEP BEHIND: while one group's MFMAs hold the matrix pipe,
+//    the other reads its fragments, stores its share of the next weight slab and requests the one after.  A
+//    group stages the map positions of its OWN 128 rows (so nobody else reads them: they are replaced at the
+//    start of the group's MFMA phase of a channel slab's last tap), the weight slabs stay double-buffered and
+//    shared: the slab of step s + 1 is stored by group 0 in slot 2s and by group 1 in slot 2s + 1, after the
+//    last reader of step s - 1 (group 1, slot 2s - 1) and before the first of step s + 1 (group 0, slot 2s + 2).
+//    Barriers wait for the LDS only (s_waitcnt lgkmcnt(0); s_barrier): global loads fly across them.
+//  * a WIDE epilogue without read-back.  The generic epilogue stores 4 bytes per lane and instruction behind
+//    one integer division per element, and the result's three-piece image was made by reading the tile back
+//    from L2 after a block barrier.  Here a wave turns its 64 x 64 accumulator tile through a private LDS
+//    patch (32 rows at a time) into 8-column row segments: bias / leaky ReLU / the leaky-ReLU backward mask of
+//    the layer below (+ feature-matching term) with 16-byte loads, 16-byte stores of the fp32 map AND of its
+//    image pieces from the same registers, column sums (the bias gradient) reduced over the wave's rows
+//    before the atomics; one division per ROW.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PITCH = 208;                 // bytes of a staged position / weight row: 3 x 64 + 16 (52 dwords)
+constexpr int LH = 160;                    // staged positions of a group's 128 rows (host check)
+constexpr int OPERA = 2 * LH * PITCH;      // both groups' positions
+constexpr int OPERB = 128 * PITCH;         // one weight slab
+constexpr int EPITCH = 72;                 // floats per row of a wave's epilogue patch (32 x 64 + pad)
+constexpr int ESZ = 32 * EPITCH * 4 + 64 * 8;   // bytes per wave: patch + 64 row offsets
+
+struct x6p_tap {
+  int P0, HpIn, offpos, C32;
+  unsigned bytes;
+};
+
+__device__ __forceinline__ void lds_barrier() {
+  // LDS traffic of this wave done, then the block barrier; outstanding global loads keep flying
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ void tile_of_block(int BM, int BN, int& m0, int& n0) {
+  const int tiles_n = gridDim.y, tiles_m = gridDim.x;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.y * tiles_m + blockIdx.x;
+  const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  m0 = tm * BM;
+  n0 = tn * BN;
+}
+
+// three bf16 pieces of eight floats, packed as 16 bytes per piece (round to nearest even at every step, as
+// f2g_split_bf16x3 / x3_tile_readback)
+__device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
+  unsigned pk[3][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 a = (__bf16)x[e];
+    const float r1 = x[e] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    const unsigned sa = __builtin_bit_cast(unsigned short, a), sb = __builtin_bit_cast(unsigned short, b),
+                   sc = __builtin_bit_cast(unsigned short, c);
+    if (e & 1) pk[0][e >> 1] |= sa << 16, pk[1][e >> 1] |= sb << 16, pk[2][e >> 1] |= sc << 16;
+    else pk[0][e >> 1] = sa, pk[1][e >> 1] = sb, pk[2][e >> 1] = sc;
+  }
+  p0 = u32x4{pk[0][0], pk[0][1], pk[0][2], pk[0][3]};
+  p1 = u32x4{pk[1][0], pk[1][1], pk[1][2], pk[1][3]};
+  p2 = u32x4{pk[2][0], pk[2][1], pk[2][2], pk[2][3]};
+}
+
+// The wave's 64 x 64 accumulator tile (rows r0.., columns c0..) -> memory.  ep = this wave's LDS patch.
+__device__ __forceinline__ void wide_epilogue(const f2g_epilogue& E, f32x16 (&acc)[2][2], int M, int N, int r0,
+                                              int c0, int lane, unsigned char* ep) {
+  float* patch = reinterpret_cast<float*>(ep);
+  long long* rowoff = reinterpret_cast<long long*>(ep + 32 * EPITCH * 4);
+  const int li = lane & 31, h = lane >> 5;
+  {
+    // element offset of row r0 + lane in the output (row map: one division per row), -1 = past the end
+    const int row = r0 + lane;
+    long long off = -1;
+    if (row < M) {
+      if (E.P0o > 0) {
+        const int sq = row / E.P0o;
+        off = (long long)sq * E.seq_stride_o + (long long)(row - sq * E.P0o) * E.row_stride_o + E.off_o;
+      } else {
+        off = (long long)row * E.ldc;
+      }
+    }
+    rowoff[lane] = off;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int c8 = lane & 7, col = c0 + c8 * 8;
+  const bool cok = col < N;
+  float bias[8], cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = (E.bias && cok) ? E.bias[col + e] : 0.f, cs[e] = 0.f;
+  const float fmw = E.fm_ref ? E.fm_w * (E.fm_wdev ? E.fm_wdev[0] : 1.f) : 0.f;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    // (the patch's previous readers: this wave itself, in program order -- the LDS executes a wave's
+    // instructions in order, so no barrier is needed for a wave-private patch)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        patch[((e & 3) + 8 * (e >> 2) + 4 * h) * EPITCH + ni * 32 + li] = acc[mi][ni][e];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (lane >> 3) + 8 * j;                 // row of the patch
+      const long long ro = rowoff[mi * 32 + r];
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(patch + r * EPITCH + c8 * 8);
+      const f32x4 u1 = *reinterpret_cast<const f32x4*>(patch + r * EPITCH + c8 * 8 + 4);
+      if (ro < 0 || !cok) continue;
+      const long long off = ro + col;
+      float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] += bias[e];
+        if (E.lrelu_slope != 0.f) v[e] = v[e] > 0.f ? v[e] : E.lrelu_slope * v[e];
+      }
+      if (E.mask_src) {   // leaky-ReLU backward of the layer below (+ feature-matching term)
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(E.mask_src + off);
+        const f32x4 y1 = *reinterpret_cast<const f32x4*>(E.mask_src + off + 4);
+        const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        if (E.fm_ref) {
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(E.fm_ref + off);
+          const f32x4 f1 = *reinterpret_cast<const f32x4*>(E.fm_ref + off + 4);
+          const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dl = y[e] - f[e];
+            v[e] += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= y[e] > 0.f ? 1.f : E.mask_slope;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] += v[e];
+      *reinterpret_cast<f32x4*>(E.C + off) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(E.C + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      if (E.x3_out) {
+        u32x4 p0, p1, p2;
+        split3x8(v, p0, p1, p2);
+        __bf16* q = reinterpret_cast<__bf16*>(E.x3_out) + (off >> 5) * 96 + (off & 31);
+        *reinterpret_cast<u32x4*>(q) = p0;
+        *reinterpret_cast<u32x4*>(q + 32) = p1;
+        *reinterpret_cast<u32x4*>(q + 64) = p2;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (E.colsum) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = cs[e];
+      s += __shfl_xor(s, 8);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 8 && cok) atomicAdd(E.colsum + col + e, s);
+    }
+  }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                          const x6p_tap R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int NJA = (LH * 12 + 255) / 256, NJB = 128 * 12 / 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, gt = tid & 255;
+  const int wm = (wave >> 1) & 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(256, 128, m0, n0);
+  const int mg = m0 + 128 * grp;                  // first row of this group's half of the tile
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  auto posrow = [&](int r) {
+    const int sq = r / R.P0;
+    return sq * R.HpIn + (r - sq * R.P0) + R.offpos;
+  };
+  const int pbase = posrow(mg);
+  const int rlast = mg + 127 < M ? mg + 127 : M - 1;
+  const int L = mg < M ? posrow(rlast) - pbase + TAPS : 0;     // staged positions (<= LH: host check)
+  const unsigned rowbytesA = (unsigned)R.C32 * 192u;           // one position of the map image
+  const unsigned rowbytesW = (unsigned)(K / 32) * 192u;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytesW, 0x00020000);
+  unsigned char* myA = smem6 + grp * (LH * PITCH);
+  unsigned voA[NJA], voW[NJB];
+  int loA[NJA], loW[NJB];
+#pragma unroll
+  for (int j = 0; j < NJA; ++j) {
+    const int id = gt + 256 * j, q = id / 12, c = id - q * 12;
+    voA[j] = q < L ? (unsigned)(pbase + q) * rowbytesA + c * 16 : 0xf0000000u;   // (outside the resource: zeros)
+    loA[j] = q < LH ? q * PITCH + c * 16 : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < NJB; ++j) {
+    const int id = tid + 512 * j, row = id / 12, c = id - row * 12;
+    voW[j] = (unsigned)(n0 + row) * rowbytesW + c * 16;
+    loW[j] = OPERA + row * PITCH + c * 16;
+  }
+  u32x4 xa[NJA], xw[NJB];
+  auto gloadA = [&](int cs) {
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], cs * 192, 0);
+  };
+  auto gloadB = [&](int slab) {
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], slab * 192, 0);
+  };
+  auto storeA = [&]() {
+#pragma unroll
+    for (int j = 0; j < NJA; ++j)
+      if (loA[j] >= 0) *reinterpret_cast<u32x4*>(myA + loA[j]) = xa[j];
+  };
+  auto storeB = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) *reinterpret_cast<u32x4*>(smem6 + buf * OPERB + loW[j]) = xw[j];
+  };
+  // fragment rows of this lane: output rows mg + wm * 64 + i * 32 + li -> staged position of the group
+  const unsigned char* rA[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = mg + wm * 64 + i * 32 + li;
+    rA[i] = myA + (r < M ? posrow(r) - pbase : 0) * PITCH + h * 16;
+  }
+  const unsigned char* rB = smem6 + OPERA + (wn * 64 + li) * PITCH + h * 16;
+  // weight slab of step s = (cs, t): K order = channel slab outer, tap inner -> image slab t * C32 + cs
+  const int nsteps = R.C32 * TAPS;
+  auto slab_of = [&](int s) {
+    if (s >= nsteps) s = 0;                      // (past the end: re-read, never used)
+    const int c2 = s / TAPS, t2 = s - c2 * TAPS;
+    return t2 * R.C32 + c2;
+  };
+  gloadA(0);
+  gloadB(slab_of(0));
+  storeA();
+  storeB(0);
+  gloadA(1 < R.C32 ? 1 : 0);
+  gloadB(slab_of(1));
+  lds_barrier();
+  if (grp == 1) lds_barrier();                   // group 1 runs one slot behind
+  int step = 0;
+  for (int cs = 0; cs < R.C32; ++cs) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t, ++step) {
+      const int buf = step & 1;
+      // ---- read slot: this step's fragments; my share of the next weight slab; request the one after
+      bf16x8 fa[2][3][2], fb[2][3][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA[i] + t * PITCH + p * 64 + ks * 32);
+            fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + buf * OPERB + p * 64 + i * 32 * PITCH + ks * 32);
+          }
+      storeB(buf ^ 1);
+      gloadB(slab_of(step + 2));
+      lds_barrier();
+      // ---- MFMA slot (the other group reads meanwhile)
+      if (t == TAPS - 1 && cs + 1 < R.C32) {
+        // last tap of this channel slab: the group's staged positions are replaced (their only readers are
+        // this group's waves, whose reads were complete before the barrier above)
+        storeA();
+        gloadA(cs + 2 < R.C32 ? cs + 2 : 0);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int j = sdeg - i;
+            if (j < 0 || j > 2) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      // (group 1's last MFMA slot needs no barrier behind it: group 0 is in its epilogue by then, and that
+      // slot touches no LDS -- both groups pass 1 + 2 * nsteps barriers)
+      if (!(grp == 1 && step == nsteps - 1)) lds_barrier();
+    }
+  }
+  // every fragment read of the main loop is complete (the last ones were group 1's, before the barrier group 0
+  // has just passed): the waves turn their tiles through private patches at the bottom of the LDS
+  wide_epilogue(d.E, acc, M, N, mg + wm * 64, n0 + wn * 64, lane, smem6 + wave * ESZ);
+}
+
+}  // namespace
+
+// epilogue features the wide epilogue implements: bias, leaky ReLU, row map, leaky-ReLU backward mask (+ the
+// feature-matching term), column sums, the result's three-piece image
+static bool x6p_epilogue_ok(const f2g_epilogue& E, int N) {
+  if (E.res || E.aux || E.prelu_slope || E.prelu_out || E.atomic || E.accumulate || E.c_bf16 || E.colsum_alpha ||
+      E.scale != 0.f || (N & 7))
+    return false;
+  if ((((uintptr_t)E.C) & 15) || (E.mask_src && (((uintptr_t)E.mask_src) & 15)) ||
+      (E.fm_ref && ((((uintptr_t)E.fm_ref) & 15) || !E.mask_src)) || (E.x3_out && (((uintptr_t)E.x3_out) & 15)))
+    return false;
+  if (E.P0o > 0) return !((E.seq_stride_o | E.row_stride_o | E.off_o) & 7);
+  return !(E.ldc & 7);
+}
+
+// d: a precision-3 descriptor that passed gemm.hip's x6_tap_ok(d, taps) (stride-1 windows of `taps` positions
+// over a halo-map image, <= 160 staged positions per 128 rows).  0 = not taken.
+int f2g_x6p_ok(const f2g_gemm_desc& d, int taps) {
+  const char* ev = getenv("F2G_X6P");       // 0 off, 1 (default) chip-filling grids, 2 whatever the grid
+  const int mode = ev ? atoi(ev) : 1;       // (read per call so that a test can switch it, as F2G_X6_TAP8)
+  if (mode == 0 || (taps != 5 && taps != 2)) return 0;
+  if (d.A.unit / 32 < 2) return 0;
+  if (!x6p_epilogue_ok(d.E, d.B.rows)) return 0;
+  const long long tiles = (long long)((d.A.rows + 255) / 256) * ((d.B.rows + 127) / 128);
+  return (mode >= 2 || tiles >= 256) ? 1 : 0;
+}
+
+int f2g_launch_x6p(const f2g_gemm_desc& d, int taps, long long a_extent, hipStream_t st) {
+  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
+  constexpr size_t smem = (size_t)OPERA + 2 * OPERB;
+  static_assert(8 * ESZ <= (int)smem, "epilogue patches fit under the main loop's buffers");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6p_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  x6p_tap R;
+  R.P0 = d.A.P0, R.HpIn = (int)(d.A.seq_stride / d.A.unit), R.offpos = -d.A.pad0, R.C32 = d.A.unit / 32;
+  R.bytes = (unsigned)(a_extent * 6);
+  dim3 grid((M + 255) / 256, (N + 127) / 128);
+  if (taps == 5) hipLaunchKernelGGL(gemm_x6p_kernel<5>, grid, dim3(512), smem, st, d, M, N, K, R);
+  else hipLaunchKernelGGL(gemm_x6p_kernel<2>, grid, dim3(512), smem, st, d, M, N, K, R);
+  return f2g_check_launch();
+}

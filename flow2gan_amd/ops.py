@@ -844,17 +844,18 @@ class GemmTimer:
         self.shapes.append(shape)
 
     def report(self, top: int = 25) -> str:
-        """Per-shape table (form, M, N, K): calls, total ms, TFLOP/s -- after a synchronise."""
+        """Per-shape table (form, M, N, K, kernel family): calls, total ms, TFLOP/s -- after a synchronise."""
         agg = {}
-        for (s, e, f), shp in zip(self.records, self.shapes):
-            a = agg.setdefault(shp, [0, 0.0, 0.0])
+        for (s, e, f), shp, pth in zip(self.records, self.shapes, self.paths):
+            a = agg.setdefault(tuple(shp) + (pth,), [0, 0.0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e)
             a[2] += f
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
-        out = ["form      M      N      K  calls  total_ms  TFLOP/s"]
-        for (form, m, n, k), (c, ms, f) in rows:
-            out.append(f"{form:4d} {m:6d} {n:6d} {k:6d} {c:6d} {ms:9.3f} {f / (ms * 1e-3) / 1e12:8.1f}")
+        out = ["form      M      N      K  calls  total_ms  TFLOP/s  family"]
+        for key, (c, ms, f) in rows:
+            form, m, n, k = key[:4]
+            out.append(f"{form:4d} {m:6d} {n:6d} {k:6d} {c:6d} {ms:9.3f} {f / (ms * 1e-3) / 1e12:8.1f}  {key[-1]}")
         return "\n".join(out)
 
     def summary(self):

@@ -1263,7 +1263,7 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, monkeypatch):
         ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS = was
 
 
-@pytest.mark.parametrize("tap8", [0, 2], ids=["tile128", "tile256"])
+@pytest.mark.parametrize("tap8", [0, 2, 3], ids=["tile128", "tile256", "pingpong"])
 @pytest.mark.parametrize("B2,T,p", [(4, 24000, 3), (2, 11025, 11), (6, 6000, 2)])
 def test_fp32_class_gemm_over_halo_windows_and_producer_images(ops, B2, T, p, tap8, monkeypatch):
     """precision 3 over the MPD stack's operands: conv windows into the halo maps (rows a stride apart, K
@@ -1272,9 +1272,12 @@ def test_fp32_class_gemm_over_halo_windows_and_producer_images(ops, B2, T, p, ta
     gradients, stride residues interleaving rows).  Every produced image must equal f2g_split_bf16x3 of the
     stored map bit for bit (zero halo rows included), and maps / gradients must agree with the exact-fp32
     path to fp32 rounding.  tile256: the tap-walking windows on gemm_x6t8_kernel (one block of 8 waves per
-    CU, 256 output rows, double-buffered weight slabs) wherever its geometry allows, whatever the grid size."""
+    CU, 256 output rows, double-buffered weight slabs) wherever its geometry allows, whatever the grid size;
+    pingpong: gemm_x6p_kernel (round 5: two wave groups half a step apart, wide epilogue that writes map and
+    image from the same registers) wherever ITS geometry allows -- the other two ids switch it off."""
     from flow2gan_amd import fused_disc as fd
-    monkeypatch.setenv("F2G_X6_TAP8", str(tap8))
+    monkeypatch.setenv("F2G_X6_TAP8", str(min(tap8, 2)))
+    monkeypatch.setenv("F2G_X6P", "2" if tap8 == 3 else "0")
     gen = torch.Generator().manual_seed(T + p)
     x2 = g(0.1 * torch.randn(B2, T, generator=gen))
     ch = fd.MPD_CH
