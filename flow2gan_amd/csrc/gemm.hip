@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "common.h"
+#include "x6_epilogue.h"
 
 namespace {
 
@@ -2648,7 +2649,7 @@ struct x6_rows {
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                         const x6_rows R) {
+                                                         const x6_rows R, const int wide) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
   constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2727,6 +2728,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
         }
     __builtin_amdgcn_s_setprio(0);
   }
+  if (wide) {
+    // (every fragment read of the main loop lies before its last barrier: a wave that is through its MFMAs
+    // may overlay the operand buffers with its private patch)
+    X6LAB_EPI x6e::wide_epilogue(d.E, acc, M, N, m0 + wm * 64, n0 + wn * 64, lane, smem6 + wave * x6e::ESZ);
+    return;
+  }
   X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
   if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
@@ -2744,7 +2751,7 @@ struct x6_tap {
 
 template <int TAPS>
 __global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                          const x6_tap R) {
+                                                          const x6_tap R, const int wide) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
   constexpr int PITCH = 208, LMAX = 160, OPER = LMAX * PITCH, NJA = 8, NJB = 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2848,6 +2855,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d,
           }
       __builtin_amdgcn_s_setprio(0);
     }
+  }
+  if (wide) {
+    // (every fragment read of the main loop lies before its last barrier: a wave that is through its MFMAs
+    // may overlay the operand buffers with its private patch)
+    X6LAB_EPI x6e::wide_epilogue(d.E, acc, M, N, m0 + wm * 64, n0 + wn * 64, lane, smem6 + wave * x6e::ESZ);
+    return;
   }
   X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
   if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
@@ -2996,7 +3009,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x6t8_kernel(const f2g_gemm_desc d
 // does -- 4 bytes per element from L2 instead of 6, no image pass, no producer, 5.5 VALU instructions per
 // element beside the 48 MFMAs per slab and wave.
 __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                          const x6_rows R) {
+                                                          const x6_rows R, const int wide) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
   constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3079,6 +3092,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
         }
   }
+  if (wide) {
+    // (every fragment read of the main loop lies before its last barrier: a wave that is through its MFMAs
+    // may overlay the operand buffers with its private patch)
+    X6LAB_EPI x6e::wide_epilogue(d.E, acc, M, N, m0 + wm * 64, n0 + wn * 64, lane, smem6 + wave * x6e::ESZ);
+    return;
+  }
   X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
   if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
@@ -3124,6 +3143,12 @@ static bool x6_tap_ok(const f2g_gemm_desc& d, int taps) {
   return 128 + taps - 1 + (HpIn - A.P0) * (128 / A.P0 + 1) <= 160;
 }
 
+// 1: the launch takes the wide epilogue (x6_epilogue.h; F2G_X6_WIDE=0: the generic one + image read-back)
+static int x6_wide(const f2g_gemm_desc& d) {
+  const char* ev = getenv("F2G_X6_WIDE");          // (read per call so that a test can switch it)
+  return (!ev || atoi(ev) != 0) && x6e::wide_ok(d.E, d.B.rows) ? 1 : 0;
+}
+
 static int launch_x6t(const f2g_gemm_desc& d, int taps, hipStream_t st) {
   const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
   constexpr size_t smem = (160 + 128) * 208;
@@ -3139,8 +3164,8 @@ static int launch_x6t(const f2g_gemm_desc& d, int taps, hipStream_t st) {
   R.P0 = d.A.P0, R.HpIn = (int)(d.A.seq_stride / d.A.unit), R.offpos = -d.A.pad0, R.C32 = d.A.unit / 32;
   R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
   dim3 grid((M + 127) / 128, (N + 127) / 128);
-  if (taps == 5) hipLaunchKernelGGL(gemm_x6t_kernel<5>, grid, dim3(256), smem, st, d, M, N, K, R);
-  else hipLaunchKernelGGL(gemm_x6t_kernel<2>, grid, dim3(256), smem, st, d, M, N, K, R);
+  if (taps == 5) hipLaunchKernelGGL(gemm_x6t_kernel<5>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
+  else hipLaunchKernelGGL(gemm_x6t_kernel<2>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   g_last_path = 4;
   return f2g_check_launch();
 }
@@ -3210,7 +3235,7 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
   }
   R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
   dim3 grid((M + 127) / 128, (N + 127) / 128);
-  hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K, R);
+  hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   g_last_path = 4;
   return f2g_check_launch();
 }
@@ -3242,7 +3267,7 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
     R.bytes = (unsigned)(x6_a_extent(d.A) * 4);
   }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
-  hipLaunchKernelGGL(gemm_x6f_kernel, grid, dim3(256), smem, st, d, M, N, K, R);
+  hipLaunchKernelGGL(gemm_x6f_kernel, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   g_last_path = 4;
   return f2g_check_launch();
 }

@@ -21,15 +21,15 @@
 //    patch (32 rows at a time) into 8-column row segments: bias / leaky ReLU / the leaky-ReLU backward mask of
 //    the layer below (+ feature-matching term) with 16-byte loads, 16-byte stores of the fp32 map AND of its
 //    image pieces from the same registers, column sums (the bias gradient) reduced over the wave's rows
-//    before the atomics; one division per ROW.
+//    before the atomics; one division per ROW (x6_epilogue.h, shared with gemm.hip's six-product kernels).
 #include <stdlib.h>
 
 #include "common.h"
+#include "x6_epilogue.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -37,8 +37,7 @@ constexpr int PITCH = 208;                 // bytes of a staged position / weigh
 constexpr int LH = 160;                    // staged positions of a group's 128 rows (host check)
 constexpr int OPERA = 2 * LH * PITCH;      // both groups' positions
 constexpr int OPERB = 128 * PITCH;         // one weight slab
-constexpr int EPITCH = 72;                 // floats per row of a wave's epilogue patch (32 x 64 + pad)
-constexpr int ESZ = 32 * EPITCH * 4 + 64 * 8;   // bytes per wave: patch + 64 row offsets
+using x6e::ESZ;
 
 struct x6p_tap {
   int P0, HpIn, offpos, C32;
@@ -59,121 +58,6 @@ __device__ __forceinline__ void tile_of_block(int BM, int BN, int& m0, int& n0) 
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   m0 = tm * BM;
   n0 = tn * BN;
-}
-
-// three bf16 pieces of eight floats, packed as 16 bytes per piece (round to nearest even at every step, as
-// f2g_split_bf16x3 / x3_tile_readback)
-__device__ __forceinline__ void split3x8(const float (&x)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
-  unsigned pk[3][4];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 a = (__bf16)x[e];
-    const float r1 = x[e] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const __bf16 c = (__bf16)(r1 - (float)b);
-    const unsigned sa = __builtin_bit_cast(unsigned short, a), sb = __builtin_bit_cast(unsigned short, b),
-                   sc = __builtin_bit_cast(unsigned short, c);
-    if (e & 1) pk[0][e >> 1] |= sa << 16, pk[1][e >> 1] |= sb << 16, pk[2][e >> 1] |= sc << 16;
-    else pk[0][e >> 1] = sa, pk[1][e >> 1] = sb, pk[2][e >> 1] = sc;
-  }
-  p0 = u32x4{pk[0][0], pk[0][1], pk[0][2], pk[0][3]};
-  p1 = u32x4{pk[1][0], pk[1][1], pk[1][2], pk[1][3]};
-  p2 = u32x4{pk[2][0], pk[2][1], pk[2][2], pk[2][3]};
-}
-
-// The wave's 64 x 64 accumulator tile (rows r0.., columns c0..) -> memory.  ep = this wave's LDS patch.
-__device__ __forceinline__ void wide_epilogue(const f2g_epilogue& E, f32x16 (&acc)[2][2], int M, int N, int r0,
-                                              int c0, int lane, unsigned char* ep) {
-  float* patch = reinterpret_cast<float*>(ep);
-  long long* rowoff = reinterpret_cast<long long*>(ep + 32 * EPITCH * 4);
-  const int li = lane & 31, h = lane >> 5;
-  {
-    // element offset of row r0 + lane in the output (row map: one division per row), -1 = past the end
-    const int row = r0 + lane;
-    long long off = -1;
-    if (row < M) {
-      if (E.P0o > 0) {
-        const int sq = row / E.P0o;
-        off = (long long)sq * E.seq_stride_o + (long long)(row - sq * E.P0o) * E.row_stride_o + E.off_o;
-      } else {
-        off = (long long)row * E.ldc;
-      }
-    }
-    rowoff[lane] = off;
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int c8 = lane & 7, col = c0 + c8 * 8;
-  const bool cok = col < N;
-  float bias[8], cs[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = (E.bias && cok) ? E.bias[col + e] : 0.f, cs[e] = 0.f;
-  const float fmw = E.fm_ref ? E.fm_w * (E.fm_wdev ? E.fm_wdev[0] : 1.f) : 0.f;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    // (the patch's previous readers: this wave itself, in program order -- the LDS executes a wave's
-    // instructions in order, so no barrier is needed for a wave-private patch)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        patch[((e & 3) + 8 * (e >> 2) + 4 * h) * EPITCH + ni * 32 + li] = acc[mi][ni][e];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = (lane >> 3) + 8 * j;                 // row of the patch
-      const long long ro = rowoff[mi * 32 + r];
-      const f32x4 u0 = *reinterpret_cast<const f32x4*>(patch + r * EPITCH + c8 * 8);
-      const f32x4 u1 = *reinterpret_cast<const f32x4*>(patch + r * EPITCH + c8 * 8 + 4);
-      if (ro < 0 || !cok) continue;
-      const long long off = ro + col;
-      float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] += bias[e];
-        if (E.lrelu_slope != 0.f) v[e] = v[e] > 0.f ? v[e] : E.lrelu_slope * v[e];
-      }
-      if (E.mask_src) {   // leaky-ReLU backward of the layer below (+ feature-matching term)
-        const f32x4 y0 = *reinterpret_cast<const f32x4*>(E.mask_src + off);
-        const f32x4 y1 = *reinterpret_cast<const f32x4*>(E.mask_src + off + 4);
-        const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-        if (E.fm_ref) {
-          const f32x4 f0 = *reinterpret_cast<const f32x4*>(E.fm_ref + off);
-          const f32x4 f1 = *reinterpret_cast<const f32x4*>(E.fm_ref + off + 4);
-          const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float dl = y[e] - f[e];
-            v[e] += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= y[e] > 0.f ? 1.f : E.mask_slope;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) cs[e] += v[e];
-      *reinterpret_cast<f32x4*>(E.C + off) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(E.C + off + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      if (E.x3_out) {
-        u32x4 p0, p1, p2;
-        split3x8(v, p0, p1, p2);
-        __bf16* q = reinterpret_cast<__bf16*>(E.x3_out) + (off >> 5) * 96 + (off & 31);
-        *reinterpret_cast<u32x4*>(q) = p0;
-        *reinterpret_cast<u32x4*>(q + 32) = p1;
-        *reinterpret_cast<u32x4*>(q + 64) = p2;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (E.colsum) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float s = cs[e];
-      s += __shfl_xor(s, 8);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (lane < 8 && cok) atomicAdd(E.colsum + col + e, s);
-    }
-  }
 }
 
 template <int TAPS>
@@ -310,23 +194,10 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(const f2g_gemm_desc d,
   }
   // every fragment read of the main loop is complete (the last ones were group 1's, before the barrier group 0
   // has just passed): the waves turn their tiles through private patches at the bottom of the LDS
-  wide_epilogue(d.E, acc, M, N, mg + wm * 64, n0 + wn * 64, lane, smem6 + wave * ESZ);
+  x6e::wide_epilogue(d.E, acc, M, N, mg + wm * 64, n0 + wn * 64, lane, smem6 + wave * ESZ);
 }
 
 }  // namespace
-
-// epilogue features the wide epilogue implements: bias, leaky ReLU, row map, leaky-ReLU backward mask (+ the
-// feature-matching term), column sums, the result's three-piece image
-static bool x6p_epilogue_ok(const f2g_epilogue& E, int N) {
-  if (E.res || E.aux || E.prelu_slope || E.prelu_out || E.atomic || E.accumulate || E.c_bf16 || E.colsum_alpha ||
-      E.scale != 0.f || (N & 7))
-    return false;
-  if ((((uintptr_t)E.C) & 15) || (E.mask_src && (((uintptr_t)E.mask_src) & 15)) ||
-      (E.fm_ref && ((((uintptr_t)E.fm_ref) & 15) || !E.mask_src)) || (E.x3_out && (((uintptr_t)E.x3_out) & 15)))
-    return false;
-  if (E.P0o > 0) return !((E.seq_stride_o | E.row_stride_o | E.off_o) & 7);
-  return !(E.ldc & 7);
-}
 
 // d: a precision-3 descriptor that passed gemm.hip's x6_tap_ok(d, taps) (stride-1 windows of `taps` positions
 // over a halo-map image, <= 160 staged positions per 128 rows).  0 = not taken.
@@ -335,7 +206,7 @@ int f2g_x6p_ok(const f2g_gemm_desc& d, int taps) {
   const int mode = ev ? atoi(ev) : 1;       // (read per call so that a test can switch it, as F2G_X6_TAP8)
   if (mode == 0 || (taps != 5 && taps != 2)) return 0;
   if (d.A.unit / 32 < 2) return 0;
-  if (!x6p_epilogue_ok(d.E, d.B.rows)) return 0;
+  if (!x6e::wide_ok(d.E, d.B.rows)) return 0;
   const long long tiles = (long long)((d.A.rows + 255) / 256) * ((d.B.rows + 127) / 128);
   return (mode >= 2 || tiles >= 256) ? 1 : 0;
 }
