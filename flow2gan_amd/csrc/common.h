@@ -14,6 +14,10 @@ void f2g_set_error(const char* msg);
 // gemm_x6p.hip: ping-pong tap-walking fp32-class GEMM (precision 3 over halo-map images); ok = 1 if taken
 int f2g_x6p_ok(const f2g_gemm_desc& d, int taps);
 int f2g_launch_x6p(const f2g_gemm_desc& d, int taps, long long a_extent, hipStream_t st);
+// the same schedule over row operands (plain matrices / strided single-segment windows): split = 0 images, 1 = fp32
+int f2g_x6pr_ok(const f2g_gemm_desc& d);
+int f2g_launch_x6pr(const f2g_gemm_desc& d, int split, int P0, unsigned seq, unsigned step, unsigned off,
+                    unsigned bytes, hipStream_t st);
 // elementwise.hip: out[k][c - begin[k]] += sum_r a[r, c] for up to 3 column ranges (null = skip)
 struct f2g_colsegs {
   float* out[3];

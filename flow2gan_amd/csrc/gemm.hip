@@ -3234,6 +3234,10 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
     R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 6), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 6);
   }
   R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
+  if (f2g_x6pr_ok(d)) {     // round 5: ping-pong wave groups on a 256 x 128 tile (gemm_x6p.hip)
+    g_last_path = 4;
+    return f2g_launch_x6pr(d, 0, R.P0, R.seq6, R.step6, R.off6, R.bytes, st);
+  }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
   hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   g_last_path = 4;
@@ -3265,6 +3269,10 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
     R.P0 = d.A.P0, R.seq6 = (unsigned)(d.A.seq_stride * 4);
     R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 4), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 4);
     R.bytes = (unsigned)(x6_a_extent(d.A) * 4);
+  }
+  if (f2g_x6pr_ok(d)) {     // round 5: ping-pong wave groups, the split under the other group's MFMAs
+    g_last_path = 4;
+    return f2g_launch_x6pr(d, 1, R.P0, R.seq6, R.step6, R.off6, R.bytes, st);
   }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
   hipLaunchKernelGGL(gemm_x6f_kernel, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));

@@ -307,7 +307,7 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
         d.precision = 0       # (what does not qualify below runs on the exact fp32 MFMA)
         in_kernel = X6F == 1
         if X6F == 2 and X6F_MIN_K <= A.cols < X6_MIN_K and (
-                (Bm.rows >= X6F_MIN_N and ((A.rows + 127) // 128) * ((Bm.rows + 127) // 128) >= 376)
+                (Bm.rows >= X6F_MIN_N and ((A.rows + 127) // 128) * ((Bm.rows + 127) // 128) >= X6F_MIN_TILES)
                 or (A.rows >= X6F_TALL_ROWS and Bm.rows >= 128)):
             in_kernel = True      # (mid-length reductions on well-filled grids: see X6F)
         if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS \
@@ -540,9 +540,12 @@ X6_WGRAD = _os.environ.get("F2G_X6_WGRAD", "1") != "0"
 # 12032 x 512 x 1536: 109 : 111 : 95; 6016 x 2304 x 768: 103 : 109 : 96 -- profiles/r03_x6_step.txt),
 # or very tall GEMMs from 128 columns on (113920 x 128 x 1024: 129 against 98; 24064 x 384 x 1152 loses: 88 : 95)
 X6F = int(_os.environ.get("F2G_X6F", "2"))
-X6F_MIN_K = int(_os.environ.get("F2G_X6F_MIN_K", "640"))
-X6F_MIN_N = int(_os.environ.get("F2G_X6F_MIN_N", "512"))
+# (round 5: with the wide epilogue -- x6_epilogue.h -- the in-kernel-split kernel also wins on the generator's
+# short reductions: K >= 384, >= 384 columns, >= 180 tiles; same-box step 183.4 -> 178.2 ms, profiles/r05_x6_rules.txt)
+X6F_MIN_K = int(_os.environ.get("F2G_X6F_MIN_K", "384"))
+X6F_MIN_N = int(_os.environ.get("F2G_X6F_MIN_N", "384"))
 X6F_TALL_ROWS = int(_os.environ.get("F2G_X6F_TALL_ROWS", "65536"))
+X6F_MIN_TILES = int(_os.environ.get("F2G_X6F_MIN_TILES", "180"))
 
 
 def _x3_window_ok(o: Operand) -> bool:

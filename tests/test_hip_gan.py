@@ -128,10 +128,19 @@ def leaky_relu_sign_flips(gan, ogan, real, fake_h, fake_o):
 @pytest.mark.parametrize("fixture,cfg", [("tiny_stage2", TINY), ("tiny_stage2_44k", TINY44)],
                          ids=["24k", "44k"])
 @pytest.mark.parametrize("tag,n", [("n1", 1), ("n2", 2)])
-def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, monkeypatch):
+@pytest.mark.parametrize("pingpong", [False, True], ids=["rule", "pingpong"])
+def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, pingpong, gemm_mode, monkeypatch):
     """D-step / G-step losses and gradients against the REFERENCE's recorded vectors; the 44k
     fixture is BASELINE config 5's geometry (sr 44100 in the seven mel-recon filterbanks and the
-    128-band / n_fft 2048 / hop 512 front end, config.py:64-95, gan.py:44-55)."""
+    128-band / n_fft 2048 / hop 512 front end, config.py:64-95, gan.py:44-55).
+    pingpong (bf16x6 only): the round-5 six-product kernels (gemm_x6p.hip: ping-pong wave groups on 256-row
+    tiles) forced onto every launch their geometry allows, whatever the grid size -- the library's rule gives
+    them chip-filling grids only, which these small cases never are."""
+    if pingpong:
+        if gemm_mode not in ("bf16x6", "3"):
+            pytest.skip("the ping-pong kernels are six-product kernels")
+        monkeypatch.setenv("F2G_X6P", "2")
+        monkeypatch.setenv("F2G_X6PR", "2")
     g = golden(fixture)
     gan = build_gan(f2g, g, cfg)
     assert gan.generator.sampling_rate == cfg["sampling_rate"]

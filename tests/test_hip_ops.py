@@ -1188,13 +1188,17 @@ def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
     assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("tile", ["tile128", "pingpong"])
 @pytest.mark.parametrize("kernel", ["images", "in-kernel split"])
 @pytest.mark.parametrize("M,N,K", [(6016, 768, 2304), (1500, 200, 96), (4099, 1152, 384)])
-def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, monkeypatch):
+def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, tile, monkeypatch):
     """precision 3 (`bf16x6`): three bf16 pieces per operand, six MFMAs per product.  Against float64 its
     error must be of the class of the exact-fp32 kernel's on the same operands (max over ALL entries of
     |err| / sum |a w| below 1e-6 and within 3x of the fp32 MFMA's; plain bf16 is at 1e-3), on ragged extents, with bias / residual / PReLU epilogues
-    and as a data gradient (form 1 through the cached transpose)."""
+    and as a data gradient (form 1 through the cached transpose).  tile128: gemm_x6_kernel / gemm_x6f_kernel
+    (128 x 128 tiles, two blocks per CU); pingpong: gemm_x6pr_kernel (round 5: 256 x 128 tiles, two wave groups
+    half a step apart) whatever the grid size."""
+    monkeypatch.setenv("F2G_X6PR", "2" if tile == "pingpong" else "0")
     gen = torch.Generator().manual_seed(M + K)
     a = torch.randn(M, K, generator=gen) * (1.0 + 3.0 * torch.rand(M, K, generator=gen))
     w = torch.randn(N, K, generator=gen) * 0.05
@@ -1231,7 +1235,7 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, monkeypatch):
             monkeypatch.setattr(ops, "X6_MIN_K", 1 << 20)                   # every K below it: in-kernel split
         out3 = ops.x3_reserve(torch.full((M, N), float("nan"), device=DEV))
         ops.gemm(ops.mat(ad), ops.mat(wd), out3, bias=g(bias), lrelu=0.1, x3_out=True)
-        if kernel == "images" or (N >= 512 and ((M + 127) // 128) * ((N + 127) // 128) >= 376):
+        if kernel == "images" or (N >= ops.X6F_MIN_N and ((M + 127) // 128) * ((N + 127) // 128) >= ops.X6F_MIN_TILES):
             img = getattr(out3, "_f2g_x3", None)
             assert img is not None and not getattr(out3, "_f2g_x3_bad", False)
             assert torch.equal(img.view(torch.int16), ops.x3_flat_image(out3).view(torch.int16))
