@@ -2096,6 +2096,14 @@ void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
 #else
 #define X6LAB_X3
 #endif
+// Main-loop barrier of the six-product kernels: the LDS traffic of this wave is done, then the block barrier.
+// __syncthreads() also waits for vmcnt(0), i.e. for the NEXT slab's global loads the wave has just issued --
+// the prefetch would be drained at every slab (round 5; gemm_x6p.hip has it from the start).
+#if F2G_X6LAB & 4      // (lab build: the old barrier, for A/B runs)
+#define X6_LDS_BARRIER() __syncthreads()
+#else
+#define X6_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 __device__ __forceinline__ void split3x4(const u32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
   // (by value first: __builtin_bit_cast applied to a vector-element expression reads element 0)
   const unsigned u0 = v.x, u1 = v.y, u2 = v.z, u3 = v.w;
@@ -2208,7 +2216,7 @@ void gemm_leanw6_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
     kb += stepB;
     srow += BK;
     gload(t + 1 < nt);           // (past the end: the first slab again, never used)
-    __syncthreads();
+    X6_LDS_BARRIER();
     bf16x8 fa[2][3][2], fb[2][3][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -2219,7 +2227,7 @@ void gemm_leanw6_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
           fa[ks][pc][tt] = tr_frag(sm + ks * 16 * 256 + pc * PL + rofA[tt]);
           fb[ks][pc][tt] = tr_frag(sm + ks * 16 * 256 + (3 + pc) * PL + rofB[tt]);
         }
-    __syncthreads();
+    X6_LDS_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -2699,7 +2707,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
       *reinterpret_cast<u32x4*>(smem6 + OPER + lo[j]) = xw[j];
     }
     gload(t + 1 < nt ? t + 1 : 0);       // (past the end: re-read, never used)
-    __syncthreads();
+    X6_LDS_BARRIER();
     bf16x8 fa[2][3][2], fb[2][3][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -2710,7 +2718,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
           fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + i * 32 * PITCH + ks * 32);
           fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
         }
-    __syncthreads();
+    X6_LDS_BARRIER();
     __builtin_amdgcn_s_setprio(X6_MFMA_PRIO);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -2826,7 +2834,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d,
         const int tn = t + 1 < TAPS ? t + 1 : 0, cn = t + 1 < TAPS ? cs : (cs + 1 < R.C32 ? cs + 1 : 0);
         gloadB(tn * R.C32 + cn);
       }
-      __syncthreads();
+      X6_LDS_BARRIER();
       bf16x8 fa[2][3][2], fb[2][3][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -2837,7 +2845,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d,
             fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA[i] + t * PITCH + p * 64 + ks * 32);
             fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
           }
-      __syncthreads();
+      X6_LDS_BARRIER();
       __builtin_amdgcn_s_setprio(X6_MFMA_PRIO);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -3065,7 +3073,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
       *reinterpret_cast<u32x2*>(smem6 + OPER + lo[j] + 128) = p2;
     }
     gload(t + 1 < nt ? t + 1 : 0);       // (past the end: re-read, never used)
-    __syncthreads();
+    X6_LDS_BARRIER();
     bf16x8 fa[2][3][2], fb[2][3][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -3076,7 +3084,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
           fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + i * 32 * PITCH + ks * 32);
           fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
         }
-    __syncthreads();
+    X6_LDS_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
