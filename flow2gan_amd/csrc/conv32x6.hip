@@ -670,6 +670,109 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_wgrad6_kernel(const f2g_conv
   }
 }
 
+// ---- the fifth layer of a band stack: Conv2d(32, 32, (3, 3), padding (1, 1)), stride 1 (round 5) -------
+// (discriminators.py:171-181, last entry of the band stack.)  As an implicit GEMM this is M = 10^5 pixels x
+// N = 32 x K = 288 on the generic kernel's 128 x 32 tiles with bounds-tested windows: 51 TFLOP/s forward, 29
+// in the weight gradient (profiles/r05_*).  Direct, fp32 class: the images are narrow (7 ... 33 columns after
+// three stride-2 layers), so a tile is R WHOLE rows (R * W <= 256 pixels, >= 90 % of the MFMA rows used at
+// every band width) staged with one zero column on either side and one row above / below -- the nine taps are
+// then nine constant offsets into the staged patch, with no per-tap masks.  One persistent block of 8 waves per
+// CU: all nine weight tiles (55 KB image, 208-byte rows) stay in LDS for the block's life, the next tile's
+// patch is requested before the current tile's 108 MFMAs per wave and split into its three pieces behind them.
+// The data gradient of a stride-1 conv is the same kernel over the gradient map with the taps flipped and the
+// channel matrix transposed (the host re-lays the weights once per version).
+constexpr int P33 = 352;                 // staged pixels of a tile: (R + 2) * (W + 2) <= P33
+constexpr int T33 = 9;
+
+__global__ __launch_bounds__(512, 1) void conv33_x6_kernel(const f2g_conv32_desc d, int R, int tiles_h, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+  unsigned char* At = smb;                       // [P33] staged pixels
+  unsigned char* Bt = smb + P33 * PB;            // [9 taps][32 co] weight rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int W = d.Win, PW = W + 2, npx = (R + 2) * PW, tpx = R * W;
+  const unsigned mgW = magic_of(W), mgPW = magic_of(PW);
+  // weights: image [co][9 taps][192 bytes] -> LDS rows (tap, co) of 208 bytes
+  {
+    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(d.w);
+    for (int c = tid; c < T33 * C * 12; c += 512) {
+      const int row = c / 12, part = c - row * 12;           // row = co * 9 + tap in the image
+      const int co = row / T33, tap = row - co * T33;
+      *reinterpret_cast<u32x4*>(Bt + (tap * C + co) * PB + part * 16) =
+          *reinterpret_cast<const u32x4*>(wimg + row * 192 + part * 16);
+    }
+  }
+  // this thread's chunks of a patch: chunk id = tid + 512 q -> (staged pixel, 4 channels)
+  constexpr int NQ = (P33 * 8 + 511) / 512;
+  int prow[NQ], poff[NQ], pdst[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int id = tid + 512 * q, px = id >> 3, c4 = id & 7;
+    const int pr = fast_div(px, PW, mgPW), pc = px - pr * PW;
+    const bool ok = px < npx && pc >= 1 && pc <= W;
+    prow[q] = ok ? pr : -(1 << 20);                          // (columns of the zero border: never valid)
+    poff[q] = (pr - 1) * (int)d.x_line + (pc - 1) * C + c4 * 4;
+    pdst[q] = px < npx ? px * PB + c4 * 8 : -1;
+  }
+  auto load_patch = [&](int tile, f32x4 (&pf)[NQ]) {
+    const int sq = tile / tiles_h, h0 = (tile - sq * tiles_h) * R;
+    const float* org = d.x + (long long)sq * d.x_seq + (long long)h0 * d.x_line;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int h = h0 - 1 + prow[q];
+      pf[q] = *reinterpret_cast<const f32x4*>((h >= 0 && h < d.H) ? org + poff[q] : c6_zero);
+    }
+  };
+  auto store_patch = [&](const f32x4 (&pf)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (pdst[q] >= 0) store_px3(At + pdst[q], pf[q]);
+  };
+  // this lane's output pixel: tile pixel 32 wave + li -> (row, column) -> staged position
+  const int mypx = wave * 32 + li;
+  const int myr = fast_div(mypx, W, mgW), myc = mypx - myr * W;
+  const unsigned char* Ap = At + (mypx < tpx ? ((myr + 1) * PW + myc + 1) * PB : (PW + 1) * PB) + hh * 16;
+  const unsigned char* Bp = Bt + li * PB + hh * 16;
+  const float bias = d.bias ? d.bias[li] : 0.f;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  {
+    f32x4 pf[NQ];
+    load_patch(tile, pf);
+    store_patch(pf);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < ntiles;
+    f32x4 pf[NQ];
+    load_patch(more ? nxt : tile, pf);            // (the last tile re-requests its own: never stored)
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < T33; ++t)
+      tap6(Ap + ((t / 3 - 1) * PW + (t % 3 - 1)) * PB, Bp + t * (C * PB), acc0, acc1);
+    {
+      const int sq = tile / tiles_h, h0 = (tile - sq * tiles_h) * R;
+      float* ys = d.y + (long long)sq * d.y_seq + (long long)h0 * d.y_line;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int r = fast_div(p, W, mgW), c = p - r * W;
+        if (p < tpx && h0 + r < d.H) {
+          float v = acc0[e] + acc1[e] + bias;
+          if (d.lrelu_slope != 0.f) v = v > 0.f ? v : d.lrelu_slope * v;
+          ys[(long long)r * d.y_line + c * C + li] = v;
+        }
+      }
+    }
+    __syncthreads();                               // every wave is done with this patch
+    if (more) store_patch(pf);
+    __syncthreads();
+  }
+}
+
 template <int TH_, int TW_>
 constexpr size_t fwd6_smem() {
   return (size_t)2 * ((TH_ + 2) * (TW_ + 4) * PB + 64) + 2 * TG * WBB + 4 * 16 * 64 * sizeof(float);
@@ -765,5 +868,32 @@ int f2g_conv32_wgrad6_launch(const f2g_conv32_desc* d, float* gw, hipStream_t st
     hipLaunchKernelGGL((conv32_s2_wgrad6_kernel<16, 8>), dim3(grid), dim3(512), sm16, st, *d, gw, tiles_h, tiles_w, per);
   else
     hipLaunchKernelGGL((conv32_s2_wgrad6_kernel<8, 16>), dim3(grid), dim3(512), sm8, st, *d, gw, tiles_h, tiles_w, per);
+  return f2g_check_launch();
+}
+
+// Conv2d(32, 32, (3, 3), padding (1, 1)) + bias + leaky ReLU, fp32 class (include/flow2gan_hip.h)
+extern "C" int f2g_conv33_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
+  if (!d || !d->x || !d->w || !d->y || d->precision != 3 || d->Win != d->Wout || d->mask_src || d->colsum)
+    return F2G_EINVAL;
+  if ((((uintptr_t)d->x) & 15) || (((uintptr_t)d->w) & 15) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
+  if (d->S <= 0 || d->H <= 0 || d->Win <= 0) return F2G_OK;
+  const int W = d->Win;
+  if (W > 112 || d->x_line >= (1ll << 24)) return F2G_EINVAL;     // 3 * (W + 2) staged pixels <= P33
+  int R = 256 / W;                                   // whole rows per tile
+  if (R > d->H) R = d->H;
+  while (R > 1 && (R + 2) * (W + 2) > P33) --R;
+  if (R < 1 || (R + 2) * (W + 2) > P33) return F2G_EINVAL;
+  const int tiles_h = (d->H + R - 1) / R;
+  const long long nt = (long long)tiles_h * d->S;
+  if (nt >= (1ll << 30)) return F2G_EINVAL;
+  constexpr size_t smem = (size_t)P33 * PB + (size_t)T33 * C * PB;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv33_x6_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  const int grid = (int)(nt < 256 ? nt : 256);          // one resident block per CU
+  hipLaunchKernelGGL(conv33_x6_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, *d, R, tiles_h, (int)nt);
   return f2g_check_launch();
 }

@@ -486,6 +486,11 @@ def _mrd_forward_one(x2, win: int, prm: list):
             elif l < 4:
                 y = ops.empty(S * Ft * Wout, MRD_CH, device=dev)
                 gemm(A, mat(wp), y, bias=b, lrelu=SLOPE)
+            elif DIRECT_CONV32 and ops.GEMM_PRECISION == 3 and ops.CONV33_X6 and Wout <= ops.CONV33_MAX_W:
+                # 32 -> 32 channels, (3, 3) taps, stride 1, into the band's slice of the concatenated map
+                y = None
+                ops.conv33(x, S, Ft, Wout, wp, b, SLOPE, cat, y_off=foff * MRD_CH, y_line=Wcat * MRD_CH,
+                           y_seq=Ft * Wcat * MRD_CH)
             else:
                 y = None
                 gemm(A, mat(wp), cat, bias=b, lrelu=SLOPE,
@@ -523,6 +528,18 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
         wT = ops.derived(w, "dgrad_taps", build_t)
         ops.conv32_s2_dgrad(g_pre, S, H, Win, Wout, wT, gx, g_seq=g_seq, g_line=g_line, g_off=g_off,
                             mask=mask, fm=fm, colsum=colsum)
+        return gx
+    if (DIRECT_CONV32 and ops.GEMM_PRECISION == 3 and ops.CONV33_X6 and Cin == MRD_CH and Cout == MRD_CH
+            and kh == 3 and kw == 3 and sw == 1 and x_line is None and x_off == 0 and mask is None
+            and colsum is None and Win <= ops.CONV33_MAX_W):
+        # stride 1: the data gradient is the forward kernel over the gradient map with the taps flipped and
+        # the channel matrix transposed, [ci][8 - tap][co]
+        def build_f(t):
+            out = ops.empty(Cin, kh * kw * Cout, device=t.device)
+            ops.permute4(out, t, (Cin, kh * kw, Cout, 1), (kh * kw, -1, Cin * kh * kw, 0), in_offset=kh * kw - 1)
+            return out
+        wf = ops.derived(w, "dgrad33", build_f)
+        ops.conv33(g_pre, S, H, Win, wf, None, 0.0, gx, x_off=g_off, x_line=g_line, x_seq=g_seq, form=1)
         return gx
     if x_line is None:
         x_line = Win * Cin

@@ -652,6 +652,36 @@ def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope:
     return y
 
 
+CONV33_X6 = _os.environ.get("F2G_CONV33_X6", "1") != "0"    # bf16x6 mode: direct (3, 3) band layer
+CONV33_MAX_W = 112     # one image row + its border must fit the kernel's 352 staged pixels: 3 * (W + 2) <= 352
+
+
+def conv33(x, S: int, H: int, W: int, w_packed, bias, slope: float, y, x_off: int = 0, x_line=None, x_seq=None,
+           y_off: int = 0, y_line=None, y_seq=None, form: int = 0):
+    """Conv2d(32, 32, (3, 3), padding (1, 1)) (+ bias + leaky ReLU) on channels-last images, fp32 class
+    (conv32x6.hip: conv33_x6_kernel): x (S, H, W, 32) -> y (S, H, W, 32), both optionally strided slices of
+    wider maps (floats); w_packed = (32, 9*32) [co][tap][ci] -- for the data gradient the caller passes the
+    gradient map and the flipped / transposed matrix [ci][8 - tap][co] (form = 1: bench.py's FLOP table)."""
+    d = L.Conv32Desc()
+    d.x = ptr(x) + 4 * x_off
+    d.x_line = x_line if x_line is not None else W * 32
+    d.x_seq = x_seq if x_seq is not None else H * d.x_line
+    d.S, d.H, d.Win, d.Wout = S, H, W, W
+    img = x3_image(w_packed)
+    d.precision = 3
+    d._keep = img
+    d.w, d.bias, d.lrelu_slope = ptr(img), ptr(bias), slope
+    d.y = ptr(y) + 4 * y_off
+    d.y_line = y_line if y_line is not None else W * 32
+    d.y_seq = y_seq if y_seq is not None else H * d.y_line
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_conv33_fwd", C.byref(d)),
+                        2.0 * S * H * W * 32 * 9 * 32, (form, S * H * W, 32, 9 * 32))
+    else:
+        call("f2g_conv33_fwd", C.byref(d))
+    return y
+
+
 def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, g_line=None,
                     g_off: int = 0, mask=None, fm=None, colsum=None):
     """Data gradient of Conv2d(32, 32, (3, 9), stride (1, 2), padding (1, 4)): g (S, H, Wout, 32)

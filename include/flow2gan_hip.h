@@ -555,6 +555,14 @@ int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream);
 /* Weight gradient of that layer: x = layer input (S, H, Win, 32), y = gradient of the
  * pre-activation (S, H, Wout, 32) (read), gw (32, 27*32) [co][tap][ci] accumulated atomically. */
 int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stream_t stream);
+/* Fifth layer of a band stack, Conv2d(32, 32, (3, 3), padding (1, 1)), stride 1 (discriminators.py:171-181,
+ * last entry) as a direct kernel, fp32 class only (precision must be 3; the exact-fp32 step keeps the
+ * implicit GEMM): x (S, H, W, 32) and y (S, H, W, 32) with explicit sequence / line strides (Win == Wout
+ * == W <= 112; the forward writes its band's slice of the concatenated map), w = the f2g_split_bf16x3 image of the
+ * packed (32, 9*32) matrix [co][tap][ci], + bias + leaky ReLU.  The DATA GRADIENT of this layer is the same
+ * call over the gradient map with w = the image of [ci][8 - tap][co] (taps flipped, channel matrix
+ * transposed) and no bias / slope.  mask_src / colsum must be NULL. */
+int f2g_conv33_fwd(const f2g_conv32_desc* d, f2g_stream_t stream);
 
 /* First layer of every MRD band stack, Conv2d(2, 32, (3, 9), stride 1, padding (1, 4))
  * (discriminators.py:171,195-203), as direct kernels (conv2ch.hip).  The input is a frequency band

@@ -1066,6 +1066,44 @@ def test_direct_conv32_fp32_class(ops, S, H, Win):
     close(out["bf16x6"][4], want_m.sum(0), rtol=1e-4, name="column sums")
 
 
+@pytest.mark.parametrize("S,H,W", [(3, 47, 13), (2, 94, 7), (5, 19, 33), (128, 47, 32), (2, 5, 1), (3, 9, 112),
+                                   (300, 23, 17), (1, 200, 20)])
+def test_direct_conv33_fp32_class(ops, S, H, W):
+    """conv32x6.hip conv33_x6_kernel (round 5): the (3, 3) fifth layer of an MRD band stack as a direct kernel
+    with fp32-class products -- forward (bias + leaky ReLU, written into a band's slice of a wider concatenated
+    map) and data gradient (the same kernel over a slice of the concatenated gradient map with flipped /
+    transposed weights, as fused_disc._conv2d_dgrad builds them) against float64 conv2d + autograd at the
+    exact-fp32 tolerances; band widths on both sides of the tile-row rule (R whole rows per 256-pixel tile),
+    more tiles than the persistent kernel has blocks, single-column and 112-column (the widest) images."""
+    from flow2gan_amd import fused_disc as fd
+    x = rnd(S * H * W, 32, seed=1)
+    w = rnd(32, 32, 3, 3, seed=2, scale=0.08)
+    b = rnd(32, seed=3)
+    foff, Wcat = 5, W + 9                                  # the band's slice of the concatenated maps
+    gcat = rnd(S * H * Wcat, 32, seed=4)
+    xd = x.reshape(S, H, W, 32).permute(0, 3, 1, 2).double().requires_grad_(True)
+    pre = torch.nn.functional.conv2d(xd, w.double(), b.double(), padding=(1, 1))
+    ref = torch.nn.functional.leaky_relu(pre, 0.1).permute(0, 2, 3, 1).detach()           # (S, H, W, 32)
+    gy = gcat.reshape(S, H, Wcat, 32)[:, :, foff:foff + W]
+    pre.backward(gy.permute(0, 3, 1, 2).double())
+    gref = xd.grad.permute(0, 2, 3, 1).reshape(S * H * W, 32)
+    was = ops.GEMM_PRECISION
+    try:
+        ops.set_gemm_precision("bf16x6")
+        wd = torch.nn.Parameter(g(w))
+        wp = ops.derived(wd, "pack", fd.pack_conv_weight)
+        cat = torch.full((S * H * Wcat, 32), 7.0, device=DEV)
+        ops.conv33(g(x), S, H, W, wp, g(b), 0.1, cat, y_off=foff * 32, y_line=Wcat * 32, y_seq=H * Wcat * 32)
+        catv = cat.cpu().reshape(S, H, Wcat, 32)
+        close(catv[:, :, foff:foff + W].double(), ref, rtol=2e-5, name="conv33 forward")
+        assert bool((catv[:, :, :foff] == 7.0).all()) and bool((catv[:, :, foff + W:] == 7.0).all())
+        gx = torch.full((S * H * W, 32), 7.0, device=DEV)
+        fd._conv2d_dgrad(g(gcat), S, H, W, 32, wd, 1, W, gx, g_line=Wcat * 32, g_seq=H * Wcat * 32, g_off=foff * 32)
+        close(gx.cpu().double(), gref, rtol=2e-5, name="conv33 data gradient")
+    finally:
+        ops.GEMM_PRECISION = was
+
+
 @pytest.mark.parametrize("S,H,W,lo,Wtot", [(2, 11, 34, 7, 50), (3, 8, 32, 0, 32), (1, 5, 3, 2, 9), (2, 21, 77, 10, 100)])
 def test_conv2ch_direct_kernels_match_autograd(ops, S, H, W, lo, Wtot):
     """conv2ch.hip (first MRD layer, 2 -> 32 channels on a band of the interleaved spectrogram):
