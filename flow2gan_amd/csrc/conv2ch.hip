@@ -457,41 +457,61 @@ __global__ __launch_bounds__(256) void convpost_fwd_kernel(const f2g_conv2ch_des
     d.y[((long long)s * d.H + hh) * d.W + ww] = a0 + a1 + (d.bias ? d.bias[0] : 0.f);
 }
 
-// gw[tap*32 + ci] += sum_px g[px] * x[px + tap][ci]; thread = one of the 288 weights
-__global__ __launch_bounds__(256) void convpost_wgrad_kernel(const f2g_conv2ch_desc d, int tiles_h,
-                                                             int tiles_w, int tiles_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float patch[];   // patch + the tile's 256 gradients
-  float* gt = patch + QPH * QPW * GP;
-  const int tid = threadIdx.x;
-  const int ntiles = d.S * tiles_h * tiles_w;
-  // weights owned by this thread: k0 = tid (tap tid/32, ci tid%32) and, for tid < 32, k1 = 256 + tid
-  const int t0k = tid >> 5, c0k = tid & 31;
-  const int off0 = ((t0k / 3) * QPW + t0k % 3) * GP + c0k;
-  const int off1 = ((8 / 3) * QPW + 8 % 3) * GP + c0k;      // tap 8
-  float acc0 = 0.f, acc1 = 0.f;
-  const int tb = blockIdx.x * tiles_per_block;
-  for (int ti = tb; ti < tb + tiles_per_block && ti < ntiles; ++ti) {
-    const int s = ti / (tiles_h * tiles_w), rem = ti - s * (tiles_h * tiles_w);
-    const int th = rem / tiles_w, tw = rem - th * tiles_w;
-    const int h0 = th * QTH, w0 = tw * QTW;
-    __syncthreads();
-    stage32(patch, d.x + (long long)s * d.H * d.W * CO, d.H, d.W, h0, w0, tid);
-    {
-      const int pw = tid & 31, ph = tid >> 5;
-      const int hh = h0 + ph, ww = w0 + pw;
-      gt[tid] = (hh < d.H && ww < d.W) ? d.y[((long long)s * d.H + hh) * d.W + ww] : 0.f;
+// gw[tap*32 + ci] += sum_px g[px] * x[px + tap][ci]  =  sum_q x[q][ci] * g[q - tap]: every pixel of the
+// 32-channel map is read ONCE, straight from global memory (8 threads per pixel, 16 bytes each: whole 128-byte
+// rows per lane group), and multiplied with the nine score gradients around it (a 1-channel map: L2-resident);
+// 36 accumulators per thread, reduced over the block's 32 pixel groups in LDS, one atomic per weight and block.
+// (Round 4's kernel kept a thread per WEIGHT and walked a staged tile's 256 pixels with one LDS read per FMA:
+// 0.45 TB/s on the map, 224 us per launch.)
+__global__ __launch_bounds__(256) void convpost_wgrad_kernel(const f2g_conv2ch_desc d, int px_per_block) {
+  __shared__ float red[32][9 * CO + 1];
+  const int tid = threadIdx.x, c4 = tid & 7, pg = tid >> 3;
+  const long long npx = (long long)d.S * d.H * d.W;
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long p0 = (long long)blockIdx.x * px_per_block;
+  const long long pend = p0 + px_per_block < npx ? p0 + px_per_block : npx;
+  constexpr int U = 4;                     // pixels in flight per thread
+  for (long long p = p0 + pg; p < pend; p += 32 * U) {
+    float4 v[U];
+    float gn[U][9];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long q = p + 32 * u;
+      const bool on = q < pend;
+      const long long qq = on ? q : p;
+      v[u] = *reinterpret_cast<const float4*>(d.x + qq * CO + c4 * 4);
+      const int w = (int)(qq % d.W);
+      const int h = (int)((qq / d.W) % d.H);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // x[q] is the window element of tap t for the output pixel q - (t/3 - 1, t%3 - 1)
+        const int oh = h - (t / 3 - 1), ow = w - (t % 3 - 1);
+        const bool ok = on && oh >= 0 && oh < d.H && ow >= 0 && ow < d.W;
+        gn[u][t] = ok ? d.y[qq - (long long)(t / 3 - 1) * d.W - (t % 3 - 1)] : 0.f;
+      }
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int px = 0; px < QTH * QTW; ++px) {
-      const float gv = gt[px];
-      const int pb = ((px >> 5) * QPW + (px & 31)) * GP;
-      acc0 += gv * patch[pb + off0];
-      if (tid < 32) acc1 += gv * patch[pb + off1];
-    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        acc[t].x += gn[u][t] * v[u].x; acc[t].y += gn[u][t] * v[u].y;
+        acc[t].z += gn[u][t] * v[u].z; acc[t].w += gn[u][t] * v[u].w;
+      }
   }
-  atomicAdd(d.gw + tid, acc0);
-  if (tid < 32) atomicAdd(d.gw + 256 + tid, acc1);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    red[pg][t * CO + c4 * 4 + 0] = acc[t].x; red[pg][t * CO + c4 * 4 + 1] = acc[t].y;
+    red[pg][t * CO + c4 * 4 + 2] = acc[t].z; red[pg][t * CO + c4 * 4 + 3] = acc[t].w;
+  }
+  __syncthreads();
+  for (int k = tid; k < 9 * CO; k += 256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int g2 = 0; g2 < 32; ++g2) s += red[g2][k];
+    atomicAdd(d.gw + k, s);
+  }
 }
 
 // gx[px][ci] = sum_tap g[px - tap] * w[tap][ci]: 8 threads per pixel, 4 channels each
@@ -594,19 +614,10 @@ extern "C" int f2g_convpost_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream) 
 extern "C" int f2g_convpost_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
   if (!d || !d->x || !d->y || !d->gw || (((uintptr_t)d->x) & 15)) return F2G_EINVAL;
   if (!conv2ch_ok(d)) return F2G_OK;
-  const size_t smem = (size_t)(QPH * QPW * GP + QTH * QTW) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpost_wgrad_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
-  }
-  const int tiles_h = (d->H + QTH - 1) / QTH, tiles_w = (d->W + QTW - 1) / QTW;
-  const int ntiles = d->S * tiles_h * tiles_w;
-  int per = (ntiles + 1023) / 1024;
-  if (per < 1) per = 1;
-  hipLaunchKernelGGL(convpost_wgrad_kernel, dim3((ntiles + per - 1) / per), dim3(256), smem, ST, *d,
-                     tiles_h, tiles_w, per);
+  const long long npx = (long long)d->S * d->H * d->W;
+  long long per = (npx + 1023) / 1024;     // <= 1024 blocks: 0.3 M atomics on 288 addresses per launch
+  if (per < 128) per = 128;
+  hipLaunchKernelGGL(convpost_wgrad_kernel, dim3((unsigned)((npx + per - 1) / per)), dim3(256), 0, ST, *d, (int)per);
   return f2g_check_launch();
 }
 

@@ -204,16 +204,29 @@ __global__ __launch_bounds__(256) void mpdpost_wgrad_kernel(const f2g_mpdpost_de
   const int Hp = d.H + 2 * d.halo;
   long long r = (long long)blockIdx.x * rows_per;
   const long long rend = r + rows_per < R ? r + rows_per : R;
-  for (; r < rend; ++r) {
-    const int s = (int)(r / Hq), hp = (int)(r - (long long)s * Hq) - 1;
-    const float* g = d.g + (long long)s * d.H;
-    const float g0 = hp + 1 < d.H ? g[hp + 1] : 0.f;                  // tap 0 of output hp + 1
-    const float g1 = (hp >= 0 && hp < d.H) ? g[hp] : 0.f;             // tap 1 of output hp
-    const float g2 = hp >= 1 ? g[hp - 1] : 0.f;                       // tap 2 of output hp - 1
-    const float4 v = reinterpret_cast<const float4*>(d.y + ((long long)s * Hp + d.halo + hp) * CP)[t];
-    a0.x += g0 * v.x; a0.y += g0 * v.y; a0.z += g0 * v.z; a0.w += g0 * v.w;
-    a1.x += g1 * v.x; a1.y += g1 * v.y; a1.z += g1 * v.z; a1.w += g1 * v.w;
-    a2.x += g2 * v.x; a2.y += g2 * v.y; a2.z += g2 * v.z; a2.w += g2 * v.w;
+  // (round 5: eight map rows requested before any is consumed -- one 16-byte load in flight per thread left
+  // the kernel at 1.5 TB/s: these streams are a memory-level-parallelism problem)
+  constexpr int U = 8;
+  for (; r < rend; r += U) {
+    float4 v[U];
+    float g0[U], g1[U], g2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long ru = r + u < rend ? r + u : rend - 1;
+      const int s = (int)(ru / Hq), hp = (int)(ru - (long long)s * Hq) - 1;
+      const float* g = d.g + (long long)s * d.H;
+      const bool on = r + u < rend;
+      g0[u] = (on && hp + 1 < d.H) ? g[hp + 1] : 0.f;                  // tap 0 of output hp + 1
+      g1[u] = (on && hp >= 0 && hp < d.H) ? g[hp] : 0.f;               // tap 1 of output hp
+      g2[u] = (on && hp >= 1) ? g[hp - 1] : 0.f;                       // tap 2 of output hp - 1
+      v[u] = reinterpret_cast<const float4*>(d.y + ((long long)s * Hp + d.halo + hp) * CP)[t];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a0.x += g0[u] * v[u].x; a0.y += g0[u] * v[u].y; a0.z += g0[u] * v[u].z; a0.w += g0[u] * v[u].w;
+      a1.x += g1[u] * v[u].x; a1.y += g1[u] * v[u].y; a1.z += g1[u] * v[u].z; a1.w += g1[u] * v[u].w;
+      a2.x += g2[u] * v[u].x; a2.y += g2[u] * v[u].y; a2.z += g2[u] * v[u].z; a2.w += g2[u] * v[u].w;
+    }
   }
   float* o = gw + 4 * t;
   atomicAdd(o + 0, a0.x); atomicAdd(o + 1, a0.y); atomicAdd(o + 2, a0.z); atomicAdd(o + 3, a0.w);
@@ -285,8 +298,10 @@ extern "C" int f2g_mpdpost_wgrad(const f2g_mpdpost_desc* d, float* gw, f2g_strea
   if (!d || !d->y || !d->g || !gw || d->H <= 0 || d->halo < 1 || (((uintptr_t)d->y) & 15)) return F2G_EINVAL;
   if (d->S <= 0) return F2G_OK;
   const long long R = (long long)d->S * (d->H + 2);
-  int per = (int)((R + 511) / 512);
-  if (per < 1) per = 1;
+  // <= 256 blocks (one per CU, eight rows in flight per thread): 0.8 M atomics on 3072 addresses per launch --
+  // with 1024 blocks the same-address atomics, not the stream, set the time (128 us against 106)
+  int per = (int)((R + 255) / 256);
+  if (per < 8) per = 8;
   hipLaunchKernelGGL(mpdpost_wgrad_kernel, dim3((unsigned)((R + per - 1) / per)), dim3(256), 0,
                      (hipStream_t)stream, *d, gw, per);
   return f2g_check_launch();
