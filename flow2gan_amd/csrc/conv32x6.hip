@@ -404,6 +404,22 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
     const bool more = nxt < ntiles;
     f32x4 pf[NCHK];
     load_patch(more ? nxt : tile, pf);
+    int sq, h0, m0;
+    tile_pos(tile, sq, h0, m0);
+    // (round 5) the mask of this tile's outputs is requested HERE, sixteen values per lane: read in the
+    // epilogue it put a memory round trip behind every tile's MFMAs with nothing else resident on the CU --
+    // which is why the fused leaky-ReLU backward used to lose against a separate pass over the map
+    float my[16];
+    if (msk && !fm) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        int qh, qw;
+        px_of_row<TW_>(pg, (q & 3) + 8 * (q >> 2) + 4 * hh, qh, qw);
+        const int oh = h0 + qh, om = m0 + qw;
+        const long long off = (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + li;
+        my[q] = (oh < d.H && om < Wp) ? d.mask_src[off] : 1.f;
+      }
+    }
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -421,8 +437,6 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
     }
 #undef F2G_C6_GOFF
     // ---- epilogue: optional leaky-ReLU backward of the layer below (+ feature-matching term)
-    int sq, h0, m0;
-    tile_pos(tile, sq, h0, m0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       int qh, qw;
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
         const long long off = (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + li;
         float v = acc0[q] + acc1[q];
         if (msk) {
-          const float y = d.mask_src[off];
+          const float y = fm ? d.mask_src[off] : my[q];
           if (fm) {
             const float dl = y - d.fm_ref[off];
             v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
@@ -734,6 +748,7 @@ __global__ __launch_bounds__(512, 1) void conv33_x6_kernel(const f2g_conv32_desc
   const unsigned char* Ap = At + (mypx < tpx ? ((myr + 1) * PW + myc + 1) * PB : (PW + 1) * PB) + hh * 16;
   const unsigned char* Bp = Bt + li * PB + hh * 16;
   const float bias = d.bias ? d.bias[li] : 0.f;
+  float cs = 0.f;                                // column sums of what this lane stores (channel li)
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
   {
@@ -747,6 +762,18 @@ __global__ __launch_bounds__(512, 1) void conv33_x6_kernel(const f2g_conv32_desc
     const bool more = nxt < ntiles;
     f32x4 pf[NQ];
     load_patch(more ? nxt : tile, pf);            // (the last tile re-requests its own: never stored)
+    const int sq = tile / tiles_h, h0 = (tile - sq * tiles_h) * R;
+    const long long ybase = (long long)sq * d.y_seq + (long long)h0 * d.y_line;
+    // data-gradient role: the leaky-ReLU backward mask of the layer below, requested before the MFMAs
+    float my[16];
+    if (d.mask_src) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int p = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const int r = fast_div(p, W, mgW), c = p - r * W;
+        my[e] = (p < tpx && h0 + r < d.H) ? d.mask_src[ybase + (long long)r * d.y_line + c * C + li] : 1.f;
+      }
+    }
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -754,8 +781,7 @@ __global__ __launch_bounds__(512, 1) void conv33_x6_kernel(const f2g_conv32_desc
     for (int t = 0; t < T33; ++t)
       tap6(Ap + ((t / 3 - 1) * PW + (t % 3 - 1)) * PB, Bp + t * (C * PB), acc0, acc1);
     {
-      const int sq = tile / tiles_h, h0 = (tile - sq * tiles_h) * R;
-      float* ys = d.y + (long long)sq * d.y_seq + (long long)h0 * d.y_line;
+      float* ys = d.y + ybase;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int p = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
@@ -763,6 +789,8 @@ __global__ __launch_bounds__(512, 1) void conv33_x6_kernel(const f2g_conv32_desc
         if (p < tpx && h0 + r < d.H) {
           float v = acc0[e] + acc1[e] + bias;
           if (d.lrelu_slope != 0.f) v = v > 0.f ? v : d.lrelu_slope * v;
+          if (d.mask_src) v *= my[e] > 0.f ? 1.f : d.mask_slope;
+          cs += v;
           ys[(long long)r * d.y_line + c * C + li] = v;
         }
       }
@@ -770,6 +798,10 @@ __global__ __launch_bounds__(512, 1) void conv33_x6_kernel(const f2g_conv32_desc
     __syncthreads();                               // every wave is done with this patch
     if (more) store_patch(pf);
     __syncthreads();
+  }
+  if (d.colsum) {
+    cs += __shfl_xor(cs, 32);
+    if (hh == 0) atomicAdd(d.colsum + li, cs);
   }
 }
 
@@ -873,8 +905,7 @@ int f2g_conv32_wgrad6_launch(const f2g_conv32_desc* d, float* gw, hipStream_t st
 
 // Conv2d(32, 32, (3, 3), padding (1, 1)) + bias + leaky ReLU, fp32 class (include/flow2gan_hip.h)
 extern "C" int f2g_conv33_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
-  if (!d || !d->x || !d->w || !d->y || d->precision != 3 || d->Win != d->Wout || d->mask_src || d->colsum)
-    return F2G_EINVAL;
+  if (!d || !d->x || !d->w || !d->y || d->precision != 3 || d->Win != d->Wout || d->fm_ref) return F2G_EINVAL;
   if ((((uintptr_t)d->x) & 15) || (((uintptr_t)d->w) & 15) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
   if (d->S <= 0 || d->H <= 0 || d->Win <= 0) return F2G_OK;
   const int W = d->Win;

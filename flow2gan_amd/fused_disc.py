@@ -419,6 +419,9 @@ FUSE_LRELU = int(_os.environ.get("F2G_FUSE_LRELU", "0"))
 # the five frequency bands of a resolution as nested launch lanes (their conv stacks are independent
 # until conv_post; the narrow bands' launches fill a fraction of the chip): 0 = one after the other
 BAND_LANES = _os.environ.get("F2G_BAND_LANES", "0") != "0"
+# D-step of the MRD on the direct fp32-class kernels: leaky-ReLU backward mask + bias-gradient sums fused into
+# the data gradients (conv32x6.hip requests a tile's mask before its MFMAs); 0 = the separate passes
+MRD_FUSE_MASK = _os.environ.get("F2G_MRD_FUSE_MASK", "1") != "0"
 
 
 def _band_edges(n_fft: int):
@@ -530,8 +533,8 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
                             mask=mask, fm=fm, colsum=colsum)
         return gx
     if (DIRECT_CONV32 and ops.GEMM_PRECISION == 3 and ops.CONV33_X6 and Cin == MRD_CH and Cout == MRD_CH
-            and kh == 3 and kw == 3 and sw == 1 and x_line is None and x_off == 0 and mask is None
-            and colsum is None and Win <= ops.CONV33_MAX_W):
+            and kh == 3 and kw == 3 and sw == 1 and x_line is None and x_off == 0 and fm is None
+            and Win <= ops.CONV33_MAX_W):
         # stride 1: the data gradient is the forward kernel over the gradient map with the taps flipped and
         # the channel matrix transposed, [ci][8 - tap][co]
         def build_f(t):
@@ -539,7 +542,8 @@ def _conv2d_dgrad(g_pre, S, H, Wout, Cout, w, sw, Win, gx, *, g_line=None, g_seq
             ops.permute4(out, t, (Cin, kh * kw, Cout, 1), (kh * kw, -1, Cin * kh * kw, 0), in_offset=kh * kw - 1)
             return out
         wf = ops.derived(w, "dgrad33", build_f)
-        ops.conv33(g_pre, S, H, Win, wf, None, 0.0, gx, x_off=g_off, x_line=g_line, x_seq=g_seq, form=1)
+        ops.conv33(g_pre, S, H, Win, wf, None, 0.0, gx, x_off=g_off, x_line=g_line, x_seq=g_seq, form=1,
+                   mask=mask, colsum=colsum)
         return gx
     if x_line is None:
         x_line = Win * Cin
@@ -736,7 +740,12 @@ class MRDLossFn(torch.autograd.Function):
                         mk = (yb, soff * Ft * Win * C, SLOPE)
                         fmk = (yb, 0, 1.0 / nb_, g1) if ((not train_disc) and l - 1 >= 1) else None
                         gx = ops.empty(Sx * Ft * Win, Cin, device=dev)
-                        if FUSE_LRELU & 2:
+                        # (round 5) D-step on the direct fp32-class kernels: their data gradients request the
+                        # mask of a tile BEFORE its MFMAs, so the fused leaky-ReLU backward (+ bias-gradient
+                        # column sums) costs no exposed round trip and saves a pass over the map
+                        fuse_d = (train_disc and MRD_FUSE_MASK and DIRECT_CONV32 and ops.GEMM_PRECISION == 3
+                                  and ops.CONV32_X6 and (l < 4 or (ops.CONV33_X6 and Win <= ops.CONV33_MAX_W)))
+                        if (FUSE_LRELU & 2) or fuse_d:
                             _conv2d_dgrad(dy_t, Sx, Ft, Wout, C, w, sw, Win, gx, g_line=dy_line,
                                           g_seq=dy_seq, g_off=dy_off, mask=mk, fm=fmk,
                                           colsum=gbs[l - 1])

@@ -657,7 +657,7 @@ CONV33_MAX_W = 112     # one image row + its border must fit the kernel's 352 st
 
 
 def conv33(x, S: int, H: int, W: int, w_packed, bias, slope: float, y, x_off: int = 0, x_line=None, x_seq=None,
-           y_off: int = 0, y_line=None, y_seq=None, form: int = 0):
+           y_off: int = 0, y_line=None, y_seq=None, form: int = 0, mask=None, colsum=None):
     """Conv2d(32, 32, (3, 3), padding (1, 1)) (+ bias + leaky ReLU) on channels-last images, fp32 class
     (conv32x6.hip: conv33_x6_kernel): x (S, H, W, 32) -> y (S, H, W, 32), both optionally strided slices of
     wider maps (floats); w_packed = (32, 9*32) [co][tap][ci] -- for the data gradient the caller passes the
@@ -674,6 +674,10 @@ def conv33(x, S: int, H: int, W: int, w_packed, bias, slope: float, y, x_off: in
     d.y = ptr(y) + 4 * y_off
     d.y_line = y_line if y_line is not None else W * 32
     d.y_seq = y_seq if y_seq is not None else H * d.y_line
+    if mask is not None:      # (data-gradient role) leaky-ReLU backward of the layer below fused into the store
+        d.mask_src = ptr(mask[0]) + 4 * mask[1]
+        d.mask_slope = float(mask[2])
+    d.colsum = ptr(colsum)
     if GEMM_TIMER is not None:
         GEMM_TIMER.time(lambda: call("f2g_conv33_fwd", C.byref(d)),
                         2.0 * S * H * W * 32 * 9 * 32, (form, S * H * W, 32, 9 * 32))

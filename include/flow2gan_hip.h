@@ -561,7 +561,9 @@ int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stream_t stream
  * == W <= 112; the forward writes its band's slice of the concatenated map), w = the f2g_split_bf16x3 image of the
  * packed (32, 9*32) matrix [co][tap][ci], + bias + leaky ReLU.  The DATA GRADIENT of this layer is the same
  * call over the gradient map with w = the image of [ci][8 - tap][co] (taps flipped, channel matrix
- * transposed) and no bias / slope.  mask_src / colsum must be NULL. */
+ * transposed) and no bias / slope; there mask_src (+ mask_slope) / colsum apply the leaky-ReLU backward of
+ * the layer below and leave the column sums of the stored gradient as in f2g_conv32_s2_dgrad (fm_ref must
+ * be NULL). */
 int f2g_conv33_fwd(const f2g_conv32_desc* d, f2g_stream_t stream);
 
 /* First layer of every MRD band stack, Conv2d(2, 32, (3, 9), stride 1, padding (1, 4))

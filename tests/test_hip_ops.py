@@ -1100,6 +1100,16 @@ def test_direct_conv33_fp32_class(ops, S, H, W):
         gx = torch.full((S * H * W, 32), 7.0, device=DEV)
         fd._conv2d_dgrad(g(gcat), S, H, W, 32, wd, 1, W, gx, g_line=Wcat * 32, g_seq=H * Wcat * 32, g_off=foff * 32)
         close(gx.cpu().double(), gref, rtol=2e-5, name="conv33 data gradient")
+        # the same with the leaky-ReLU backward of the layer below and the bias-gradient column sums fused
+        yact = rnd(S * H * W, 32, seed=5)
+        yact = torch.where(yact > 0, yact, 0.1 * yact)
+        gm = torch.full((S * H * W, 32), 7.0, device=DEV)
+        cs = torch.zeros(32, device=DEV)
+        fd._conv2d_dgrad(g(gcat), S, H, W, 32, wd, 1, W, gm, g_line=Wcat * 32, g_seq=H * Wcat * 32, g_off=foff * 32,
+                         mask=(g(yact), 0, 0.1), colsum=cs)
+        want_m = gref * torch.where(yact > 0, 1.0, 0.1).double()
+        close(gm.cpu().double(), want_m, rtol=2e-5, name="conv33 masked data gradient")
+        close(cs.cpu().double(), want_m.sum(0), rtol=1e-4, name="conv33 column sums")
     finally:
         ops.GEMM_PRECISION = was
 
