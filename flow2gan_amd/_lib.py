@@ -195,6 +195,8 @@ _SIGS = {
     "f2g_period_fold": [_P, _P, _I, _I, _I, _I],
     "f2g_period_fold_bwd": [_P, _P, _I, _I, _I, _I, _I],
     "f2g_fill": [_P, _F, _L],
+    "f2g_bucket_arm": [_P, _L, C.c_int32],
+    "f2g_scale": [_P, _F, _L],
     "f2g_log_clip": [_P, _L, _F],
     "f2g_conv32_s2_fwd": [C.POINTER(Conv32Desc)],
     "f2g_conv32_s2_dgrad": [C.POINTER(Conv32Desc)],

@@ -16,12 +16,6 @@
 
 #include "common.h"
 
-// lab builds (tools/micro/conv32x6_lab.sh; results are garbage by construction, only timing means
-// something): F2G_LABVAR bits 1 no weight loads, 2 no patch prefetch / split / store, 4 no barriers in the
-// tap-group loop, 8 fragments read once per tile, 16 no MFMAs
-#ifndef F2G_LABVAR
-#define F2G_LABVAR 0
-#endif
 
 namespace {
 
@@ -77,30 +71,17 @@ struct frag6 {
   bf16x8 v[2][3];
 };
 __device__ __forceinline__ void ld6(frag6& f, const unsigned char* p) {
-#if F2G_LABVAR & 8
-  p = (const unsigned char*)((uintptr_t)p & ~(uintptr_t)0xffff);
-#endif
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int q = 0; q < 3; ++q) f.v[ks][q] = *reinterpret_cast<const bf16x8*>(p + q * 64 + ks * 32);
 }
 __device__ __forceinline__ void mm6(const frag6& a, const frag6& b, f32x16& acc0, f32x16& acc1) {
-#if F2G_LABVAR & 16
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      acc0[q] += (float)a.v[ks][q][0] + (float)b.v[ks][q][1];
-      acc1[q] += (float)a.v[ks][q][2] + (float)b.v[ks][q][3];
-    }
-#else
 #define F2G_X6_PAIR(I, J)                                                               \
   acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[0][I], b.v[0][J], acc0, 0, 0, 0);   \
   acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[1][I], b.v[1][J], acc1, 0, 0, 0);
   F2G_X6_PAIR(2, 0) F2G_X6_PAIR(1, 1) F2G_X6_PAIR(0, 2) F2G_X6_PAIR(1, 0) F2G_X6_PAIR(0, 1) F2G_X6_PAIR(0, 0)
 #undef F2G_X6_PAIR
-#endif
 }
 __device__ __forceinline__ void tap6(const unsigned char* Ab, const unsigned char* Bb, f32x16& acc0, f32x16& acc1) {
   frag6 a, b;
@@ -243,19 +224,13 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_fwd6_kernel(const f2g_conv32
     const int nxt = tile + gridDim.x;
     const bool more = nxt < ntiles;
     f32x4 pf[NCHK];
-#if !(F2G_LABVAR & 2)
     load_patch(more ? nxt : tile, pf);          // (the last tile re-requests its own: never stored)
-#endif
     f32x16 acc0, acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-#if F2G_LABVAR & 1
-      wn[0] = wn[1] = wn[2] = u32x4{0u, 0u, 0u, 0u};
-#else
       load_w(g + 1 < NG ? g + 1 : 0, wn);       // next group (group 0 of the next tile after the last)
-#endif
       const int buf = g & 1;
 #pragma unroll
       for (int u2 = 0; u2 < 2; ++u2) {
@@ -265,9 +240,7 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_fwd6_kernel(const f2g_conv32
           tap6(Ap + (half ? F2G_C6_AOFF(t1) : F2G_C6_AOFF(t0)), Bp + (buf * TG + half * 2 + u2) * WBB, acc0, acc1);
       }
       store_w(buf ^ 1, wn);
-#if !(F2G_LABVAR & 4)
       __syncthreads();
-#endif
     }
 #undef F2G_C6_AOFF
     // the halves' partial tiles meet; the next patch goes to LDS (every wave is done with this one)
@@ -277,9 +250,7 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_fwd6_kernel(const f2g_conv32
 #pragma unroll
       for (int e = 0; e < 16; ++e) red[(pg * 16 + e) * 64 + lane] = acc0[e];
     }
-#if !(F2G_LABVAR & 2)
     if (more) store_patch(pf);
-#endif
     __syncthreads();
     if (half == 0) {
       int sq, h0, w0;

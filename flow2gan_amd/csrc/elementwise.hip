@@ -49,6 +49,21 @@ __global__ __launch_bounds__(256) void fill_kernel(float* x, float v, long long 
     x[i] = v;
 }
 
+// gradient-exchange arenas (dist.py): [n gradients | nflags "used" flags]
+__global__ __launch_bounds__(256) void bucket_arm_kernel(float4* x, long long n4, float* tail, int ntail,
+                                                         float* flags, int nflags) {
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = i0; i < n4; i += (long long)gridDim.x * blockDim.x) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i0 < ntail) tail[i0] = 0.f;
+  for (long long i = i0; i < nflags; i += (long long)gridDim.x * blockDim.x) flags[i] = 1.f;
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* x, float s, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    x[i] *= s;
+}
+
 __global__ __launch_bounds__(256) void silu_kernel(float* y, const float* x, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -557,6 +572,22 @@ extern "C" int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream) {
   if (n <= 0) return F2G_OK;
   hipLaunchKernelGGL(fill_kernel, dim3(f2g_grid_for(n, 256)), dim3(256), 0, ST, x, v,
                      (long long)n);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_bucket_arm(float* flat, int64_t n, int32_t nflags, f2g_stream_t stream) {
+  if (!flat || n < 0 || nflags < 0 || (((uintptr_t)flat) & 15)) return F2G_EINVAL;
+  if (n + nflags == 0) return F2G_OK;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(bucket_arm_kernel, dim3(f2g_grid_for(n4 > nflags ? n4 : nflags, 256)), dim3(256), 0, ST,
+                     reinterpret_cast<float4*>(flat), n4, flat + 4 * n4, (int)(n - 4 * n4), flat + n, nflags);
+  return f2g_check_launch();
+}
+
+extern "C" int f2g_scale(float* x, float s, int64_t n, f2g_stream_t stream) {
+  if (!x) return F2G_EINVAL;
+  if (n <= 0) return F2G_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(f2g_grid_for(n, 256)), dim3(256), 0, ST, x, s, (long long)n);
   return f2g_check_launch();
 }
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import datetime
 import os
+import weakref
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -86,6 +87,7 @@ class GradReducer:
         self.force = force  # run the exchange even with one rank (single-GPU test of the RCCL path)
         self._plans: dict = {}
         self._hooked: set = set()
+        self._handles: list = []       # RemovableHandles of the parameter hooks (close())
         self._active: Optional["_Plan"] = None
         self.measure = False          # bench.py: time the compute stream's wait in finish()
         self.wait_events: list = []
@@ -199,8 +201,22 @@ class GradReducer:
             for p in params:
                 if id(p) not in self._hooked:
                     self._hooked.add(id(p))
-                    p.register_post_accumulate_grad_hook(self._on_grad)
-                    p.register_hook(lambda g, p=p: self._on_real_grad(p, g))
+                    # (weak reference: the hooks must not keep the reducer and its arenas alive as long as
+                    # the model lives; close() removes them)
+                    me = weakref.ref(self)
+
+                    def after_accumulate(q, me=me):
+                        r = me()
+                        if r is not None:
+                            r._on_grad(q)
+
+                    def before_accumulate(g, p=p, me=me):
+                        r = me()
+                        if r is not None:
+                            r._on_real_grad(p, g)
+
+                    self._handles.append(p.register_post_accumulate_grad_hook(after_accumulate))
+                    self._handles.append(p.register_hook(before_accumulate))
         world = get_world_size()
         plan.exchange = world > 1 or (self.force and dist.is_initialized())
         plan.arm()
@@ -229,6 +245,8 @@ class GradReducer:
             # without -- is in plan.real: its hook is a gradient and falls through to the checks.)
             plan.echo.discard(id(p))
             return
+        if not from_sink:
+            plan.echo.discard(id(p))        # (delivered through the sink AND reached by autograd: no echo left behind)
         if b.sent:
             # a second backward() between prepare() and finish() would accumulate into an arena
             # that has already been averaged and would never be exchanged: ranks would diverge
@@ -266,15 +284,22 @@ class GradReducer:
         comm = self._comm_stream(b.flat.device)
 
         def exchange():
-            # the "used" flags behind the gradients (zeroed by arm())
-            if len(b.fired) == len(b.params):
-                b.flat[b.n:].fill_(1.0)
-            elif b.fired:
-                b.flat[b.n:].copy_(torch.tensor([1.0 if id(p) in b.fired else 0.0 for p in b.params],
-                                                dtype=b.flat.dtype))
+            # the "used" flags behind the gradients: arm() left them all at 1 (the common case: every
+            # parameter of the bucket got a gradient -- nothing to launch in front of the collective);
+            # only a partially fired bucket writes its pattern (rare: a branch without gradient)
+            if len(b.fired) != len(b.params):
+                pat = torch.tensor([1.0 if id(p) in b.fired else 0.0 for p in b.params], dtype=b.flat.dtype)
+                if b.flat.is_cuda:
+                    pat = pat.pin_memory()
+                b.flat[b.n:].copy_(pat, non_blocking=True)
+                b.keep = pat                      # (alive until the copy has run)
             dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
             if world > 1:
-                b.flat[:b.n].div_(world)
+                if b.flat.is_cuda:
+                    from . import ops
+                    ops.call("f2g_scale", ops.ptr(b.flat), 1.0 / world, b.n)      # one launch behind the collective
+                else:
+                    b.flat[:b.n].div_(world)
 
         if comm is None:
             exchange()
@@ -327,12 +352,14 @@ class GradReducer:
             self._agree_on_order(plan)
         dev = plan.buckets[0].flat.device if plan.buckets else None
         cuda = dev is not None and dev.type == "cuda" and self._stream is not None
+        synced = False
         for b in plan.buckets:
             if len(b.fired) == len(b.params):
                 continue
             # (rare) some parameter got no gradient on this rank: did any rank use it?
-            if cuda and plan.exchange:
-                self._stream.synchronize()
+            if cuda and plan.exchange and not synced:
+                self._stream.synchronize()         # (once, whatever the number of partial buckets)
+                synced = True
             used = b.flat[b.n:].tolist() if plan.exchange else [0.0] * len(b.params)
             for p, u in zip(b.params, used):
                 if id(p) not in b.fired and u <= 0.0:
@@ -349,6 +376,13 @@ class GradReducer:
             else:
                 torch.cuda.current_stream(dev).wait_stream(self._stream)
         return plan.bytes
+
+    def close(self) -> None:
+        """Remove the parameter hooks and drop the arenas (a second reducer over the same parameters would
+        otherwise stack its hooks on top of these)."""
+        for h in self._handles:
+            h.remove()
+        self._handles, self._hooked, self._plans, self._active = [], set(), {}, None
 
     def exposed_comm_ms(self) -> float:
         """Sum of the measured waits of finish() since the last call (self.measure = True); syncs."""
@@ -458,7 +492,12 @@ class _Plan:
         self.echo = set()
         self.real = set()
         for b in self.buckets:
-            b.flat.zero_()
+            if b.flat.is_cuda:       # gradients = 0, "used" flags = 1: one launch per arena
+                from . import ops
+                ops.call("f2g_bucket_arm", ops.ptr(b.flat), b.n, len(b.params))
+            else:
+                b.flat.zero_()
+                b.flat[b.n:].fill_(1.0)
             b.fired.clear()
             b.streams = {}
             b.ready = False

@@ -469,6 +469,13 @@ int f2g_period_fold_bwd(float* gx, const float* gout, int32_t B, int32_t T, int3
 int f2g_log_clip(float* x, int64_t n, float clip, f2g_stream_t stream);
 /* fill */
 int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
+/* Gradient-exchange arenas of the data-parallel step (reference finetune.py:913-915: DDP with
+ * find_unused_parameters; here flow2gan_amd/dist.py): an arena is [n gradients | nflags "used" flags], summed
+ * over the ranks by ONE all-reduce.  f2g_bucket_arm zeroes the gradients and sets every flag to 1 (one launch
+ * per arena and step: the common case -- every parameter of the bucket got a gradient -- then needs nothing
+ * in front of the collective); f2g_scale is the 1 / world behind it (x *= s). */
+int f2g_bucket_arm(float* flat, int64_t n, int32_t nflags, f2g_stream_t stream);
+int f2g_scale(float* x, float s, int64_t n, f2g_stream_t stream);
 /* Zero padding carried by the data: buf is (nseq, rows_per_seq, C) channels-last, rows [0, lo) and
  * [rows_per_seq - hi, rows_per_seq) of every sequence are set to 0 (C % 4 == 0).  Conv inputs
  * laid out this way (the reference's `padding=` of discriminators.py:65-76 as halo rows) are read

@@ -289,14 +289,17 @@ def test_full_size_batch_64_reproduces_reference_waveform(f2g, golden):
         y = m.infer(mel, None, 4, True, noise=noise.to(DEV).expand(64, -1).contiguous())
     want = T(g["audio_n4"])
     assert y.shape == (64, want.shape[1])
-    worst = max(rms(y[b:b + 1], want) for b in (0, 17, 63))
+    worst = max(rms(y[b:b + 1], want) for b in range(64))
     assert worst < RMS_TOL, worst
     from flow2gan_amd import ops as _ops
     # rows agree with each other (up to the summation order of split tiles; the opt-in split-bf16
     # GEMM mode amplifies those last-bit differences through its 2^-16 products)
     # (bf16x6: the same last-bit differences of the atomically accumulated time-MLP GEMMs, seen through
-    # other roundings: measured 1.6e-5)
-    assert float((y - y[:1]).abs().max()) < {1: 5e-5, 3: 3e-5}.get(_ops.GEMM_PRECISION, 1e-5)
+    # other roundings -- a one-ulp change of an operand re-draws the error of its six-product sum (<= 2^-23
+    # of the product, against 2^-24 per fp32 add), so rows that differ in last bits drift apart ~3x faster
+    # than on the exact fp32 MFMA: 1.6e-5 with the K >= 2048 GEMMs in this mode (round 4), 3.8e-5 with every
+    # GEMM from K = 384 on (round 5).  Every row stays within the 1e-4 RMS of the reference waveform above.)
+    assert float((y - y[:1]).abs().max()) < {1: 5e-5, 3: 6e-5}.get(_ops.GEMM_PRECISION, 1e-5)
 
 
 def test_full_width_stage1_loss_and_grads_vs_oracle_then_batch_64(f2g, monkeypatch):
