@@ -223,7 +223,7 @@ _SIGS = {
     "f2g_split_bf16x3": [_P, _P, _L, _I, _I],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
-                                 "f2g_gemm_lean_ok", "f2g_fused_mlp_ok",
+                                 "f2g_gemm_lean_ok", "f2g_gemm_wgrad_lean", "f2g_fused_mlp_ok",
                                  "f2g_dwnorm_bwd_workspace", "f2g_split_bf16x3_bytes", "f2g_gemm_x6_ok",
                                  "f2g_dwconv_bwd_workspace", "f2g_sadam_chunk_elems"])
 
@@ -248,6 +248,8 @@ def _load():
         fn.restype = C.c_int64
     lib.f2g_gemm_lean_ok.argtypes = [C.POINTER(GemmDesc)]
     lib.f2g_gemm_lean_ok.restype = C.c_int
+    lib.f2g_gemm_wgrad_lean.argtypes = [C.POINTER(GemmDesc)]
+    lib.f2g_gemm_wgrad_lean.restype = C.c_int
     lib.f2g_split_bf16x3_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.f2g_split_bf16x3_bytes.restype = C.c_int64
     lib.f2g_gemm_x6_ok.argtypes = [C.POINTER(GemmDesc)]

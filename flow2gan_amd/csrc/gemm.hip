@@ -2447,6 +2447,20 @@ inline bool leanw_ok(const f2g_gemm_desc& d) {
   return (long long)(B.rows / B.P0) * B.seq_stride * 4 < 0x7ff00000ll;
 }
 
+// exact fp32 weight gradient (form 2, both operands fp32): the K-major lean kernel where its shape conditions
+// hold and every block walks a long reduction (>= 4096 rows: the MPD weight gradients, 115 -> 125-131
+// TFLOP/s, step 254.5 -> 252.6 ms; on the generator's 6016-row weight gradients the generic kernel's 8 waves
+// hide the short K loops better: 92 vs 83).  F2G_LEAN_WGRAD: 0 off, 1 auto (default), 2 always.  ONE rule for
+// f2g_gemm's dispatch and for the host's query (f2g_gemm_wgrad_lean).
+inline bool leanw_fp32_takes(const f2g_gemm_desc& d, int split) {
+  static const int leanw_mode = (getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) ? 0
+                                : (getenv("F2G_LEAN_WGRAD") ? atoi(getenv("F2G_LEAN_WGRAD")) : 1);
+  if (d.form != 2 || d.A.split || d.B.split || split < 1) return false;
+  // (its scalar row walk assumes that a slab crosses at most two sequence ends)
+  return leanw_mode > 0 && d.precision == 0 && d.E.atomic && leanw_ok(d) &&
+         (host_plain(d.B) || d.B.P0 >= 16) && (leanw_mode > 1 || d.A.rows / split >= 4096);
+}
+
 int launch_leanw(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
   constexpr size_t smem = 2 * 2 * 32 * 128 * sizeof(float);
   int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
@@ -3316,6 +3330,13 @@ extern "C" int f2g_gemm_last_path(void) { return g_last_path; }
 
 // Would f2g_gemm run this form-0 descriptor on the lean kernel (whatever its precision)?  The host
 // asks before it pre-splits the operands of a split-bf16 GEMM.
+// 1 if f2g_gemm would run this form-2 descriptor (exact fp32, E.atomic, split_k as set) on the K-major lean
+// weight-gradient kernel -- two blocks per CU, so the host deals its blocks in rounds of 512 (ops.split_for)
+extern "C" int f2g_gemm_wgrad_lean(const f2g_gemm_desc* dp) {
+  if (!dp || !dp->A.base || !dp->B.base) return 0;
+  return leanw_fp32_takes(*dp, dp->split_k < 1 ? 1 : dp->split_k) ? 1 : 0;
+}
+
 extern "C" int f2g_gemm_lean_ok(const f2g_gemm_desc* dp) {
   if (!dp || !dp->A.base || !dp->B.base) return 0;
   static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
@@ -3491,17 +3512,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
       if (!(d.precision == 1 && d.A.split && d.B.split && lean_on && leanw_ok(d))) return F2G_EINVAL;
       return launch_leanw3(d, M, N, K, split, st);
     }
-    {   // exact fp32: the K-major lean kernel where its shape conditions hold and every block walks
-      // a long reduction (>= 4096 rows: the MPD weight gradients, 115 -> 125-131 TFLOP/s, step
-      // 254.5 -> 252.6 ms; on the generator's 6016-row weight gradients the generic kernel's 8 waves
-      // hide the short K loops better: 92 vs 83).  F2G_LEAN_WGRAD: 0 off, 1 auto (default), 2 always.
-      static const int leanw_mode = (getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) ? 0
-                                    : (getenv("F2G_LEAN_WGRAD") ? atoi(getenv("F2G_LEAN_WGRAD")) : 1);
-      // (its scalar row walk assumes that a slab crosses at most two sequence ends)
-      if (leanw_mode > 0 && d.precision == 0 && d.E.atomic && leanw_ok(d) &&
-          (host_plain(d.B) || d.B.P0 >= 16) && (leanw_mode > 1 || K / split >= 4096))
-        return launch_leanw(d, M, N, K, split, st);
-    }
+    if (leanw_fp32_takes(d, split)) return launch_leanw(d, M, N, K, split, st);
     int am = op_mode(d.A, false), bm = op_mode(d.B, false);
     // split-K chunks are multiples of BK, so PF only needs the total extent % BK == 0
     if (am == PF && bm == PF) return dispatch_tile<true, true, PF, PF>(d, M, N, K, split, st);

@@ -298,9 +298,11 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
         # (>= 4096 rows per block with the general rule's factor), its blocks are dealt in rounds of 512
         tiles = ((A.cols + 127) // 128) * ((Bm.cols + 127) // 128)
         split_k = split_for(A.rows, tiles)
-        if (WGRAD_SPLIT512 and form == 2 and GEMM_PRECISION == 0 and atomic and A.rows // split_k >= 4096
-                and ((Bm.P0 == 1 and Bm.P1 == 1) or Bm.P0 >= 16) and L.lib.f2g_gemm_lean_ok(C.byref(d))):
-            split_k = split_for(A.rows, tiles, True)
+        if WGRAD_SPLIT512 and form == 2 and GEMM_PRECISION == 0 and atomic:
+            # (the library's own dispatch rule, asked with the descriptor as it would be launched)
+            d.split_k, d.precision = split_k, 0
+            if L.lib.f2g_gemm_wgrad_lean(C.byref(d)):
+                split_k = split_for(A.rows, tiles, True)
     d.split_k = split_k
     d.precision = GEMM_PRECISION
     if GEMM_PRECISION == 3:

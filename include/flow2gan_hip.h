@@ -156,6 +156,10 @@ typedef struct {
 } f2g_gemm_desc;
 
 int f2g_gemm(const f2g_gemm_desc* d, f2g_stream_t stream);
+/* 1 if f2g_gemm would run this form-2 (weight-gradient) descriptor -- precision 0, E.atomic, split_k as set --
+ * on the K-major lean kernel (two blocks per CU): the same rule as the dispatch itself, so that the host can
+ * choose its split factor for that kernel's rounds of 512 blocks without restating the conditions. */
+int f2g_gemm_wgrad_lean(const f2g_gemm_desc* d);
 /* 1 if f2g_gemm would run this form-0 descriptor on the lean kernel (buffer loads, no VALU in the K
  * loop), whatever its precision: the host asks before pre-splitting the operands of a precision-1
  * GEMM.  Form 2: 1 if the split-bf16 weight-gradient kernel (K-major operands transposed by

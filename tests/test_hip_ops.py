@@ -1060,6 +1060,7 @@ def test_direct_conv32_fp32_class(ops, S, H, Win):
                                            (want_m, "masked data gradient", 2e-5),
                                            (want_w, "weight gradient", 1e-4))):
         close(out["bf16x6"][i], want, rtol=tol, name=f"conv32 fp32-class {name}")
+        close(out["fp32"][i], want, rtol=tol, name=f"conv32 exact fp32 {name}")     # (not only the yardstick below)
         e6 = float((out["bf16x6"][i] - want).abs().max())
         e0 = float((out["fp32"][i] - want).abs().max())
         assert e6 <= 3.0 * e0 + 1e-7 * float(want.abs().max()), (name, e6, e0)
@@ -1114,10 +1115,13 @@ def test_direct_conv33_fp32_class(ops, S, H, W):
         ops.GEMM_PRECISION = was
 
 
-@pytest.mark.parametrize("S,H,W,lo,Wtot", [(2, 11, 34, 7, 50), (3, 8, 32, 0, 32), (1, 5, 3, 2, 9), (2, 21, 77, 10, 100)])
+@pytest.mark.parametrize("S,H,W,lo,Wtot", [(2, 11, 34, 7, 50), (3, 8, 32, 0, 32), (1, 5, 3, 2, 9), (2, 21, 77, 10, 100),
+                                           (300, 40, 64, 3, 70)])
 def test_conv2ch_direct_kernels_match_autograd(ops, S, H, W, lo, Wtot):
     """conv2ch.hip (first MRD layer, 2 -> 32 channels on a band of the interleaved spectrogram):
-    forward, weight gradient and data gradient against torch conv2d + autograd in fp64."""
+    forward, weight gradient and data gradient against torch conv2d + autograd in fp64.  The last case has
+    600 column tiles x sequences (the persistent forward walking down its rows with prefetched patches) and
+    3000 tiles for the weight gradient (more than one tile per block: the prefetching tile walk)."""
     ld = ops.pad4(2 * Wtot)
     spec = torch.zeros(S * H, ld)
     spec[:, :2 * Wtot] = rnd(S * H, 2 * Wtot, seed=1)
@@ -1169,9 +1173,12 @@ def test_convpost_direct_kernels_match_autograd(ops, S, H, W):
     close(gx, x.grad.permute(0, 2, 3, 1).reshape(S * H * W, 32), name="convpost dgrad")
 
 
-@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (5, 17, 26)])
+@pytest.mark.parametrize("S,H,Win", [(3, 11, 13), (2, 8, 64), (2, 21, 51), (1, 5, 2), (5, 17, 26), (40, 47, 77),
+                                     (64, 94, 19)])
 def test_direct_conv32_wgrad_matches_autograd(ops, S, H, Win):
-    """conv32.hip weight gradient (direct, taps spread over the waves) vs torch autograd in fp64."""
+    """conv32.hip weight gradient (direct, taps spread over the waves) vs torch autograd in fp64.  The last
+    two cases have 720 / 768 tiles -- more than the 256 blocks of the double-buffered kernel
+    (conv32_s2_wgrad_p_kernel: the next tile staged behind the current tile's MFMAs), one per tile shape."""
     Wout = (Win - 1) // 2 + 1
     xr, gy = rnd(S * H * Win, 32, seed=1), rnd(S * H * Wout, 32, seed=4)
     w = rnd(32, 32, 3, 9, seed=2, scale=0.05).double().requires_grad_(True)
