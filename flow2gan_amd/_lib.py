@@ -122,7 +122,8 @@ class Mpd0Desc(C.Structure):  # == f2g_mpd0_desc
 class MpdPostDesc(C.Structure):  # == f2g_mpdpost_desc
     _fields_ = [("y", C.c_void_p), ("S", C.c_int32), ("H", C.c_int32), ("halo", C.c_int32),
                 ("_pad", C.c_int32), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
-                ("g", C.c_void_p)]
+                ("g", C.c_void_p), ("mask_src", C.c_void_p), ("fm_ref", C.c_void_p), ("fm_wdev", C.c_void_p),
+                ("mask_slope", C.c_float), ("fm_w", C.c_float), ("colsum", C.c_void_p), ("x3_out", C.c_void_p)]
 
 
 class FusedMlpDesc(C.Structure):  # == f2g_fused_mlp_desc

@@ -175,22 +175,77 @@ __global__ __launch_bounds__(256) void mpdpost_fwd_kernel(const f2g_mpdpost_desc
 }
 
 // gy[s, halo + h, :] = g[s, h+1] w[0] + g[s, h] w[1] + g[s, h-1] w[2]   (rows 0..H-1; halo rows untouched)
-__global__ __launch_bounds__(256) void mpdpost_dgrad_kernel(const f2g_mpdpost_desc d) {
+// Round 5: optionally the leaky-ReLU backward of the 1024-channel layer the gradient lands on (mask_src = that
+// layer's output, same halo layout; + the feature-matching term against fm_ref), the column sums of the result
+// (that layer's bias gradient) and the result's three-piece image for the fp32-class data gradient that reads
+// it next -- the separate pass over the map (read g, read y, write g) and the image pass (read g, write 6
+// bytes per element) both read what this kernel has in registers.
+__device__ __forceinline__ void split3_4(const float (&x)[4], uint2& p0, uint2& p1, uint2& p2) {
+  unsigned short q[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 a = (__bf16)x[e];
+    const float r1 = x[e] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    q[0][e] = __builtin_bit_cast(unsigned short, a);
+    q[1][e] = __builtin_bit_cast(unsigned short, b);
+    q[2][e] = __builtin_bit_cast(unsigned short, c);
+  }
+  p0 = make_uint2(q[0][0] | ((unsigned)q[0][1] << 16), q[0][2] | ((unsigned)q[0][3] << 16));
+  p1 = make_uint2(q[1][0] | ((unsigned)q[1][1] << 16), q[1][2] | ((unsigned)q[1][3] << 16));
+  p2 = make_uint2(q[2][0] | ((unsigned)q[2][1] << 16), q[2][2] | ((unsigned)q[2][3] << 16));
+}
+
+__global__ __launch_bounds__(256) void mpdpost_dgrad_kernel(const f2g_mpdpost_desc d, int rows_per) {
   const int t = threadIdx.x;
   const float4 w0 = reinterpret_cast<const float4*>(d.w)[t], w1 = reinterpret_cast<const float4*>(d.w + CP)[t],
                w2 = reinterpret_cast<const float4*>(d.w + 2 * CP)[t];
   const long long R = (long long)d.S * d.H;
   const int Hp = d.H + 2 * d.halo;
-  for (long long r = blockIdx.x; r < R; r += gridDim.x) {
+  const float fmw = d.fm_ref ? d.fm_w * (d.fm_wdev ? d.fm_wdev[0] : 1.f) : 0.f;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  long long r = (long long)blockIdx.x * rows_per;
+  const long long rend = r + rows_per < R ? r + rows_per : R;
+  for (; r < rend; ++r) {
     const int s = (int)(r / d.H), h = (int)(r - (long long)s * d.H);
     const float* g = d.g + (long long)s * d.H;
     const float ga = h + 1 < d.H ? g[h + 1] : 0.f, gb = g[h], gc = h > 0 ? g[h - 1] : 0.f;
-    float4 o;
-    o.x = ga * w0.x + gb * w1.x + gc * w2.x;
-    o.y = ga * w0.y + gb * w1.y + gc * w2.y;
-    o.z = ga * w0.z + gb * w1.z + gc * w2.z;
-    o.w = ga * w0.w + gb * w1.w + gc * w2.w;
-    reinterpret_cast<float4*>(d.y + ((long long)s * Hp + d.halo + h) * CP)[t] = o;
+    float o[4];
+    o[0] = ga * w0.x + gb * w1.x + gc * w2.x;
+    o[1] = ga * w0.y + gb * w1.y + gc * w2.y;
+    o[2] = ga * w0.z + gb * w1.z + gc * w2.z;
+    o[3] = ga * w0.w + gb * w1.w + gc * w2.w;
+    const long long off = ((long long)s * Hp + d.halo + h) * CP + 4 * t;
+    if (d.mask_src) {
+      const float4 yv = *reinterpret_cast<const float4*>(d.mask_src + off);
+      const float y[4] = {yv.x, yv.y, yv.z, yv.w};
+      if (d.fm_ref) {
+        const float4 fv = *reinterpret_cast<const float4*>(d.fm_ref + off);
+        const float f[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dl = y[e] - f[e];
+          o[e] += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] *= y[e] > 0.f ? 1.f : d.mask_slope;
+    }
+    cs.x += o[0]; cs.y += o[1]; cs.z += o[2]; cs.w += o[3];
+    *reinterpret_cast<float4*>(d.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    if (d.x3_out) {
+      uint2 p0, p1, p2;
+      split3_4(o, p0, p1, p2);
+      __bf16* q = reinterpret_cast<__bf16*>(d.x3_out) + (off >> 5) * 96 + (off & 31);
+      *reinterpret_cast<uint2*>(q) = p0;
+      *reinterpret_cast<uint2*>(q + 32) = p1;
+      *reinterpret_cast<uint2*>(q + 64) = p2;
+    }
+  }
+  if (d.colsum) {
+    float* c = d.colsum + 4 * t;
+    atomicAdd(c + 0, cs.x); atomicAdd(c + 1, cs.y); atomicAdd(c + 2, cs.z); atomicAdd(c + 3, cs.w);
   }
 }
 
@@ -288,9 +343,15 @@ extern "C" int f2g_mpdpost_dgrad(const f2g_mpdpost_desc* d, f2g_stream_t stream)
   if (!d || !d->y || !d->w || !d->g || d->H <= 0 || (((uintptr_t)d->y) & 15) || (((uintptr_t)d->w) & 15))
     return F2G_EINVAL;
   if (d->S <= 0) return F2G_OK;
-  long long b = (long long)d->S * d->H;
-  if (b > 256 * 16) b = 256 * 16;
-  hipLaunchKernelGGL(mpdpost_dgrad_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, *d);
+  if ((d->mask_src && (((uintptr_t)d->mask_src) & 15)) || (d->fm_ref && ((((uintptr_t)d->fm_ref) & 15) || !d->mask_src)) ||
+      (d->x3_out && (((uintptr_t)d->x3_out) & 7)))
+    return F2G_EINVAL;
+  const long long R = (long long)d->S * d->H;
+  // <= 2048 blocks over contiguous row ranges (with column sums: 1024 atomics per block)
+  long long per = (R + 2047) / 2048;
+  if (per < 1) per = 1;
+  hipLaunchKernelGGL(mpdpost_dgrad_kernel, dim3((unsigned)((R + per - 1) / per)), dim3(256), 0, (hipStream_t)stream,
+                     *d, (int)per);
   return f2g_check_launch();
 }
 

@@ -319,13 +319,18 @@ class MPDLossFn(torch.autograd.Function):
                 return gm
 
             def post_dgrad(mk, fk, ck):
-                if mk is None and ops.MPD0_DIRECT and y5.shape[1] == 1024:
-                    gy5 = _halo_rows(Sx, H5, 1024, dev)
+                if ops.MPD0_DIRECT and y5.shape[1] == 1024 and (mk is None or MPDPOST_FUSE):
+                    # (round 5) the stream kernel applies the mask / feature-matching term / bias sums itself and
+                    # leaves the image the fp32-class data gradient of the 1024-channel layer reads next
+                    gy5 = _halo_rows(Sx, H5, 1024, dev, x3=mk is not None)
                     return ops.mpdpost_dgrad(gs, Sx, H5, HALO, ops.derived(wpost, "pack", pack_conv_weight),
-                                             gy5, g_off=roff * H5)
+                                             gy5, g_off=roff * H5, mask=mk, fm=fk, colsum=ck)
                 return _conv1d_dgrad(gs, Sx, H5, 1, wpost, 1, 1, H5, g_off=roff * H5, g_halo=False,
                                      mask=mk, fm=fk, colsum=ck)
-            g = land(None, 5, post_dgrad)
+            if ops.MPD0_DIRECT and y5.shape[1] == 1024 and MPDPOST_FUSE:
+                g = post_dgrad(*below(5))
+            else:
+                g = land(None, 5, post_dgrad)
             for l in reversed(range(5)):
                 w = prm[2 * l]
                 Cin, Cout, stv = MPD_CH[l], MPD_CH[l + 1], MPD_STRIDE[l]
@@ -422,6 +427,9 @@ BAND_LANES = _os.environ.get("F2G_BAND_LANES", "0") != "0"
 # D-step of the MRD on the direct fp32-class kernels: leaky-ReLU backward mask + bias-gradient sums fused into
 # the data gradients (conv32x6.hip requests a tile's mask before its MFMAs); 0 = the separate passes
 MRD_FUSE_MASK = _os.environ.get("F2G_MRD_FUSE_MASK", "1") != "0"
+# conv_post's data gradient (mpd0.hip stream kernel) with the leaky-ReLU backward of the layer below, its bias
+# sums and the result's image fused; 0 = the separate pass over the 1024-channel map
+MPDPOST_FUSE = _os.environ.get("F2G_MPDPOST_FUSE", "1") != "0"
 
 
 def _band_edges(n_fft: int):

@@ -312,6 +312,8 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
                 (Bm.rows >= X6F_MIN_N and ((A.rows + 127) // 128) * ((Bm.rows + 127) // 128) >= X6F_MIN_TILES)
                 or (A.rows >= X6F_TALL_ROWS and Bm.rows >= 128)):
             in_kernel = True      # (mid-length reductions on well-filled grids: see X6F)
+        if X6F == 2 and X6_MIN_K <= A.cols < X6_NOPASS_K and A.P0 == 1 and A.P1 == 1 and not _is_const(A._keep[0]):
+            in_kernel = True      # (a plain activation matrix has no producer-written image: no image pass)
         if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS \
                 and (A.cols >= X6_MIN_K or in_kernel) and not atomic \
                 and split_k <= 1 and out.dtype == torch.float32 and _x3_window_ok(A):
@@ -548,6 +550,9 @@ X6F_MIN_K = int(_os.environ.get("F2G_X6F_MIN_K", "384"))
 X6F_MIN_N = int(_os.environ.get("F2G_X6F_MIN_N", "384"))
 X6F_TALL_ROWS = int(_os.environ.get("F2G_X6F_TALL_ROWS", "65536"))
 X6F_MIN_TILES = int(_os.environ.get("F2G_X6F_MIN_TILES", "180"))
+# long reductions over a PLAIN activation matrix (the generator's K = 2304 GEMMs): below this K the in-kernel
+# split instead of an image pass (f2g_split_bf16x3: 10 bytes per element) in front of the image kernel
+X6_NOPASS_K = int(_os.environ.get("F2G_X6_NOPASS_K", "4096"))
 
 
 def _x3_window_ok(o: Operand) -> bool:
@@ -1464,9 +1469,26 @@ def mpdpost_fwd(y, S, H, halo, w3, bias, out):
     return out
 
 
-def mpdpost_dgrad(g, S, H, halo, w3, gy, g_off=0):
-    """gy (halo layout (S, H + 2*halo, 1024), halo rows pre-zeroed) = data gradient of conv_post."""
-    _timed_hbm("f2g_mpdpost_dgrad", 4.0 * S * H * (1024 + 1), C.byref(_mpdpost_desc(gy, S, H, halo, w3, None, None, g, g_off)))
+def mpdpost_dgrad(g, S, H, halo, w3, gy, g_off=0, mask=None, fm=None, colsum=None):
+    """gy (halo layout (S, H + 2*halo, 1024), halo rows pre-zeroed) = data gradient of conv_post; optionally with
+    the leaky-ReLU backward of the layer it lands on (mask = (activation map, float offset, slope); fm =
+    (reference map, float offset, weight, device scalar)), that layer's bias gradient (colsum) and -- when gy
+    carries x3_reserve storage -- the three-piece image of the result (bf16x6 mode)."""
+    d = _mpdpost_desc(gy, S, H, halo, w3, None, None, g, g_off)
+    nbytes = 4.0 * S * H * (1024 + 1)
+    if mask is not None:
+        d.mask_src, d.mask_slope = ptr(mask[0]) + 4 * mask[1], float(mask[2])
+        nbytes += 4.0 * S * H * 1024
+        if fm is not None:
+            d.fm_ref, d.fm_w, d.fm_wdev = ptr(fm[0]) + 4 * fm[1], float(fm[2]), ptr(fm[3])
+            nbytes += 4.0 * S * H * 1024
+    d.colsum = ptr(colsum)
+    buf = getattr(gy, "_f2g_x3_buf", None)
+    if buf is not None and not getattr(gy, "_f2g_x3_bad", False):
+        d.x3_out = ptr(buf)
+        gy._f2g_x3 = buf
+        nbytes += 6.0 * S * H * 1024
+    _timed_hbm("f2g_mpdpost_dgrad", nbytes, C.byref(d))
     return gy
 
 

@@ -520,6 +520,17 @@ typedef struct {
   const float* bias;
   float* out;
   const float* g;
+  /* dgrad only (all optional): leaky-ReLU backward of the 1024-channel layer the gradient lands on -- with
+   * y5 = mask_src at the output's own offsets, v = (v + fm_w * fm_wdev[0] * sign(y5 - fm_ref)) * (y5 > 0 ? 1 :
+   * mask_slope) (the fm term only with fm_ref) --, colsum[1024] += column sums of the stored gradient (that
+   * layer's bias gradient), x3_out = the f2g_split_bf16x3 flat image of the buffer y points into (f2g_epilogue) */
+  const float* mask_src;
+  const float* fm_ref;
+  const float* fm_wdev;
+  float mask_slope;
+  float fm_w;
+  float* colsum;
+  void* x3_out;
 } f2g_mpdpost_desc;
 int f2g_mpdpost_fwd(const f2g_mpdpost_desc* d, f2g_stream_t stream);
 int f2g_mpdpost_dgrad(const f2g_mpdpost_desc* d, f2g_stream_t stream);

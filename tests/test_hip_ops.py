@@ -582,6 +582,29 @@ def test_mpd_last_layer_direct_kernels(ops, S, H):
     gv = gy.view(S, H + 2 * HALO, Cc)
     close(gv[:, HALO:HALO + H], yd.grad.permute(0, 2, 1), name="mpdpost dgrad")
     assert float(gv[:, :HALO].abs().max()) == 0.0 and float(gv[:, HALO + H:].abs().max()) == 0.0
+    # round 5: the same with the leaky-ReLU backward of the layer it lands on (+ the feature-matching term
+    # against the other half's map), the bias-gradient column sums and the result's three-piece image
+    from flow2gan_amd import fused_disc as fd
+    ref_map = torch.zeros(S, H + 2 * HALO, Cc)
+    ref_map[:, HALO:HALO + H] = rnd(S, H, Cc, seed=6)
+    wdev = torch.tensor([0.7], device=DEV)
+    was = ops.GEMM_PRECISION
+    try:
+        ops.set_gemm_precision("bf16x6")
+        gm = fd._halo_rows(S, H, Cc, DEV, x3=True)
+        cs = torch.zeros(Cc, device=DEV)
+        ops.mpdpost_dgrad(g(gs), S, H, HALO, g(w3), gm, mask=(g(y), 0, 0.1), fm=(g(ref_map), 0, 0.3, wdev), colsum=cs)
+    finally:
+        ops.GEMM_PRECISION = was
+    plain = yd.grad.permute(0, 2, 1)
+    yv, rv = y[:, HALO:HALO + H].double(), ref_map[:, HALO:HALO + H].double()
+    want = (plain + 0.3 * 0.7 * torch.sign(yv - rv)) * torch.where(yv > 0, 1.0, 0.1)
+    gmv = gm.view(S, H + 2 * HALO, Cc)
+    close(gmv[:, HALO:HALO + H], want, name="mpdpost fused dgrad")
+    assert float(gmv[:, :HALO].abs().max()) == 0.0 and float(gmv[:, HALO + H:].abs().max()) == 0.0
+    close(cs, want.sum((0, 1)), rtol=1e-4, name="mpdpost fused column sums")
+    img = getattr(gm, "_f2g_x3", None)
+    assert img is not None and torch.equal(img.view(torch.int16), ops.x3_flat_image(gm).view(torch.int16))
 
 
 @pytest.mark.parametrize("Cin,Cout,kw,sw", [(2, 32, 9, 1), (32, 32, 9, 2), (32, 32, 3, 1), (32, 1, 3, 1)])
