@@ -324,7 +324,7 @@ def main():
                            "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
                            "direct-conv": "conv32 direct kernels (the 32 -> 32 channel MRD band layers)",
                            "lean-streamk": "gemm_lean_kernel (stream-K)",
-                           "x6": "gemm_x6t8 / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
+                           "x6": "gemm_x6p / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
                                  "pieces per operand, six MFMAs per product)",
                            "narrow": "narrow VALU kernels"}.get(dn, dn),
                 # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
