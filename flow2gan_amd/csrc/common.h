@@ -14,6 +14,9 @@ void f2g_set_error(const char* msg);
 // gemm_x6p.hip: ping-pong tap-walking fp32-class GEMM (precision 3 over halo-map images); ok = 1 if taken
 int f2g_x6p_ok(const f2g_gemm_desc& d, int taps);
 int f2g_launch_x6p(const f2g_gemm_desc& d, int taps, long long a_extent, hipStream_t st);
+// tap-walking fp32-class weight gradient of a stride-1 five-tap conv over halo maps (gemm_x6p.hip)
+int f2g_leanw6t_ok(const f2g_gemm_desc& d, int split);
+int f2g_launch_leanw6t(const f2g_gemm_desc& d, int split, hipStream_t st);
 // the same schedule over row operands (plain matrices / strided single-segment windows): split = 0 images, 1 = fp32
 int f2g_x6pr_ok(const f2g_gemm_desc& d);
 int f2g_launch_x6pr(const f2g_gemm_desc& d, int split, int P0, unsigned seq, unsigned step, unsigned off,

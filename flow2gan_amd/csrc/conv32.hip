@@ -1127,7 +1127,10 @@ extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) 
   if (d->precision != 0 && d->precision != 1 && d->precision != 3) return F2G_EINVAL;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
-  if (d->precision == 3) return f2g_conv32_fwd6_launch(d, (hipStream_t)stream);   // w = f2g_split_bf16x3 image
+  if (d->precision == 3) {   // w = f2g_split_bf16x3 image; the output leaves as 16-byte row segments
+    if (!al(d->y) || (d->y_line & 3) || (d->y_seq & 3)) return F2G_EINVAL;
+    return f2g_conv32_fwd6_launch(d, (hipStream_t)stream);
+  }
   const size_t smem = (size_t)(2 * SUB + 2 * TG * WB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1185,7 +1188,10 @@ extern "C" int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   if (!al(d->x) || !al(d->w) || (d->x_line & 3) || (d->x_seq & 3)) return F2G_EINVAL;
   if (d->precision != 0 && d->precision != 1 && d->precision != 3) return F2G_EINVAL;
-  if (d->precision == 3) return f2g_conv32_dgrad6_launch(d, (hipStream_t)stream);  // w = image of wT (864 x 32)
+  if (d->precision == 3) {   // w = image of wT (864 x 32); output, mask and reference map as 16-byte row segments
+    if (!al(d->y) || (d->y_line & 3) || (d->y_seq & 3) || !al(d->mask_src) || !al(d->fm_ref)) return F2G_EINVAL;
+    return f2g_conv32_dgrad6_launch(d, (hipStream_t)stream);
+  }
   const size_t smem = (size_t)(GSUB + 2 * TG * WB) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {

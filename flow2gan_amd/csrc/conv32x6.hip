@@ -253,19 +253,30 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_fwd6_kernel(const f2g_conv32
     if (more) store_patch(pf);
     __syncthreads();
     if (half == 0) {
+      // (round 5) the finished 32 pixels x 32 channels leave through this pixel group's 4 KB of `red`, turned to
+      // [pixel][channel]: four 16-byte stores per lane instead of sixteen 4-byte ones
       int sq, h0, w0;
       tile_pos(tile, sq, h0, w0);
       float* ys = d.y + (long long)sq * d.y_seq;
+      float* turn = red + pg * (16 * 64);
+      float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
+        v[e] = acc0[e] + red[(pg * 16 + e) * 64 + lane] + bias;
+        if (d.lrelu_slope != 0.f) v[e] = v[e] > 0.f ? v[e] : d.lrelu_slope * v[e];
+      }
+      __builtin_amdgcn_wave_barrier();            // (the partner half's partial sums are in registers)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) turn[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32 + li] = v[e];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
         int qh, qw;
-        px_of_row<TW_>(pg, (e & 3) + 8 * (e >> 2) + 4 * hh, qh, qw);
+        px_of_row<TW_>(pg, (lane >> 3) + 8 * j, qh, qw);
         const int oh = h0 + qh, ow = w0 + qw;
-        if (oh < d.H && ow < d.Wout) {
-          float v = acc0[e] + red[(pg * 16 + e) * 64 + lane] + bias;
-          if (d.lrelu_slope != 0.f) v = v > 0.f ? v : d.lrelu_slope * v;
-          ys[(long long)oh * d.y_line + (long long)ow * C + li] = v;
-        }
+        const f32x4 u = *reinterpret_cast<const f32x4*>(turn + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
+        if (oh < d.H && ow < d.Wout)
+          *reinterpret_cast<f32x4*>(ys + (long long)oh * d.y_line + (long long)ow * C + 4 * (lane & 7)) = u;
       }
     }
   }
@@ -289,6 +300,9 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
   extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
   unsigned char* At = smb;                               // [IHv][GWv] pixels
   unsigned char* Bt = smb + IHv * GWv * PB;              // [2 buffers][TG taps][32 rows]
+  // (round 5) epilogue turn: a wave's 32 positions x 32 channels leave through a private 4 KB patch as 16-byte
+  // row segments -- 4 stores (and 4 mask loads) per lane and tile instead of 16 four-byte ones
+  float* turn = reinterpret_cast<float*>(Bt + 2 * TG * WBB) + (threadIdx.x >> 6) * (32 * 32);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hh = lane >> 5;
   const int pg = wave & 3, E = wave >> 2;                // E = column parity of this wave half
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
   const unsigned char* Bp = Bt + (E * 2) * WBB + li * PB + hh * 16;
   const bool msk = d.mask_src != nullptr, fm = d.fm_ref != nullptr;
   const float fmw = fm ? d.fm_w * (d.fm_wdev ? d.fm_wdev[0] : 1.f) : 0.f;
-  float cs = 0.f;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};            // column sums of what this lane stores (channels 4 (lane & 7) ..)
 
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
@@ -377,19 +391,21 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
     load_patch(more ? nxt : tile, pf);
     int sq, h0, m0;
     tile_pos(tile, sq, h0, m0);
-    // (round 5) the mask of this tile's outputs is requested HERE, sixteen values per lane: read in the
-    // epilogue it put a memory round trip behind every tile's MFMAs with nothing else resident on the CU --
-    // which is why the fused leaky-ReLU backward used to lose against a separate pass over the map
-    float my[16];
-    if (msk && !fm) {
+    // (round 5) the mask of this tile's outputs is requested HERE, four 16-byte segments per lane (item j =
+    // position (lane >> 3) + 8 j of the wave's 32, channels 4 (lane & 7) ..): read in the epilogue it put a
+    // memory round trip behind every tile's MFMAs with nothing else resident on the CU -- which is why the
+    // fused leaky-ReLU backward used to lose against a separate pass over the map
+    long long ioff[4];
+    f32x4 my[4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        int qh, qw;
-        px_of_row<TW_>(pg, (q & 3) + 8 * (q >> 2) + 4 * hh, qh, qw);
-        const int oh = h0 + qh, om = m0 + qw;
-        const long long off = (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + li;
-        my[q] = (oh < d.H && om < Wp) ? d.mask_src[off] : 1.f;
-      }
+    for (int j = 0; j < 4; ++j) {
+      int qh, qw;
+      px_of_row<TW_>(pg, (lane >> 3) + 8 * j, qh, qw);
+      const int oh = h0 + qh, om = m0 + qw;
+      ioff[j] = (oh < d.H && om < Wp)
+                    ? (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + 4 * (lane & 7)
+                    : -1;
+      if (msk && !fm) my[j] = *reinterpret_cast<const f32x4*>(ioff[j] >= 0 ? d.mask_src + ioff[j] : c6_zero);
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -407,33 +423,48 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
       __syncthreads();
     }
 #undef F2G_C6_GOFF
-    // ---- epilogue: optional leaky-ReLU backward of the layer below (+ feature-matching term)
+    // ---- epilogue: the wave's tile through its private patch ([position][channel]); optional leaky-ReLU
+    // backward of the layer below (+ feature-matching term), column sums
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      int qh, qw;
-      px_of_row<TW_>(pg, (q & 3) + 8 * (q >> 2) + 4 * hh, qh, qw);
-      const int oh = h0 + qh, om = m0 + qw;
-      if (oh < d.H && om < Wp) {
-        const long long off = (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + li;
-        float v = acc0[q] + acc1[q];
-        if (msk) {
-          const float y = fm ? d.mask_src[off] : my[q];
-          if (fm) {
-            const float dl = y - d.fm_ref[off];
-            v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+    for (int q = 0; q < 16; ++q) turn[((q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + li] = acc0[q] + acc1[q];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(turn + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
+      if (ioff[j] < 0) continue;
+      float v[4] = {u.x, u.y, u.z, u.w};
+      if (msk) {
+        const f32x4 yv = fm ? *reinterpret_cast<const f32x4*>(d.mask_src + ioff[j]) : my[j];
+        const float y[4] = {yv.x, yv.y, yv.z, yv.w};
+        if (fm) {
+          const f32x4 fv = *reinterpret_cast<const f32x4*>(d.fm_ref + ioff[j]);
+          const float f[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dl = y[e] - f[e];
+            v[e] += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
           }
-          v *= y > 0.f ? 1.f : d.mask_slope;
         }
-        cs += v;
-        d.y[off] = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= y[e] > 0.f ? 1.f : d.mask_slope;
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[e] += v[e];
+      *reinterpret_cast<f32x4*>(d.y + ioff[j]) = f32x4{v[0], v[1], v[2], v[3]};
     }
+    __builtin_amdgcn_wave_barrier();
     if (more) store_patch(pf);
     __syncthreads();
   }
   if (d.colsum) {
-    cs += __shfl_xor(cs, 32);
-    if (hh == 0) atomicAdd(d.colsum + li, cs);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = cs[e];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 8) atomicAdd(d.colsum + 4 * lane + e, v);
+    }
   }
 }
 
@@ -782,7 +813,7 @@ constexpr size_t fwd6_smem() {
 }
 template <int TH_, int TW_>
 constexpr size_t dgrad6_smem() {
-  return (size_t)(TH_ + 2) * (TW_ + 4) * PB + 2 * TG * WBB;
+  return (size_t)(TH_ + 2) * (TW_ + 4) * PB + 2 * TG * WBB + 8 * 32 * 32 * sizeof(float);
 }
 
 }  // namespace

@@ -2504,6 +2504,10 @@ int launch_leanw3(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
 }
 
 int launch_leanw6(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStream_t st) {
+  if (f2g_leanw6t_ok(d, split)) {       // round 5: all taps of a stride-1 layer from one staged window
+    g_last_path = 4;
+    return f2g_launch_leanw6t(d, split, st);
+  }
   constexpr size_t smem = 6 * 32 * 256;
   int kchunk = ((K + split - 1) / split + BK - 1) / BK * BK;
   const int zs = (K + kchunk - 1) / kchunk;

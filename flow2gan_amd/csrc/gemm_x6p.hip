@@ -348,6 +348,165 @@ __global__ __launch_bounds__(512, 1) void gemm_x6pr_kernel(const f2g_gemm_desc d
   x6e::wide_epilogue(d.E, acc, M, N, mg + wm * 64, n0 + wn * 64, lane, smem6 + wave * ESZ);
 }
 
+
+// ---- tap-walking weight gradient of a stride-1 conv layer over halo maps (round 5) ----------------------
+// gw[co][t][ci] += sum_r g[r][co] * x[r + t - pad][ci]  (the 1024-channel MPD layer: t = 0..4; reference
+// discriminators.py:65-76 backward).  gemm_leanw6_kernel gives every (tap, 128 ci) column tile its own block:
+// the same 32 gradient rows are split into their three bf16 pieces by 40 blocks, the same map rows by 8 x 5
+// -- 7.9 VALU instructions per MFMA, matrix pipe 50 % busy.  Here a block owns 128 co x 128 ci x ALL taps: a
+// slab stages 32 gradient rows and the 32 + TAPS - 1 map rows they touch ONCE (split once, K-major bf16
+// planes with gemm_leanw6_kernel's swizzle, double-buffered: one barrier per slab), and the taps walk over the
+// staged map rows by shifting the transposing fragment reads (ds_read_b64_tr_b16) one row down.  8 waves =
+// (co half) x (ci quarter), 2 x TAPS accumulator tiles each; 120 MFMAs per wave and slab behind 15 LDS stores
+// per thread (the old kernel: 48 behind 24).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * 256));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(512, 1) void gemm_leanw6t_kernel(const f2g_gemm_desc d, int K, int kchunk,
+                                                              long long xrows) {
+  constexpr int XR = 32 + TAPS - 1;              // staged map rows: the slab's 32 + the taps' overhang
+  constexpr int GPL = 32 * 256, XPL = XR * 256;  // bytes of one piece plane: gradient rows / map rows
+  constexpr int BUFB = 3 * GPL + 3 * XPL;        // one stage: [g p0 p1 p2 | x p0 p1 p2]
+  constexpr int NXQ = (XR * 32 + 511) / 512;     // map chunks per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wq = wave >> 1, li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128, c0 = blockIdx.y * 128;     // co tile, ci tile
+  const int kbeg = blockIdx.z * kchunk;
+  int kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  const int nt = (kend - kbeg + 31) / 32;
+  if (nt <= 0) return;
+  const int Cin = d.B.unit, pad = d.B.pad0;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.A.base, 0, (unsigned)((long long)K * d.A.seq_stride * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.B.base, 0, (unsigned)(xrows * Cin * 4), 0x00020000);
+  // staging: chunk id = tid + 512 q -> (row of the slab, 16-byte chunk c of the 128-wide row)
+  const int cc = tid & 31, r0 = tid >> 5;         // rows r0 + 16 q
+  unsigned offG[2];
+  int wofG[2], wofX[NXQ];
+  const unsigned rowX = (unsigned)Cin * 4u, colX = (unsigned)(c0 + 4 * cc) * 4u;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = r0 + 16 * q;
+    offG[q] = (unsigned)(((long long)r * d.A.seq_stride + m0 + 4 * cc) * 4);
+    wofG[q] = r * 256 + ((((cc >> 3) ^ (r & 3))) << 6) + (cc & 7) * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < NXQ; ++q) {
+    const int r = r0 + 16 * q;
+    wofX[q] = r < XR ? 3 * GPL + r * 256 + ((((cc >> 3) ^ (r & 3))) << 6) + (cc & 7) * 8 : -1;
+  }
+  const int stepG = (int)(32 * d.A.seq_stride * 4);
+  // transposed-read roles (gemm_leanw6_kernel): 16-lane group g4, lane i16 -> row (g4 >> 1) * 8 + (i16 >> 2)
+  // (+4 for the second half), 8 bytes at (g4 & 1) * 32 + (i16 & 3) * 8 of the tile's 64-byte column block
+  const int g4 = lane >> 4, i16 = lane & 15;
+  const int rrow = (g4 >> 1) * 8 + (i16 >> 2), within = (g4 & 1) * 32 + (i16 & 3) * 8;
+  int rofA[2], rofB[TAPS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) rofA[t] = rrow * 256 + ((((wm * 2 + t) ^ (rrow & 3))) << 6) + within;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) rofB[t] = 3 * GPL + (rrow + t) * 256 + (((wq ^ ((rrow + t) & 3))) << 6) + within;
+  f32x16 acc[2][TAPS];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][t][e] = 0.f;
+  u32x4 xg[2], xx[NXQ];
+  auto gload = [&](int s) {       // slab s of this block's chunk (rows kbeg + 32 s ..); past the end: zeros
+    const int kr = kbeg + 32 * s;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = kr + r0 + 16 * q;
+      xg[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, (s < nt && r < kend) ? offG[q] : 0x80000000u, kr * (stepG / 32), 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NXQ; ++q) {
+      const long long xr = (long long)kr - pad + r0 + 16 * q;        // flat map row of staged row r0 + 16 q
+      const bool ok = s < nt && wofX[q] >= 0 && xr >= 0 && xr < xrows;
+      // (the whole offset in the vector register: kr - pad is negative for the first slab, and the scalar
+      // offset of a buffer load takes no part in the range check)
+      xx[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? (unsigned)(xr * rowX) + colX : 0x80000000u, 0, 0);
+    }
+  };
+  auto store = [&](unsigned char* buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      u32x2 p0, p1, p2;
+      split3x4(xg[q], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(buf + wofG[q]) = p0;
+      *reinterpret_cast<u32x2*>(buf + GPL + wofG[q]) = p1;
+      *reinterpret_cast<u32x2*>(buf + 2 * GPL + wofG[q]) = p2;
+    }
+#pragma unroll
+    for (int q = 0; q < NXQ; ++q)
+      if (wofX[q] >= 0) {
+        u32x2 p0, p1, p2;
+        split3x4(xx[q], p0, p1, p2);
+        *reinterpret_cast<u32x2*>(buf + wofX[q]) = p0;
+        *reinterpret_cast<u32x2*>(buf + XPL + wofX[q]) = p1;
+        *reinterpret_cast<u32x2*>(buf + 2 * XPL + wofX[q]) = p2;
+      }
+  };
+  gload(0);
+  store(smw);
+  gload(1);
+  lds_barrier();
+  for (int s = 0; s < nt; ++s) {
+    unsigned char* cur = smw + (s & 1) * BUFB;
+    // the next slab goes into the other stage (its readers left through the barrier that closed slab s - 1)
+    store(smw + ((s + 1) & 1) * BUFB);
+    gload(s + 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[3][2];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) fa[pc][mi] = tr_frag(cur + ks * 16 * 256 + pc * GPL + rofA[mi]);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        bf16x8 fb[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) fb[pc] = tr_frag(cur + ks * 16 * 256 + pc * XPL + rofB[t]);
+#pragma unroll
+        for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int j = sdeg - i;
+            if (j < 0 || j > 2) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+              acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[j], acc[mi][t], 0, 0, 0);
+          }
+      }
+    }
+    lds_barrier();
+  }
+  // gw[co][t * Cin + ci] += acc: rows m0 + wm * 64 + mi * 32 + (MFMA row), columns t * Cin + c0 + wq * 32 + li
+  float* C0 = d.E.C;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        atomicAdd(C0 + (long long)row * d.E.ldc + t * Cin + c0 + wq * 32 + li, acc[mi][t][e]);
+      }
+}
+
 }  // namespace
 
 // d: a precision-3 descriptor that passed gemm.hip's x6_tap_ok(d, taps) (stride-1 windows of `taps` positions
@@ -422,5 +581,53 @@ int f2g_launch_x6pr(const f2g_gemm_desc& d, int split, int P0, unsigned seq, uns
   dim3 grid((M + 255) / 256, (N + 127) / 128);
   if (split) hipLaunchKernelGGL(gemm_x6pr_kernel<true>, grid, dim3(512), smem, st, d, M, N, K, R);
   else hipLaunchKernelGGL(gemm_x6pr_kernel<false>, grid, dim3(512), smem, st, d, M, N, K, R);
+  return f2g_check_launch();
+}
+
+// Weight gradient of a stride-1 conv layer over halo maps on the tap-walking kernel (gemm.hip: launch_leanw6
+// after leanw_ok).  0 = not taken.
+int f2g_leanw6t_ok(const f2g_gemm_desc& d, int split) {
+  const char* ev = getenv("F2G_W6T");       // 0 off (read per call so that a test can switch it)
+  if (ev && atoi(ev) == 0) return 0;
+  const f2g_operand& A = d.A;
+  const f2g_operand& B = d.B;
+  if (d.form != 2 || d.precision != 3 || !d.E.atomic || d.E.P0o > 0 || d.E.bias || d.E.res) return 0;
+  if (B.P1 != 1 || B.P0 < 1 || B.step0 != 1 || B.unit < 128 || (B.unit % 128) || !B.unbounded) return 0;
+  if (B.cols != 5 * B.unit || B.seglen < B.cols || B.seq_stride != (long long)B.P0 * B.unit) return 0;
+  if (A.cols % 128 || A.rows != B.rows || B.pad0 < 0 || B.pad0 > 8) return 0;
+  const long long xrows = (long long)(B.rows / B.P0) * B.P0;
+  if (xrows * B.unit * 4 >= 0x7ff00000ll || (long long)A.rows * A.seq_stride * 4 >= 0x7ff00000ll) return 0;
+  return 1;
+}
+
+int f2g_launch_leanw6t(const f2g_gemm_desc& d, int split, hipStream_t st) {
+  const int M = d.A.cols, K = d.A.rows, Cin = d.B.unit;
+  constexpr int TAPS = 5;
+  constexpr size_t smem = (size_t)2 * (3 * 32 * 256 + 3 * (32 + TAPS - 1) * 256);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw6t_kernel<5>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_done = true;
+  }
+  // one block per CU: split the rows so that tiles x chunks fill rounds of 256 blocks
+  const int tiles = (M / 128) * (Cin / 128);
+  int zs = split;
+  {
+    int best = 1;
+    double beste = 0.0;
+    for (int z = 1; z <= 64; ++z) {
+      const long long blocks = (long long)tiles * z;
+      if ((long long)K / z < 1024) break;
+      const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+      if (eff > beste + 0.02) beste = eff, best = z;
+    }
+    zs = best;
+  }
+  int kchunk = ((K + zs - 1) / zs + 31) / 32 * 32;
+  zs = (K + kchunk - 1) / kchunk;
+  const long long xrows = (long long)(d.B.rows / d.B.P0) * d.B.P0;
+  dim3 grid(M / 128, Cin / 128, zs);
+  hipLaunchKernelGGL(gemm_leanw6t_kernel<5>, grid, dim3(512), smem, st, d, K, kchunk, xrows);
   return f2g_check_launch();
 }

@@ -186,11 +186,13 @@ def test_wgrad_fp32_k_major_kernel_on_long_reductions(ops, windowed):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16x6"])
-@pytest.mark.parametrize("S,Hin,stv", [(5, 50, 3), (7, 131, 1), (3, 400, 3)])
+@pytest.mark.parametrize("S,Hin,stv", [(5, 50, 3), (7, 131, 1), (3, 400, 3), (40, 300, 1)])
 def test_wgrad_unbounded_windows(ops, mode, S, Hin, stv, monkeypatch):
     """MPD-style weight gradient: X = (5,1)-tap windows over a halo layout, read past the sequence
     ends where the gradient map's halo rows are zero (f2g_operand.unbounded); slabs that straddle
-    sequence ends, the first rows before the buffer, the last ones behind it."""
+    sequence ends, the first rows before the buffer, the last ones behind it.  bf16x6 with stride 1 runs on
+    the tap-walking kernel of round 5 (gemm_leanw6t_kernel: all five taps from one staged window of map rows);
+    the last case cuts its 12160 rows into several chunks."""
     Cin, Cout, HALO = 128, 256, 2
     Hout = (Hin + 4 - 5) // stv + 1
     Hp = Hout + 2 * HALO
