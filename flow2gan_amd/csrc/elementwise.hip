@@ -384,6 +384,50 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(float* loss, float* gb, co
   }
 }
 
+// the same over a CONTIGUOUS span (rows == 1 or ld == cols; n % 4 == 0, 16-byte aligned pointers): 16-byte
+// loads, four in flight per thread, no 64-bit division per element (round 5: the scalar kernel above read the
+// feature-matching maps at 2.6 TB/s)
+__global__ __launch_bounds__(256) void l1_loss4_kernel(float* loss, float* gb, const float4* a, const float4* b,
+                                                       long long n4, float w, float clip, const float* wdev) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const float wg = w * (wdev ? wdev[0] : 1.f);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    float4 av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+      av[u] = i < n4 ? a[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[u] = i < n4 ? b[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+      if (i >= n4) break;
+      const float x[4] = {av[u].x, av[u].y, av[u].z, av[u].w}, y[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float dd, gscale = 1.f;
+        if (clip > 0.f) {
+          dd = logf(fmaxf(x[e], clip)) - logf(fmaxf(y[e], clip));
+          gscale = y[e] > clip ? 1.f / y[e] : 0.f;
+        } else {
+          dd = x[e] - y[e];
+        }
+        acc += fabsf(dd);
+        o[e] = -wg * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f)) * gscale;
+      }
+      if (gb) reinterpret_cast<float4*>(gb)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  if (loss) {
+    acc = block_sum256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(loss, w * acc);
+  }
+}
+
 __global__ __launch_bounds__(256) void hinge_loss_kernel(float* loss, float* gs, const float* s,
                                                          long long n, float sgn, float w,
                                                          const float* wdev) {
@@ -420,6 +464,41 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(float* g, const float* y
       gv += wg * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
     }
     g[off] = gv * (y > 0.f ? 1.f : slope);
+  }
+}
+
+// the same over a contiguous span (rows == 1 or ld == cols; n % 4 == 0, aligned): 16-byte accesses, four
+// groups in flight per thread, no 64-bit division per element
+__global__ __launch_bounds__(256) void lrelu_bwd4_kernel(float4* g, const float4* y_act, const float4* f_real,
+                                                         float w, const float* wdev, float slope, long long n4) {
+  const float wg = w * (wdev ? wdev[0] : 1.f);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    float4 yv[4], gv[4], fv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+      const bool on = i < n4;
+      yv[u] = on ? y_act[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      gv[u] = on ? g[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      fv[u] = (on && f_real) ? f_real[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+      if (i >= n4) break;
+      const float y[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w}, f[4] = {fv[u].x, fv[u].y, fv[u].z, fv[u].w};
+      float o[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (f_real) {
+          const float dd = y[e] - f[e];
+          o[e] += wg * (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f));
+        }
+        o[e] *= y[e] > 0.f ? 1.f : slope;
+      }
+      g[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -760,6 +839,12 @@ extern "C" int f2g_l1_loss(float* loss, float* gb, const float* a, const float* 
                            f2g_stream_t stream) {
   if (!a || !b || (!loss && !gb)) return F2G_EINVAL;
   if (rows <= 0 || cols <= 0) return F2G_OK;
+  const long long n = (long long)rows * cols;
+  if ((rows == 1 || ld == cols) && !(n & 3) && !((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)gb)) & 15)) {
+    hipLaunchKernelGGL(l1_loss4_kernel, dim3(f2g_grid_for(n / 4, 256 * 4, 2048)), dim3(256), 0, ST, loss, gb,
+                       reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), n / 4, w, clip, wdev);
+    return f2g_check_launch();
+  }
   hipLaunchKernelGGL(l1_loss_kernel, dim3(f2g_grid_for((int64_t)rows * cols, 256, 1024)),
                      dim3(256), 0, ST, loss, gb, a, b, rows, cols, (long long)ld, w, clip, wdev);
   return f2g_check_launch();
@@ -779,6 +864,13 @@ extern "C" int f2g_lrelu_bwd(float* g, const float* y_act, const float* f_real, 
                              int64_t ld, f2g_stream_t stream) {
   if (!g || !y_act) return F2G_EINVAL;
   if (rows <= 0 || cols <= 0) return F2G_OK;
+  const long long n = (long long)rows * cols;
+  if ((rows == 1 || ld == cols) && !(n & 3) && !((((uintptr_t)g) | ((uintptr_t)y_act) | ((uintptr_t)f_real)) & 15)) {
+    hipLaunchKernelGGL(lrelu_bwd4_kernel, dim3(f2g_grid_for(n / 4, 256 * 4, 2048)), dim3(256), 0, ST,
+                       reinterpret_cast<float4*>(g), reinterpret_cast<const float4*>(y_act),
+                       reinterpret_cast<const float4*>(f_real), w, wdev, slope, n / 4);
+    return f2g_check_launch();
+  }
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(f2g_grid_for((int64_t)rows * cols, 256)), dim3(256), 0,
                      ST, g, y_act, f_real, w, wdev, slope, rows, cols, (long long)ld);
   return f2g_check_launch();
