@@ -507,6 +507,146 @@ __global__ __launch_bounds__(512, 1) void gemm_leanw6t_kernel(const f2g_gemm_des
       }
 }
 
+
+// ---- the same for STRIDED layers (the stride-3 MPD layers: x row = STRIDE * p + t - pad inside a sequence) --
+// Consecutive reduction rows read map rows STRIDE apart and the flat row index is no longer one affine function
+// over the whole buffer (a sequence has Hp gradient rows but HpIn != STRIDE * Hp map rows), so the block walks
+// its sequences one by one in slabs of 16 gradient rows (one MFMA k step; 16 rather than 32 keeps the waste of
+// a sequence's last slab at ~5 % over the five periods) and stages the 15 * STRIDE + TAPS map rows they touch:
+// every map row is still loaded and split once for all taps.  Fragment row of reduction index i and tap t =
+// staged row STRIDE * i + t (the transposing read takes each lane's own address).
+template <int TAPS, int STRIDE>
+__global__ __launch_bounds__(512, 1) void gemm_leanw6s_kernel(const f2g_gemm_desc d, int nseq, int spb,
+                                                              long long xrows) {
+  constexpr int XR = 15 * STRIDE + TAPS;         // staged map rows of a 16-row slab
+  constexpr int GPL = 16 * 256, XPL = XR * 256;
+  constexpr int BUFB = 3 * GPL + 3 * XPL;
+  constexpr int NXQ = (XR * 32 + 511) / 512;
+  static_assert((4 * STRIDE) % 4 == 0 && (16 * STRIDE) % 4 == 0, "the swizzle term must not depend on the half / k step");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wq = wave >> 1, li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int Cin = d.B.unit, pad = d.B.pad0, Hp = d.B.P0;
+  const int HpIn = (int)(d.B.seq_stride / Cin);
+  const int sq0 = blockIdx.z * spb;
+  int sq1 = sq0 + spb;
+  if (sq1 > nseq) sq1 = nseq;
+  const int nslab = (Hp + 15) / 16;
+  const int nt = (sq1 - sq0) * nslab;
+  if (nt <= 0) return;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.A.base, 0, (unsigned)((long long)nseq * Hp * d.A.seq_stride * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)d.B.base, 0, (unsigned)(xrows * Cin * 4), 0x00020000);
+  const int cc = tid & 31, r0 = tid >> 5;         // gradient row r0 of the slab; map rows r0 + 16 q
+  const unsigned rowG = (unsigned)(d.A.seq_stride * 4), colG = (unsigned)(m0 + 4 * cc) * 4u;
+  const unsigned rowX = (unsigned)Cin * 4u, colX = (unsigned)(c0 + 4 * cc) * 4u;
+  const int wofG = r0 * 256 + ((((cc >> 3) ^ (r0 & 3))) << 6) + (cc & 7) * 8;
+  int wofX[NXQ];
+#pragma unroll
+  for (int q = 0; q < NXQ; ++q) {
+    const int r = r0 + 16 * q;
+    wofX[q] = r < XR ? 3 * GPL + r * 256 + ((((cc >> 3) ^ (r & 3))) << 6) + (cc & 7) * 8 : -1;
+  }
+  const int g4 = lane >> 4, i16 = lane & 15;
+  const int rrow = (g4 >> 1) * 8 + (i16 >> 2), within = (g4 & 1) * 32 + (i16 & 3) * 8;
+  int rofA[2], rofB[TAPS];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) rofA[t] = rrow * 256 + ((((wm * 2 + t) ^ (rrow & 3))) << 6) + within;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int xr = STRIDE * rrow + t;
+    rofB[t] = 3 * GPL + xr * 256 + (((wq ^ (xr & 3))) << 6) + within;
+  }
+  f32x16 acc[2][TAPS];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][t][e] = 0.f;
+  u32x4 xg, xx[NXQ];
+  auto gload = [&](int j) {       // slab j of this block: sequence sq0 + j / nslab, gradient rows 16 (j % nslab) ..
+    const int sj = j / nslab, p0 = (j - sj * nslab) * 16, sq = sq0 + sj;
+    const bool on = j < nt;
+    const int p = p0 + r0;
+    xg = __builtin_amdgcn_raw_buffer_load_b128(
+        ra, (on && p < Hp) ? (unsigned)((long long)sq * Hp + p) * rowG + colG : 0x80000000u, 0, 0);
+    const long long xb = (long long)sq * HpIn + (long long)STRIDE * p0 - pad;     // map row of staged row 0
+#pragma unroll
+    for (int q = 0; q < NXQ; ++q) {
+      const long long xr = xb + r0 + 16 * q;
+      const bool ok = on && wofX[q] >= 0 && xr >= 0 && xr < xrows;
+      xx[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? (unsigned)xr * rowX + colX : 0x80000000u, 0, 0);
+    }
+  };
+  auto store = [&](unsigned char* buf) {
+    u32x2 p0, p1, p2;
+    split3x4(xg, p0, p1, p2);
+    *reinterpret_cast<u32x2*>(buf + wofG) = p0;
+    *reinterpret_cast<u32x2*>(buf + GPL + wofG) = p1;
+    *reinterpret_cast<u32x2*>(buf + 2 * GPL + wofG) = p2;
+#pragma unroll
+    for (int q = 0; q < NXQ; ++q)
+      if (wofX[q] >= 0) {
+        split3x4(xx[q], p0, p1, p2);
+        *reinterpret_cast<u32x2*>(buf + wofX[q]) = p0;
+        *reinterpret_cast<u32x2*>(buf + XPL + wofX[q]) = p1;
+        *reinterpret_cast<u32x2*>(buf + 2 * XPL + wofX[q]) = p2;
+      }
+  };
+  // transposing fragment read whose second half lies HS rows further (4 reduction rows = 4 * STRIDE map rows)
+  auto tr_frag_s = [&](const unsigned char* p, int half_rows) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + half_rows * 256));
+    const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  gload(0);
+  store(smw);
+  gload(1);
+  lds_barrier();
+  for (int j = 0; j < nt; ++j) {
+    unsigned char* cur = smw + (j & 1) * BUFB;
+    store(smw + ((j + 1) & 1) * BUFB);
+    gload(j + 2);
+    bf16x8 fa[3][2];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) fa[pc][mi] = tr_frag_s(cur + pc * GPL + rofA[mi], 4);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      bf16x8 fb[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) fb[pc] = tr_frag_s(cur + pc * XPL + rofB[t], 4 * STRIDE);
+#pragma unroll
+      for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int jj = sdeg - i;
+          if (jj < 0 || jj > 2) continue;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[mi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[jj], acc[mi][t], 0, 0, 0);
+        }
+    }
+    lds_barrier();
+  }
+  float* C0 = d.E.C;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        atomicAdd(C0 + (long long)row * d.E.ldc + t * Cin + c0 + wq * 32 + li, acc[mi][t][e]);
+      }
+}
+
 }  // namespace
 
 // d: a precision-3 descriptor that passed gemm.hip's x6_tap_ok(d, taps) (stride-1 windows of `taps` positions
@@ -592,10 +732,11 @@ int f2g_leanw6t_ok(const f2g_gemm_desc& d, int split) {
   const f2g_operand& A = d.A;
   const f2g_operand& B = d.B;
   if (d.form != 2 || d.precision != 3 || !d.E.atomic || d.E.P0o > 0 || d.E.bias || d.E.res) return 0;
-  if (B.P1 != 1 || B.P0 < 1 || B.step0 != 1 || B.unit < 128 || (B.unit % 128) || !B.unbounded) return 0;
-  if (B.cols != 5 * B.unit || B.seglen < B.cols || B.seq_stride != (long long)B.P0 * B.unit) return 0;
+  if (B.P1 != 1 || B.P0 < 1 || (B.step0 != 1 && B.step0 != 3) || B.unit < 128 || (B.unit % 128) || !B.unbounded) return 0;
+  if (B.cols != 5 * B.unit || B.seglen < B.cols || (B.seq_stride % B.unit) || (B.rows % B.P0)) return 0;
   if (A.cols % 128 || A.rows != B.rows || B.pad0 < 0 || B.pad0 > 8) return 0;
-  const long long xrows = (long long)(B.rows / B.P0) * B.P0;
+  if (B.step0 == 1 && B.seq_stride != (long long)B.P0 * B.unit) return 0;    // (one flat row index for the whole buffer)
+  const long long xrows = (long long)(B.rows / B.P0) * (B.seq_stride / B.unit);
   if (xrows * B.unit * 4 >= 0x7ff00000ll || (long long)A.rows * A.seq_stride * 4 >= 0x7ff00000ll) return 0;
   return 1;
 }
@@ -603,6 +744,31 @@ int f2g_leanw6t_ok(const f2g_gemm_desc& d, int split) {
 int f2g_launch_leanw6t(const f2g_gemm_desc& d, int split, hipStream_t st) {
   const int M = d.A.cols, K = d.A.rows, Cin = d.B.unit;
   constexpr int TAPS = 5;
+  if (d.B.step0 == 3) {     // strided layer: whole sequences per block, slabs of 16 gradient rows
+    constexpr size_t smem3 = (size_t)2 * (3 * 16 * 256 + 3 * (15 * 3 + TAPS) * 256);
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_leanw6s_kernel<5, 3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+      attr3 = true;
+    }
+    const int nseq = K / d.B.P0, tiles = (M / 128) * (Cin / 128);
+    // blocks = tiles x sequence chunks: the chunk count whose block total fills rounds of 256 best
+    int best = 1;
+    double beste = 0.0;
+    for (int z = 1; z <= nseq && z <= 256; ++z) {
+      const int per = (nseq + z - 1) / z;
+      if (per * d.B.P0 < 256 && z > 1) break;                    // (>= 256 reduction rows per block)
+      const long long blocks = (long long)tiles * ((nseq + per - 1) / per);
+      const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+      if (eff > beste + 0.02) beste = eff, best = z;
+    }
+    const int spb = (nseq + best - 1) / best, zs = (nseq + spb - 1) / spb;
+    const long long xrows = (long long)nseq * (d.B.seq_stride / Cin);
+    dim3 grid(M / 128, Cin / 128, zs);
+    hipLaunchKernelGGL((gemm_leanw6s_kernel<5, 3>), grid, dim3(512), smem3, st, d, nseq, spb, xrows);
+    return f2g_check_launch();
+  }
   constexpr size_t smem = (size_t)2 * (3 * 32 * 256 + 3 * (32 + TAPS - 1) * 256);
   static bool attr_done = false;
   if (!attr_done) {
