@@ -3034,10 +3034,14 @@ __global__ __launch_bounds__(512, 1) void gemm_x6t8_kernel(const f2g_gemm_desc d
 // splits the 4-float chunks it loads into the three pieces on their way into LDS, as gemm_leanw6_kernel
 // does -- 4 bytes per element from L2 instead of 6, no image pass, no producer, 5.5 VALU instructions per
 // element beside the 48 MFMAs per slab and wave.
+template <bool WIMG>
 __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d, int M, int N, int K,
                                                           const x6_rows R, const int wide) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-  constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 4;
+  // WIMG (round 5): the WEIGHT operand is its cached f2g_split_bf16x3 image (192 bytes per row and slab, stored
+  // to LDS as it comes) -- every one of the M / 128 row tiles used to split the same weight slab again; only
+  // the activation rows (read once per column tile) are still split here
+  constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 4, NJW = WIMG ? 6 : 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
   int m0, n0;
@@ -3051,27 +3055,38 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // (here R.seq6 / step6 / off6 / bytes are in units of 4 bytes per element: x6_rows_of(d, 4))
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
+  const unsigned rowbytesW = (unsigned)(K / 32) * 192u;
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)d.B.base, 0, (unsigned)((long long)N * d.B.seq_stride * 4), 0x00020000);
+      (void*)d.B.base, 0, WIMG ? (unsigned)N * rowbytesW : (unsigned)((long long)N * d.B.seq_stride * 4), 0x00020000);
   // chunk id = tid + 256 j -> (row of the tile, 16-byte chunk = 4 of the slab's 32 floats)
-  unsigned voA[NJ], voW[NJ];
-  int lo[NJ];
+  unsigned voA[NJ], voW[NJW];
+  int lo[NJ], loW[NJW];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int id = tid + 256 * j, row = id >> 3, c = id & 7;
     const int r = m0 + row, sq = r / R.P0;
     voA[j] = r < M ? (unsigned)sq * R.seq6 + (unsigned)(r - sq * R.P0) * R.step6 + R.off6 + c * 16 : 0xf0000000u;
-    voW[j] = n0 + row < N ? (unsigned)((long long)(n0 + row) * d.B.seq_stride * 4) + c * 16 : 0xf0000000u;
     lo[j] = row * PITCH + c * 8;
   }
-  u32x4 xa[NJ], xw[NJ];
-  auto gload = [&](int t) {
-    const int so = t * 128;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], so, 0);
-      xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], so, 0);
+  for (int j = 0; j < NJW; ++j) {
+    const int id = tid + 256 * j;
+    if (WIMG) {
+      const int row = id / 12, c = id - row * 12;
+      voW[j] = n0 + row < N ? (unsigned)(n0 + row) * rowbytesW + c * 16 : 0xf0000000u;
+      loW[j] = row * PITCH + c * 16;
+    } else {
+      const int row = id >> 3, c = id & 7;
+      voW[j] = n0 + row < N ? (unsigned)((long long)(n0 + row) * d.B.seq_stride * 4) + c * 16 : 0xf0000000u;
+      loW[j] = row * PITCH + c * 8;
     }
+  }
+  u32x4 xa[NJ], xw[NJW];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], t * 128, 0);
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], t * (WIMG ? 192 : 128), 0);
   };
   const unsigned char* rA = smem6 + (wm * 64 + li) * PITCH + h * 16;
   const unsigned char* rB = smem6 + OPER + (wn * 64 + li) * PITCH + h * 16;
@@ -3085,10 +3100,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
       *reinterpret_cast<u32x2*>(smem6 + lo[j]) = p0;
       *reinterpret_cast<u32x2*>(smem6 + lo[j] + 64) = p1;
       *reinterpret_cast<u32x2*>(smem6 + lo[j] + 128) = p2;
-      split3x4(xw[j], p0, p1, p2);
-      *reinterpret_cast<u32x2*>(smem6 + OPER + lo[j]) = p0;
-      *reinterpret_cast<u32x2*>(smem6 + OPER + lo[j] + 64) = p1;
-      *reinterpret_cast<u32x2*>(smem6 + OPER + lo[j] + 128) = p2;
+    }
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) {
+      if (WIMG) {
+        *reinterpret_cast<u32x4*>(smem6 + OPER + loW[j]) = xw[j];
+      } else {
+        u32x2 p0, p1, p2;
+        split3x4(xw[j], p0, p1, p2);
+        *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j]) = p0;
+        *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j] + 64) = p1;
+        *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j] + 128) = p2;
+      }
     }
     gload(t + 1 < nt ? t + 1 : 0);       // (past the end: re-read, never used)
     X6_LDS_BARRIER();
@@ -3271,11 +3294,12 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
 }
 
 // the same descriptor over the fp32 tensors themselves (split = 0): gemm_x6f_kernel
+// (B.split = 3: the weight operand as its cached image -- gemm_x6f_kernel<true>; the activation stays fp32)
 static bool x6f_ok(const f2g_gemm_desc& d) {
-  if (d.A.split || d.B.split || !x6_shape_ok(d)) return false;
-  if (!al16(d.A.base) || !al16(d.B.base) || (d.A.seq_stride & 3) || (d.B.seq_stride & 3)) return false;
+  if (d.A.split || (d.B.split != 0 && d.B.split != 3) || !x6_shape_ok(d)) return false;
+  if (!al16(d.A.base) || !al16(d.B.base) || (d.A.seq_stride & 3) || (d.B.split == 0 && (d.B.seq_stride & 3))) return false;
   const long long ext = host_plain(d.A) ? (long long)d.A.rows * d.A.seq_stride : x6_a_extent(d.A);
-  return ext * 4 < 0xe0000000ll && (long long)d.B.rows * d.B.seq_stride * 4 < 0xe0000000ll;
+  return ext * 4 < 0xe0000000ll && (long long)d.B.rows * (d.B.split ? d.B.cols * 6ll : d.B.seq_stride * 4) < 0xe0000000ll;
 }
 
 static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
@@ -3283,7 +3307,9 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
   constexpr size_t smem = 2 * 128 * 208;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6f_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6f_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6f_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
@@ -3296,12 +3322,13 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
     R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 4), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 4);
     R.bytes = (unsigned)(x6_a_extent(d.A) * 4);
   }
-  if (f2g_x6pr_ok(d)) {     // round 5: ping-pong wave groups, the split under the other group's MFMAs
+  if (d.B.split == 0 && f2g_x6pr_ok(d)) {     // round 5: ping-pong wave groups, the split under the other group's MFMAs
     g_last_path = 4;
     return f2g_launch_x6pr(d, 1, R.P0, R.seq6, R.step6, R.off6, R.bytes, st);
   }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
-  hipLaunchKernelGGL(gemm_x6f_kernel, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
+  if (d.B.split == 3) hipLaunchKernelGGL(gemm_x6f_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
+  else hipLaunchKernelGGL(gemm_x6f_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   g_last_path = 4;
   return f2g_check_launch();
 }

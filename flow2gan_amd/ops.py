@@ -338,6 +338,10 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
                 if how:
                     if not in_kernel:   # (else gemm_x6f_kernel reads the fp32 operands and splits them itself)
                         d.A, d.B = _x3_operand(A), _x3_operand(Bm)
+                    elif X6F_WIMG and Bm.P0 == 1 and Bm.P1 == 1 and _is_const(Bm._keep[0]):
+                        # the WEIGHT operand as its cached image: every row tile used to split the same weight
+                        # slab again (M / 128 times); only the activation is split in the kernel
+                        d.B = _x3_operand(Bm)
                     d.precision = 3
             if d.precision != 3:
                 d.E.x3_out = None
@@ -553,6 +557,7 @@ X6F_MIN_TILES = int(_os.environ.get("F2G_X6F_MIN_TILES", "180"))
 # long reductions over a PLAIN activation matrix (the generator's K = 2304 GEMMs): below this K the in-kernel
 # split instead of an image pass (f2g_split_bf16x3: 10 bytes per element) in front of the image kernel
 X6_NOPASS_K = int(_os.environ.get("F2G_X6_NOPASS_K", "4096"))
+X6F_WIMG = _os.environ.get("F2G_X6F_WIMG", "1") != "0"     # in-kernel-split kernel: weights from their cached image
 
 
 def _x3_window_ok(o: Operand) -> bool:
