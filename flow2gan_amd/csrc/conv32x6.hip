@@ -405,7 +405,8 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
       ioff[j] = (oh < d.H && om < Wp)
                     ? (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + 4 * (lane & 7)
                     : -1;
-      if (msk && !fm) my[j] = *reinterpret_cast<const f32x4*>(ioff[j] >= 0 ? d.mask_src + ioff[j] : c6_zero);
+      // (a clamped offset, not a pointer select against a zero block: that costs a GOT load + wait per request)
+      if (msk && !fm) my[j] = *reinterpret_cast<const f32x4*>(d.mask_src + (ioff[j] >= 0 ? ioff[j] : 0));
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -428,29 +429,56 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
 #pragma unroll
     for (int q = 0; q < 16; ++q) turn[((q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + li] = acc0[q] + acc1[q];
     __builtin_amdgcn_wave_barrier();
+    // three separate paths, so that the plain and the prefetched-mask path carry no wait of the path that
+    // loads its mask / reference values here (a merged loop waited vmcnt(0) -- i.e. for the previous item's
+    // STORE -- in front of every item: 10.5 instead of 6.4 ms over the 45 masked launches of a pass)
+    auto item = [&](int j) {
+      return *reinterpret_cast<const f32x4*>(turn + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
+    };
+    if (!msk) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 u = *reinterpret_cast<const f32x4*>(turn + ((lane >> 3) + 8 * j) * 32 + 4 * (lane & 7));
-      if (ioff[j] < 0) continue;
-      float v[4] = {u.x, u.y, u.z, u.w};
-      if (msk) {
-        const f32x4 yv = fm ? *reinterpret_cast<const f32x4*>(d.mask_src + ioff[j]) : my[j];
-        const float y[4] = {yv.x, yv.y, yv.z, yv.w};
-        if (fm) {
-          const f32x4 fv = *reinterpret_cast<const f32x4*>(d.fm_ref + ioff[j]);
-          const float f[4] = {fv.x, fv.y, fv.z, fv.w};
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 u = item(j);
+        if (ioff[j] < 0) continue;
+        cs[0] += u.x, cs[1] += u.y, cs[2] += u.z, cs[3] += u.w;
+        *reinterpret_cast<f32x4*>(d.y + ioff[j]) = u;
+      }
+    } else if (!fm) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float dl = y[e] - f[e];
-            v[e] += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
-          }
-        }
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 u = item(j);
+        if (ioff[j] < 0) continue;
+        f32x4 v;
+        v.x = u.x * (my[j].x > 0.f ? 1.f : d.mask_slope);
+        v.y = u.y * (my[j].y > 0.f ? 1.f : d.mask_slope);
+        v.z = u.z * (my[j].z > 0.f ? 1.f : d.mask_slope);
+        v.w = u.w * (my[j].w > 0.f ? 1.f : d.mask_slope);
+        cs[0] += v.x, cs[1] += v.y, cs[2] += v.z, cs[3] += v.w;
+        *reinterpret_cast<f32x4*>(d.y + ioff[j]) = v;
+      }
+    } else {
+      f32x4 yv[4], fv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= y[e] > 0.f ? 1.f : d.mask_slope;
+      for (int j = 0; j < 4; ++j) {
+        const long long o = ioff[j] >= 0 ? ioff[j] : 0;
+        yv[j] = *reinterpret_cast<const f32x4*>(d.mask_src + o);
+        fv[j] = *reinterpret_cast<const f32x4*>(d.fm_ref + o);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) cs[e] += v[e];
-      *reinterpret_cast<f32x4*>(d.y + ioff[j]) = f32x4{v[0], v[1], v[2], v[3]};
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 u = item(j);
+        if (ioff[j] < 0) continue;
+        float v[4] = {u.x, u.y, u.z, u.w};
+        const float y[4] = {yv[j].x, yv[j].y, yv[j].z, yv[j].w}, f[4] = {fv[j].x, fv[j].y, fv[j].z, fv[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dl = y[e] - f[e];
+          v[e] += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+          v[e] *= y[e] > 0.f ? 1.f : d.mask_slope;
+          cs[e] += v[e];
+        }
+        *reinterpret_cast<f32x4*>(d.y + ioff[j]) = f32x4{v[0], v[1], v[2], v[3]};
+      }
     }
     __builtin_amdgcn_wave_barrier();
     if (more) store_patch(pf);
@@ -465,6 +493,168 @@ __global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6_kernel(const f2g_conv
       v += __shfl_xor(v, 32);
       if (lane < 8) atomicAdd(d.colsum + 4 * lane + e, v);
     }
+  }
+}
+
+// The masked instance (mask_src set: the D-step's fused leaky-ReLU backward): the narrow epilogue of round 4
+// with the tile's sixteen mask values per lane requested before the MFMAs.  The LDS-turned epilogue above is
+// 3 % faster without a mask and 30 % SLOWER with one (10.5 : 8.0 ms over the 45 masked launches of a pass,
+// whatever the form of its loads and waits -- profiles/r05_conv32_dgrad_mask.txt), so both stay.
+template <int TH_, int TW_>
+__global__ __launch_bounds__(512, 1) void conv32_s2_dgrad6m_kernel(const f2g_conv32_desc d, int tiles_w,
+                                                                 int tiles_h, int ntiles) {
+  constexpr int IHv = TH_ + KH - 1, GWv = TW_ + 4;
+  constexpr int NCHK = (IHv * GWv * (C / 4) + 511) / 512;
+  constexpr int NG = 8;                                  // groups of 2 taps per parity: 15 -> 8, 12 -> 6
+  static_assert(TH_ * TW_ == 128, "a block owns 128 positions of each column parity");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+  unsigned char* At = smb;                               // [IHv][GWv] pixels
+  unsigned char* Bt = smb + IHv * GWv * PB;              // [2 buffers][TG taps][32 rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int pg = wave & 3, E = wave >> 2;                // E = column parity of this wave half
+  const int c4 = tid & 7;
+  const int NU = E ? 4 : 5, NT = KH * NU;
+  const int Wp = (d.Win + 1 - E) / 2;                    // input columns of this parity
+  const int px0 = tid >> 3;
+  auto tile_pos = [&](int tile, int& sq, int& h0, int& m0) {
+    const int tw = tile % tiles_w, rest = tile / tiles_w;
+    const int th = rest % tiles_h;
+    sq = rest / tiles_h;
+    h0 = th * TH_;
+    m0 = tw * TW_;
+  };
+  auto load_patch = [&](int tile, f32x4 (&pf)[NCHK]) {
+    int sq, h0, m0;
+    tile_pos(tile, sq, h0, m0);
+    const float* org = d.x + (long long)sq * d.x_seq + (long long)(h0 - 1) * d.x_line + (long long)(m0 - 2) * C + c4 * 4;
+#pragma unroll
+    for (int q = 0; q < NCHK; ++q) {
+      const int px = px0 + 64 * q;
+      const int r = div_small<GWv>(px), xc = px - r * GWv;
+      const int h = h0 - 1 + r, c = m0 - 2 + xc;
+      const bool ok = px < IHv * GWv && h >= 0 && h < d.H && c >= 0 && c < d.Wout;
+      pf[q] = *reinterpret_cast<const f32x4*>(ok ? org + (long long)r * d.x_line + xc * C : c6_zero);
+    }
+  };
+  auto store_patch = [&](const f32x4 (&pf)[NCHK]) {
+#pragma unroll
+    for (int q = 0; q < NCHK; ++q) {
+      const int px = px0 + 64 * q;
+      if (px < IHv * GWv) store_px3(At + px * PB + c4 * 8, pf[q]);
+    }
+  };
+  // weights of group g: taps 2g, 2g+1 of parity 0 (slots 0, 1) and of parity 1 (slots 2, 3); tap index
+  // ti of parity e -> weight tile (ti / nu) * 9 + e + 2 * (ti % nu); image rows = (tile, ci), 192 bytes each
+  const unsigned char* wimg = reinterpret_cast<const unsigned char*>(d.w);
+  int wsrc[3], wdst[3], wslot[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = tid + 512 * k;
+    const int u = c / WCH, rem = c - u * WCH;
+    const int row = rem / 12, part = rem - row * 12;
+    wslot[k] = u;
+    wsrc[k] = row * 192 + part * 16;
+    wdst[k] = u * WBB + row * PB + part * 16;
+  }
+  auto load_w = [&](int g, u32x4 (&wn)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = wslot[k] >> 1, nu = e ? 4 : 5, nt = KH * nu;
+      int ti = 2 * g + (wslot[k] & 1);
+      ti = ti < nt ? ti : nt - 1;
+      const int dh = e ? ti >> 2 : (ti * 13) >> 6;        // ti / nu for ti < 15 without a division
+      const int tile_w = dh * KW + e + 2 * (ti - dh * nu);
+      wn[k] = *reinterpret_cast<const u32x4*>(wimg + (long long)tile_w * (C * 192) + wsrc[k]);
+    }
+  };
+  auto store_w = [&](int buf, const u32x4 (&wn)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(Bt + buf * (TG * WBB) + wdst[k]) = wn[k];
+  };
+  int ph, pw;
+  px_of_row<TW_>(pg, li, ph, pw);
+  const unsigned char* Ap = At + ((ph + 2) * GWv + pw + 4) * PB + hh * 16;
+  const unsigned char* Bp = Bt + (E * 2) * WBB + li * PB + hh * 16;
+  const bool msk = d.mask_src != nullptr, fm = d.fm_ref != nullptr;
+  const float fmw = fm ? d.fm_w * (d.fm_wdev ? d.fm_wdev[0] : 1.f) : 0.f;
+  float cs = 0.f;
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  u32x4 wn[3];                                  // weight pipeline as in the forward kernel
+  {
+    f32x4 pf[NCHK];
+    load_patch(tile, pf);
+    load_w(0, wn);
+    store_patch(pf);
+    store_w(0, wn);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < ntiles;
+    f32x4 pf[NCHK];
+    load_patch(more ? nxt : tile, pf);
+    int sq, h0, m0;
+    tile_pos(tile, sq, h0, m0);
+    // (round 5) the mask of this tile's outputs is requested HERE, sixteen values per lane: read in the
+    // epilogue it put a memory round trip behind every tile's MFMAs with nothing else resident on the CU --
+    // which is why the fused leaky-ReLU backward used to lose against a separate pass over the map
+    float my[16];
+    if (msk && !fm) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        int qh, qw;
+        px_of_row<TW_>(pg, (q & 3) + 8 * (q >> 2) + 4 * hh, qh, qw);
+        const int oh = h0 + qh, om = m0 + qw;
+        const long long off = (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + li;
+        my[q] = (oh < d.H && om < Wp) ? d.mask_src[off] : 1.f;
+      }
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    // patch offset of this parity's tap ti (a literal after unrolling; E is wave-uniform)
+#define F2G_C6_GOFF(TI) ((E ? ((TI) / 4) * GWv + (TI) % 4 : ((TI) / 5) * GWv + (TI) % 5) * PB)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      load_w(g + 1 < NG ? g + 1 : 0, wn);
+      const int buf = g & 1;                    // (NG is even: group 0 is always in buffer 0)
+#pragma unroll
+      for (int u2 = 0; u2 < 2; ++u2)
+        if (2 * g + u2 < NT) tap6(Ap - F2G_C6_GOFF(2 * g + u2), Bp + (buf * TG + u2) * WBB, acc0, acc1);
+      store_w(buf ^ 1, wn);
+      __syncthreads();
+    }
+#undef F2G_C6_GOFF
+    // ---- epilogue: optional leaky-ReLU backward of the layer below (+ feature-matching term)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      int qh, qw;
+      px_of_row<TW_>(pg, (q & 3) + 8 * (q >> 2) + 4 * hh, qh, qw);
+      const int oh = h0 + qh, om = m0 + qw;
+      if (oh < d.H && om < Wp) {
+        const long long off = (long long)sq * d.y_seq + (long long)oh * d.y_line + (long long)(2 * om + E) * C + li;
+        float v = acc0[q] + acc1[q];
+        if (msk) {
+          const float y = fm ? d.mask_src[off] : my[q];
+          if (fm) {
+            const float dl = y - d.fm_ref[off];
+            v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+          }
+          v *= y > 0.f ? 1.f : d.mask_slope;
+        }
+        cs += v;
+        d.y[off] = v;
+      }
+    }
+    if (more) store_patch(pf);
+    __syncthreads();
+  }
+  if (d.colsum) {
+    cs += __shfl_xor(cs, 32);
+    if (hh == 0) atomicAdd(d.colsum + li, cs);
   }
 }
 
@@ -865,6 +1055,23 @@ int f2g_conv32_dgrad6_launch(const f2g_conv32_desc* d, hipStream_t st) {
     attr = true;
   }
   const int grid = (int)(nt < 256 ? nt : 256);
+  if (d->mask_src) {      // masked: the narrow epilogue with the prefetched mask (see conv32_s2_dgrad6m_kernel)
+    static bool attrm = false;
+    if (!attrm) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad6m_kernel<8, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dgrad6_smem<8, 16>()));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_s2_dgrad6m_kernel<16, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dgrad6_smem<16, 8>()));
+      attrm = true;
+    }
+    if (tall)
+      hipLaunchKernelGGL((conv32_s2_dgrad6m_kernel<16, 8>), dim3(grid), dim3(512), (dgrad6_smem<16, 8>()), st, *d,
+                         tiles_w, tiles_h, (int)nt);
+    else
+      hipLaunchKernelGGL((conv32_s2_dgrad6m_kernel<8, 16>), dim3(grid), dim3(512), (dgrad6_smem<8, 16>()), st, *d,
+                         tiles_w, tiles_h, (int)nt);
+    return f2g_check_launch();
+  }
   if (tall)
     hipLaunchKernelGGL((conv32_s2_dgrad6_kernel<16, 8>), dim3(grid), dim3(512), (dgrad6_smem<16, 8>()), st, *d,
                        tiles_w, tiles_h, (int)nt);

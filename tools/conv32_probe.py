@@ -45,17 +45,25 @@ for H, nb in ((47, 1025), (94, 513), (188, 257)) if ONLY in ("", "dgrad") else (
         Win = edges[b + 1] - edges[b]
         for layer in range(3):
             Wout = (Win - 1) // 2 + 1
-            S = 64                      # the G-step's backward runs on the generated half only
+            # MASK=1: the D-step's form (both halves, leaky-ReLU mask + bias sums fused); default: the G-step's
+            # (generated half only, plain)
+            MASK = os.environ.get("MASK", "0") == "1"
+            S = 128 if MASK else 64
             gy = torch.randn(S * H * Wout, 32, device=dev)
             wT = torch.randn(27, 32, 32, device=dev) * 0.05
             gx = torch.empty(S * H * Win, 32, device=dev)
-            t = timeit(lambda: ops.conv32_s2_dgrad(gy, S, H, Win, Wout, wT, gx))
+            if MASK:
+                ym = torch.randn(S * H * Win, 32, device=dev)
+                csum = torch.zeros(32, device=dev)
+                t = timeit(lambda: ops.conv32_s2_dgrad(gy, S, H, Win, Wout, wT, gx, mask=(ym, 0, 0.1), colsum=csum))
+            else:
+                t = timeit(lambda: ops.conv32_s2_dgrad(gy, S, H, Win, Wout, wT, gx))
             fl = 2.0 * S * H * Wout * 32 * 864
             tot_t += t; tot_f += fl
             print(f"dgrad H={H:3d} Win={Win:3d}: {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF", flush=True)
             Win = Wout
 if tot_t:
-    print(f"all 45 data-gradient launches of a pass (S = 64): {tot_t*1e3:.2f} ms, {tot_f/tot_t/1e12:.1f} TFLOP/s")
+    print(f"all 45 data-gradient launches of a pass (S = {128 if os.environ.get('MASK', '0') == '1' else 64}): {tot_t*1e3:.2f} ms, {tot_f/tot_t/1e12:.1f} TFLOP/s")
 
 # ---- weight gradient at the same shapes (D-step: both halves, S = 128)
 tot_t = tot_f = 0.0
