@@ -552,7 +552,7 @@ X6F = int(_os.environ.get("F2G_X6F", "2"))
 # short reductions: K >= 384, >= 384 columns, >= 180 tiles; same-box step 183.4 -> 178.2 ms, profiles/r05_x6_rules.txt)
 X6F_MIN_K = int(_os.environ.get("F2G_X6F_MIN_K", "384"))
 X6F_MIN_N = int(_os.environ.get("F2G_X6F_MIN_N", "384"))
-X6F_TALL_ROWS = int(_os.environ.get("F2G_X6F_TALL_ROWS", "65536"))
+X6F_TALL_ROWS = int(_os.environ.get("F2G_X6F_TALL_ROWS", "50000"))     # (round 5: the G-step halves of the MPD layer-3 data gradients too)
 X6F_MIN_TILES = int(_os.environ.get("F2G_X6F_MIN_TILES", "180"))
 # long reductions over a PLAIN activation matrix (the generator's K = 2304 GEMMs): below this K the in-kernel
 # split instead of an image pass (f2g_split_bf16x3: 10 bytes per element) in front of the image kernel
