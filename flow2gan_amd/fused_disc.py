@@ -170,8 +170,11 @@ def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=Tru
     One forward-form GEMM per stride residue against the cached re-laid weights."""
     Cin, K = w.shape[1], w.shape[2] * w.shape[3]
     dev = g_pre.device
-    # (bf16x6 mode: the gradient map's image for the data gradient of the layer below)
-    gx = _halo_rows(S, Hin, Cin, dev, x3=(Cin >= 128)) if out_halo else ops.empty(S * Hin, Cin, device=dev)
+    # (bf16x6 mode: the gradient map's image for the data gradient of the layer below -- only where that GEMM
+    # reads images: its residues reduce over at most two taps x Cin, and below X6_MIN_K the kernel splits the
+    # fp32 map itself; the 512-channel map's image was written for nobody: 192 KB per 256 x 128 tile)
+    want_img = 2 * Cin >= ops.X6_MIN_K
+    gx = _halo_rows(S, Hin, Cin, dev, x3=want_img) if out_halo else ops.empty(S * Hin, Cin, device=dev)
     for rho, j0, nt, e0, Lq in _residues(K, stride, pad, Hin):
         if Lq == 0:
             continue
@@ -187,7 +190,7 @@ def _conv1d_dgrad(g_pre, S, Hout, Cout, w, stride, pad, Hin, g_off=0, g_halo=Tru
             rm = (Lq, Hin * Cin, stride * Cin, rho * Cin)
         # mask / fm / colsum: leaky-ReLU backward of the layer whose output gradient this is (every
         # element of gx is written by exactly one stride residue)
-        gemm(A, mat(wq), gx, rowmap=rm, mask=mask, fm=fm, colsum=colsum, x3_out=out_halo and Cin >= 128)
+        gemm(A, mat(wq), gx, rowmap=rm, mask=mask, fm=fm, colsum=colsum, x3_out=out_halo and want_img)
     return gx
 
 
