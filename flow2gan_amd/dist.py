@@ -288,14 +288,15 @@ class GradReducer:
             # parameter of the bucket got a gradient -- nothing to launch in front of the collective);
             # only a partially fired bucket writes its pattern (rare: a branch without gradient)
             if len(b.fired) != len(b.params):
-                pat = torch.tensor([1.0 if id(p) in b.fired else 0.0 for p in b.params], dtype=b.flat.dtype)
-                if b.flat.is_cuda:
-                    pat = pat.pin_memory()
+                # (one pinned staging buffer per bucket, allocated on its first partial send: a pinned
+                # allocation per send would synchronise the device under the overlapped backward)
+                pat = b.flag_staging()
+                for i, p in enumerate(b.params):
+                    pat[i] = 1.0 if id(p) in b.fired else 0.0
                 b.flat[b.n:].copy_(pat, non_blocking=True)
-                b.keep = pat                      # (alive until the copy has run)
             dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
             if world > 1:
-                if b.flat.is_cuda:
+                if b.hip_fp32:
                     from . import ops
                     ops.call("f2g_scale", ops.ptr(b.flat), 1.0 / world, b.n)      # one launch behind the collective
                 else:
@@ -457,6 +458,20 @@ class _Bucket:
         self.fired: set = set()
         self.ready = False
         self.sent = False
+        # f2g_bucket_arm / f2g_scale are float kernels: only fp32 arenas on the GPU take them (any other
+        # parameter dtype keeps the dtype-agnostic zero_ / fill_ / div_)
+        self.hip_fp32 = self.flat.is_cuda and self.flat.dtype == torch.float32
+        self._staging = None
+
+    def flag_staging(self) -> torch.Tensor:
+        """Host buffer of the "used" flags of a partially fired bucket (pinned for CUDA arenas), reused by
+        every send: a step's copy has run before the next step's arm() -- finish() waits for the
+        communication stream -- so one buffer per bucket is enough."""
+        if self._staging is None:
+            self._staging = torch.empty(len(self.params), dtype=self.flat.dtype)
+            if self.flat.is_cuda:
+                self._staging = self._staging.pin_memory()
+        return self._staging
 
 
 class _Plan:
@@ -492,7 +507,7 @@ class _Plan:
         self.echo = set()
         self.real = set()
         for b in self.buckets:
-            if b.flat.is_cuda:       # gradients = 0, "used" flags = 1: one launch per arena
+            if b.hip_fp32:           # gradients = 0, "used" flags = 1: one launch per arena
                 from . import ops
                 ops.call("f2g_bucket_arm", ops.ptr(b.flat), b.n, len(b.params))
             else:

@@ -228,9 +228,13 @@ class CondEncoderFn(GradAwareFunction):
     """mel (B, n_mels, Fm) -> condition rows (B*Fm, channels)."""
 
     @staticmethod
-    def forward(ctx, mel, training: bool, *params):
+    def forward(ctx, mel, training: bool, lens_cpu, *params):
+        """lens_cpu: valid frames per item (the `mask` of modules.py:524-542; the generator calls
+        the encoder without one, generator.py:312) or None."""
         dev = mel.device
         B, nm, Fm = mel.shape
+        lens = None if lens_cpu is None else torch.tensor([int(v) for v in lens_cpu], dtype=torch.int32,
+                                                          device=dev)
         w_in, b_in, ls_in, beta_in = params[:4]
         Cc = w_in.shape[0]
         nblk = (len(params) - 4) // len(BLOCK_KEYS)
@@ -249,7 +253,7 @@ class CondEncoderFn(GradAwareFunction):
         saved = []
         for bp in blks:
             fn = _limit_draw(training)
-            y, z, a = block_fwd(bp, x, B, Fm, None, keep=_keep(ctx))
+            y, z, a = block_fwd(bp, x, B, Fm, lens, keep=_keep(ctx))
             flags.append((fn, _limit_draw(training)))
             saved.append((x, z, a))
             x = y
@@ -258,6 +262,7 @@ class CondEncoderFn(GradAwareFunction):
             ctx.params = params
             ctx.dims = (B, nm, Fm, Cc)
             ctx.flags = flags
+            ctx.lens = lens
         return x
 
     @staticmethod
@@ -275,7 +280,7 @@ class CondEncoderFn(GradAwareFunction):
         for i in reversed(range(nblk)):
             x, z, a = saved[i]
             fn, fs = ctx.flags[1 + i]
-            g, gb = block_bwd(blks[i], x, z, a, g, B, Fm, None, fn, fs)
+            g, gb = block_bwd(blks[i], x, z, a, g, B, Fm, ctx.lens, fn, fs)
             grads_blocks[i] = gb
         g_beta, g_ls, g_bin, g_wp = ops.zeros_many([(Cc,), (1,), (Cc,), (Cc, 3 * nm)], dev)   # (one fill)
         gh0 = ops.empty(rows, Cc, device=dev)
@@ -286,7 +291,21 @@ class CondEncoderFn(GradAwareFunction):
         ops.wgrad(gh0, Cc, gh0.stride(0), win1d(melr, B, Fm, nm, Fm, 1, 1, 3), g_wp)
         g_win = ops.empty(Cc, nm, 3, device=dev)
         ops.permute4(g_win, g_wp, (Cc, nm, 3, 1), (3 * nm, 1, nm, 0))
-        out = [None, None, g_win, g_bin, g_ls.reshape(()), g_beta]
+        g_mel = None
+        if ctx.needs_input_grad[0]:
+            # d mel (leaf API only: the generator's mel carries no gradient): the k = 3 conv's data gradient
+            # = window gradients (rows, 3 * n_mels) folded back over the three taps (row f + tap - 1)
+            gw = ops.empty(rows, 3 * nm, device=dev)
+            gemm(mat(gh0, rows, Cc), mat(wp), gw, form=1)
+            gm = ops.zeros(rows, nm, device=dev)
+            for tap in range(3):
+                sh = tap - 1
+                f0, n = max(0, -sh), Fm - abs(sh)
+                if n > 0:
+                    ops.copy3(gm, Fm * nm, nm, gw, Fm * 3 * nm, 3 * nm, B, n, nm, accumulate=True,
+                              out_offset=(f0 + sh) * nm, in_offset=f0 * 3 * nm + tap * nm)
+            g_mel = ops.rows_to_bct(ops.empty(B, nm, Fm, device=dev), gm, B, nm, Fm)
+        out = [g_mel, None, None, g_win, g_bin, g_ls.reshape(()), g_beta]
         for gb in grads_blocks:
             out += gb
         ctx.saved = None
@@ -417,14 +436,18 @@ class CondPathFn(GradAwareFunction):
 # modules.py:682-721): STFT (windowed-DFT GEMM) -> in_proj -> in_norm -> 8 blocks -> out_proj ->
 # mask -> inverse DFT GEMM -> overlap-add, accumulated into one (B, T) prediction.
 # =====================================================================================
-def branch_params(est) -> list:
-    d = est.decoder
+def decoder_params(d) -> list:
+    """Everything of a ConvNeXtDecoder outside its condition path (cond_path_params)."""
     p = [d.in_proj.weight, d.in_proj.bias, d.in_norm.log_scale, d.in_norm.bias,
          d.time_mlp[0].weight, d.time_mlp[0].bias, d.time_mlp[2].weight, d.time_mlp[2].bias,
          d.out_proj.weight, d.out_proj.bias]
     for blk in d.blocks:
         p += block_params(blk) + [blk.time_embed_proj.weight, blk.time_embed_proj.bias]
     return p
+
+
+def branch_params(est) -> list:
+    return decoder_params(est.decoder)
 
 
 N_BRANCH_HEAD = 10
@@ -508,6 +531,28 @@ def _time_path(bv: _BranchView, t):
     te_all = ops.empty(n, bv.nblk * bv.C, device=dev)
     gemm(mat(te), mat(tew), te_all, bias=teb)
     return emb, th, ts, te, tew, te_all
+
+
+def time_path_bwd(bv: _BranchView, tp, g_te_all, B: int, acc):
+    """Backward of _time_path: g_te_all (B, nblk * C) -> the six parameter-gradient accumulators
+    `acc` = (g_tew, g_teb, g_tb2, g_tw2, g_tb0, g_tw0), zero-initialised by the caller (t itself
+    needs no gradient)."""
+    emb, th, ts, te, tew, _ = tp
+    g_tew, g_teb, g_tb2, g_tw2, g_tb0, g_tw0 = acc
+    dev = g_te_all.device
+    Dt, Ht, NC = bv.Dt, bv.Ht, bv.nblk * bv.C
+    ops.colsum(g_teb, g_te_all, B, NC)
+    ops.wgrad(g_te_all, NC, NC, mat(te, B, Dt), g_tew)
+    g_te = ops.empty(B, Dt, device=dev)
+    gemm(mat(g_te_all, B, NC), mat(tew), g_te, form=1)
+    ops.colsum(g_tb2, g_te, B, Dt)
+    ops.wgrad(g_te, Dt, Dt, mat(ts, B, Ht), g_tw2)
+    g_ts = ops.empty(B, Ht, device=dev)
+    gemm(mat(g_te, B, Dt), mat(bv.tw2), g_ts, form=1)
+    g_th = ops.empty(B, Ht, device=dev)
+    ops.silu_bwd(g_th, g_ts, th)
+    ops.colsum(g_tb0, g_th, B, Ht)
+    ops.wgrad(g_th, Ht, Ht, mat(emb, B, Dt), g_tw0)
 
 
 def time_paths_ahead(flat, nparams, t_all, n_steps: int):
@@ -760,19 +805,8 @@ def _branch_backward(bv: _BranchView, meta, sv, x_shape, cproj, g_pred, wbranch_
         ops.frames_fold(gxf, g_x, B, F, N, hop, T, accumulate_gx)
         if lanes is not None:
             lanes.chain_leave()
-    # time path
-    ops.colsum(g_teb, g_te_all, B, NC)
-    ops.wgrad(g_te_all, NC, NC, mat(sv["te"], B, Dt), g_tew)
-    g_te = ops.empty(B, Dt, device=dev)
-    gemm(mat(g_te_all, B, NC), mat(sv["tew"]), g_te, form=1)
-    ops.colsum(g_tb2, g_te, B, Dt)
-    ops.wgrad(g_te, Dt, Dt, mat(sv["ts"], B, Ht), g_tw2)
-    g_ts = ops.empty(B, Ht, device=dev)
-    gemm(mat(g_te, B, Dt), mat(bv.tw2), g_ts, form=1)
-    g_th = ops.empty(B, Ht, device=dev)
-    ops.silu_bwd(g_th, g_ts, sv["th"])
-    ops.colsum(g_tb0, g_th, B, Ht)
-    ops.wgrad(g_th, Ht, Ht, mat(sv["emb"], B, Dt), g_tw0)
+    time_path_bwd(bv, (sv["emb"], sv["th"], sv["ts"], sv["te"], sv["tew"], sv["te_all"]), g_te_all, B,
+                  (g_tew, g_teb, g_tb2, g_tw2, g_tb0, g_tw0))
     out = [g_win.reshape(Cc, Cin, 1), g_bin, g_ls.reshape(()), g_beta, g_tw0, g_tb0, g_tw2, g_tb2,
            g_wout.reshape(Cin, Cc, 1), g_bout]
     for j in range(bv.nblk):

@@ -38,6 +38,21 @@ class GAN(nn.Module):
                                hop_length=n_fft // 4, n_mels=n_mels, power=1))
 
     # ---- individual terms, same names as the reference (gan.py:57-99) -------------------
+    def discriminator_loss(self, score_real: List[Tensor], score_fake: List[Tensor]) -> Tensor:
+        """sum_d mean relu(1 - s_real) + mean relu(1 + s_fake)   (gan.py:57-66) on `f2g_hinge_loss`."""
+        from ..leaf import discriminator_loss
+        return discriminator_loss(score_real, score_fake)
+
+    def generator_loss(self, score_fake: List[Tensor]) -> Tensor:
+        """sum_d mean relu(1 - s_fake)   (gan.py:68-75)."""
+        from ..leaf import generator_loss
+        return generator_loss(score_fake)
+
+    def feature_matching_loss(self, fmap_real: List[List[Tensor]], fmap_fake: List[List[Tensor]]) -> Tensor:
+        """sum_d sum_layers mean |f_real.detach() - f_fake|   (gan.py:77-87) on `f2g_l1_loss`."""
+        from ..leaf import feature_matching_loss
+        return feature_matching_loss(fmap_real, fmap_fake)
+
     def mel_recon_loss(self, real: Tensor, fake: Tensor) -> Tensor:
         specs = tuple((m.n_fft, m.hop_length, m.mel_scale.fb) for m in self.mel_recon_modules)
         return FD.MelReconLossFn.apply(real, fake, specs)

@@ -132,7 +132,7 @@ class BaseAudioGenerator(nn.Module):
         B, _, Fm = mel.shape
         if not hasattr(self, "cond_encoder"):      # generator.py:311-314: the mel itself
             return self._as_cond_rows(mel)
-        rows = fused.CondEncoderFn.apply(mel, self.training,
+        rows = fused.CondEncoderFn.apply(mel, self.training, None,
                                          *fused.cond_encoder_params(self.cond_encoder))
         return CondRows(rows, B, Fm)
 

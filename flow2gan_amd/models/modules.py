@@ -2,8 +2,9 @@
 names, shapes, init and state-dict keys (reference flow2gan/models/modules.py).
 
 The fused training / inference path (flow2gan_amd/fused.py) reads these parameters directly
-and runs hand-written HIP kernels in a channels-last layout; the leaf `forward`s below are the
-drop-in (batch, channels, time) entry points of the reference and run on the same kernels.
+and runs hand-written HIP kernels in a channels-last layout; every leaf `forward` below is the
+drop-in (batch, channels, time) entry point of its reference counterpart -- same arguments, same
+return values, autograd included -- and dispatches onto the same kernels (flow2gan_amd/leaf.py).
 Nothing here falls back to ATen compute.
 """
 from __future__ import annotations
@@ -80,7 +81,19 @@ class STFT(nn.Module):
     def __init__(self, n_fft: int, hop_length: int):
         super().__init__()
         self.n_fft, self.hop_length = n_fft, hop_length
+        self.win_length, self.onesided = n_fft, True
         self.register_buffer("window", torch.hann_window(n_fft))
+
+    def forward(self, audio: Tensor, audio_lens: Optional[Tensor] = None):
+        """(B, T) -> (complex (B, n_fft/2 + 1, 1 + T // hop), frame counts or None) -- torch.stft with
+        center / reflect padding and the periodic hann window, on the LDS-butterfly FFT kernel."""
+        from ..leaf import stft
+        spec = stft(audio, self.n_fft, self.hop_length)
+        if audio_lens is None:
+            return spec, None
+        spec_lens = 1 + torch.div(audio_lens, self.hop_length, rounding_mode="floor")
+        assert spec.shape[2] == int(spec_lens.max())
+        return spec, spec_lens
 
 
 class ISTFT(nn.Module):
@@ -89,7 +102,29 @@ class ISTFT(nn.Module):
     def __init__(self, n_fft: int, hop_length: int):
         super().__init__()
         self.n_fft, self.hop_length = n_fft, hop_length
+        self.win_length, self.onesided, self.return_complex = n_fft, True, False
         self.register_buffer("window", torch.hann_window(n_fft))
+
+    def forward(self, spec: Tensor) -> Tensor:
+        """complex (B, n_fft/2 + 1, F) -> (B, hop * (F - 1)): torch.istft(center=True)."""
+        from ..leaf import istft
+        return istft(spec, self.n_fft, self.hop_length, self.window)
+
+
+class SinusoidalPosEmb(nn.Module):
+    """reference modules.py:217-232: t (B,) -> (B, dim) = [sin | cos](scale * t * f_k)."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+        assert self.dim % 2 == 0, "SinusoidalPosEmb requires dim to be even"
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, scale=1000) -> Tensor:
+        if x.ndim < 1:
+            x = x.unsqueeze(0)
+        t = x.contiguous().float()
+        return ops.time_embedding(ops.empty(t.shape[0], self.dim, device=t.device), t, self.dim, float(scale))
 
 
 class ChannelScale(nn.Module):
@@ -98,6 +133,13 @@ class ChannelScale(nn.Module):
     def __init__(self, channels: int, scale: float = 1.0):
         super().__init__()
         self.scale = nn.Parameter(torch.full((channels, 1), scale))
+
+    def forward(self, x: Tensor) -> Tensor:
+        """x (B, C, T) * scale, the scale's gradient through LimitParamValue [0.5, 1.0] with
+        probability 0.6 while training (modules.py:259-283; one Python-RNG draw per call)."""
+        from ..leaf import ChannelScaleFn
+        from ..fused import _limit_draw
+        return ChannelScaleFn.apply(x, self.scale, _limit_draw(self.training))
 
 
 class BiasNorm(nn.Module):
@@ -112,15 +154,11 @@ class BiasNorm(nn.Module):
         self.bias = nn.Parameter(torch.empty(num_channels).normal_(mean=0, std=1e-2))
         self.log_scale_min, self.log_scale_max = log_scale_min, log_scale_max
 
-    @torch.no_grad()
     def forward(self, x: Tensor) -> Tensor:
-        B, Cc, T = x.shape
-        assert Cc == self.num_channels
-        rows = ops.empty(B * T, Cc, device=x.device)
-        ops.bct_to_rows(rows, x.contiguous(), B, Cc, T)
-        ops.biasnorm_fwd(rows, rows, B * T, Cc, self.bias, self.log_scale.reshape(1))
-        out = ops.empty(B, Cc, T, device=x.device)
-        return ops.rows_to_bct(out, rows, B, Cc, T)
+        from ..leaf import BiasNormFn
+        from ..fused import _limit_draw
+        assert x.shape[1] == self.num_channels
+        return BiasNormFn.apply(x, self.bias, self.log_scale, _limit_draw(self.training))
 
 
 class ConvNeXtBlock(nn.Module):
@@ -147,6 +185,13 @@ class ConvNeXtBlock(nn.Module):
             self.time_embed_proj = nn.Linear(time_embed_channels, channels)
         self.residual_scale = ChannelScale(channels)
 
+    def forward(self, x: Tensor, cond: Optional[Tensor] = None, time_embed: Optional[Tensor] = None,
+                mask: Optional[Tensor] = None) -> Tensor:
+        """x (B, C, T), cond (B, cond_channels, T), time_embed (B, time_embed_channels), mask
+        (B, 1, T) -> (B, C, T)   (modules.py:455-495)."""
+        from ..leaf import block_forward
+        return block_forward(self, x, cond, time_embed, mask)
+
 
 class CondEncoder(nn.Module):
     """reference modules.py:498-542."""
@@ -163,6 +208,11 @@ class CondEncoder(nn.Module):
                           conv_kernel_size=conv_kernel_size, residual_scale=residual_scale)
             for _ in range(num_layers)])
 
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        """x (B, n_mels, F), mask (B, 1, F) -> (B, channels, F)   (modules.py:524-542)."""
+        from ..leaf import cond_encoder_forward
+        return cond_encoder_forward(self, x, mask)
+
 
 class ConvNeXtDecoder(nn.Module):
     """reference modules.py:545-627."""
@@ -176,6 +226,7 @@ class ConvNeXtDecoder(nn.Module):
         self.cond_channels, self.time_embed_channels = cond_channels, time_embed_channels
         self.in_proj = nn.Conv1d(in_channels, channels, kernel_size=1)
         self.in_norm = BiasNorm(channels, channel_dim=1)
+        self.time_embed = SinusoidalPosEmb(time_embed_channels)      # (parameter-free: no state-dict key)
         th = int(time_embed_channels * hidden_factor)
         self.time_mlp = nn.Sequential(nn.Linear(time_embed_channels, th), nn.SiLU(),
                                       nn.Linear(th, time_embed_channels))
@@ -188,6 +239,13 @@ class ConvNeXtDecoder(nn.Module):
                           time_embed_channels=time_embed_channels, residual_scale=residual_scale)
             for _ in range(num_layers)])
         self.out_proj = nn.Conv1d(channels, out_channels, kernel_size=1)
+
+    def forward(self, x: Tensor, cond: Tensor, t: Optional[Tensor] = None,
+                mask: Optional[Tensor] = None) -> Tensor:
+        """x (B, in_channels, F), cond (B, cond_channels, F), t (B,), mask (B, 1, F) ->
+        (B, out_channels, F)   (modules.py:590-627)."""
+        from ..leaf import decoder_forward
+        return decoder_forward(self, x, cond, t, mask)
 
 
 class AudioConvNeXt(nn.Module):
@@ -211,6 +269,28 @@ class AudioConvNeXt(nn.Module):
             hidden_factor=hidden_factor, conv_kernel_size=conv_kernel_size,
             num_layers=num_layers, residual_scale=residual_scale)
 
+    def upsample_cond(self, cond: Tensor, fft_frames: int) -> Tensor:
+        """modules.py:668-680: repeat every condition frame `cond_upsample_factor` times, then cut or
+        zero-pad to `fft_frames` (the fused path never materialises this: `f2g_dwnorm_fwd` reads row
+        f // up).  Data movement only."""
+        B, Cc, Fc = cond.shape
+        up = self.cond_upsample_factor
+        src = cond.contiguous().float()
+        rep = ops.empty(B * Cc, Fc * up, device=cond.device)       # rep[bc, f * up + r] = cond[bc, f]
+        ops.permute4(rep, src, (B * Cc, Fc, up, 1), (Fc, 1, 0, 0))
+        if Fc * up == fft_frames:
+            return rep.view(B, Cc, fft_frames)
+        out = ops.zeros(B, Cc, fft_frames, device=cond.device)    # convert_length (utils.py:235-244)
+        ops.copy3(out, fft_frames, 0, rep, Fc * up, 0, B * Cc, 1, min(Fc * up, fft_frames))
+        return out
+
+    def forward(self, audio: Tensor, cond: Tensor, t: Optional[Tensor] = None,
+                audio_lens: Optional[Tensor] = None) -> Tensor:
+        """audio (B, T), cond (B, cond_channels, cond_frames), t (B,), audio_lens (B,) -> (B, T)
+        (modules.py:682-721): one Fourier branch, the same coarse node a model evaluation runs."""
+        from ..leaf import audio_convnext_forward
+        return audio_convnext_forward(self, audio, cond, t, audio_lens)
+
 
 class LinearFilterSpectrogram(nn.Module):
     """reference modules.py:146-214: power-2 spectrogram -> linear triangular filterbank."""
@@ -224,6 +304,11 @@ class LinearFilterSpectrogram(nn.Module):
         self.spectrogram = _Window(n_fft)
         self.register_buffer("fb", linear_fbanks(n_fft // 2 + 1, 0.0, float(sample_rate // 2),
                                                  n_filter, sample_rate))
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        """(..., T) -> (..., n_filter, 1 + T // hop)   (modules.py:202-214)."""
+        from ..leaf import filterbank_spectrogram
+        return filterbank_spectrogram(waveform, self.n_fft, self.hop_length, self.fb, 2)
 
 
 class _Window(nn.Module):
@@ -252,6 +337,11 @@ class MelSpectrogram(nn.Module):
         self.spectrogram = _Window(n_fft)
         self.mel_scale = _MelScale(melscale_fbanks(n_fft // 2 + 1, 0.0, float(sample_rate // 2),
                                                    n_mels, sample_rate))
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        """(..., T) -> (..., n_mels, 1 + T // hop): |STFT| through the mel filterbank."""
+        from ..leaf import filterbank_spectrogram
+        return filterbank_spectrogram(waveform, self.n_fft, self.hop_length, self.mel_scale.fb, 1)
 
 
 class LogMelSpectrogram(nn.Module):

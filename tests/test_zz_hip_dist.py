@@ -221,3 +221,30 @@ def test_single_rank_rccl_exchange_with_lanes_matches_plain_path(tmp_path):
     worst = torch.load(tmp_path / "rccl_single.pt")
     # same kernels, same lanes; what differs is atomics' order and the arena accumulation
     assert worst["D"] < 2e-4 and worst["G"] < 2e-4, worst
+
+
+@pytest.mark.gpu
+def test_half_precision_arena_keeps_the_dtype_agnostic_path():
+    """`f2g_bucket_arm` / `f2g_scale` are float kernels: an arena of bf16 / fp16 parameters must not take
+    them (they would write 4 * n bytes + flags at float offsets into a 2 * (n + nflags)-byte buffer)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from flow2gan_amd import dist as fdist
+    guard = torch.full((4096,), 7.0, device="cuda")      # (lands behind the arena in the caching allocator's block)
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        ps = [torch.nn.Parameter(torch.ones(33, 5, device="cuda", dtype=dt)),
+              torch.nn.Parameter(torch.ones(7, device="cuda", dtype=dt))]
+        plan = fdist._Plan(ps, 1 << 30)
+        assert len(plan.buckets) == 1
+        b = plan.buckets[0]
+        assert b.hip_fp32 == (dt == torch.float32)
+        b.flat.fill_(3.0)
+        plan.arm()
+        torch.cuda.synchronize()
+        assert b.flat.dtype == dt and b.flat.numel() == 33 * 5 + 7 + 2
+        assert float(b.flat[:b.n].float().abs().max()) == 0.0
+        assert b.flat[b.n:].float().tolist() == [1.0, 1.0]
+        assert all(p.grad is v for p, v in zip(ps, b.views))
+        st = b.flag_staging()
+        assert st.dtype == dt and st.is_pinned() and b.flag_staging() is st
+    assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
