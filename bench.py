@@ -356,8 +356,8 @@ def main():
                 "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
                 # (six-product families only) what a bare stream of these MFMAs sustains on real operand data:
                 # the spec peak assumes clocks the bf16 pipe does not hold under load
-                **({"sustained": {"peak": 267.0, "frac": round(dfl / dsec / 1e12 / 267.0, 4),
-                                  "source": "bare six-MFMA stream, tools/micro/mfma_peak.hip (power-limited clocks)"}}
+                **({"sustained": {"peak": 291.0, "frac": round(dfl / dsec / 1e12 / 291.0, 4),
+                                  "source": "bare six-MFMA stream on N(0,1) bf16 operands, tools/micro/x6_stream_peak.hip -> profiles/r06_x6_stream_peak.txt (1.67 GHz effective: power-limited)"}}
                    if peak == PEAK_BF16_MFMA_TFLOPS / 6.0 else {}),
                 "launches_per_step": dl,
                 "avg_launch_us": round(1e6 * dsec / dl, 1),
