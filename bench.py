@@ -287,6 +287,7 @@ def main():
         """`roofline` object of one GEMM mode (the precision is already set): dominant kernel family of a
         serialised per-launch HIP-event pass, its PMC traffic, the MFMA class by family, the HBM class."""
         timer = event_pass()
+        timer.report_by_epilogue = bool(os.environ.get("F2G_GEMM_REPORT_EPI"))
         n, flops, secs = timer.summary()
         if os.environ.get("F2G_GEMM_REPORT") and rank == 0 and mode == args.gemm:
             print(timer.report(int(os.environ["F2G_GEMM_REPORT"])), file=sys.stderr)

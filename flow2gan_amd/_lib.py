@@ -42,7 +42,7 @@ class Epilogue(C.Structure):
         ("prelu_slope", C.c_void_p), ("prelu_out", C.c_void_p), ("ld_prelu_out", C.c_int64),
         ("mask_src", C.c_void_p), ("fm_ref", C.c_void_p), ("fm_wdev", C.c_void_p),
         ("mask_slope", C.c_float), ("fm_w", C.c_float),
-        ("x3_out", C.c_void_p),
+        ("x3_out", C.c_void_p), ("colsum_part_ld", C.c_int64),
     ]
 
 
@@ -226,6 +226,7 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
                                  "f2g_gemm_lean_ok", "f2g_gemm_wgrad_lean", "f2g_fused_mlp_ok",
                                  "f2g_dwnorm_bwd_workspace", "f2g_split_bf16x3_bytes", "f2g_gemm_x6_ok",
+                                 "f2g_gemm_colsum_part_rows", "f2g_set_option", "f2g_get_option",
                                  "f2g_dwconv_bwd_workspace", "f2g_sadam_chunk_elems"])
 
 
@@ -255,10 +256,16 @@ def _load():
     lib.f2g_split_bf16x3_bytes.restype = C.c_int64
     lib.f2g_gemm_x6_ok.argtypes = [C.POINTER(GemmDesc)]
     lib.f2g_gemm_x6_ok.restype = C.c_int
+    lib.f2g_gemm_colsum_part_rows.argtypes = [C.POINTER(GemmDesc)]
+    lib.f2g_gemm_colsum_part_rows.restype = C.c_int32
     lib.f2g_fused_mlp_ok.argtypes = [C.c_int32, C.c_int32]
     lib.f2g_fused_mlp_ok.restype = C.c_int
     lib.f2g_sadam_chunk_elems.argtypes = []
     lib.f2g_sadam_chunk_elems.restype = C.c_int32
+    lib.f2g_set_option.argtypes = [C.c_char_p, C.c_int32]
+    lib.f2g_set_option.restype = C.c_int
+    lib.f2g_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
+    lib.f2g_get_option.restype = C.c_int
     lib.f2g_version.restype = C.c_char_p
     lib.f2g_last_error.restype = C.c_char_p
     return lib
@@ -269,6 +276,22 @@ lib = _load()
 
 def version() -> str:
     return lib.f2g_version().decode()
+
+
+def set_option(name: str, value: int) -> int:
+    """Set a dispatch option of the library (include/flow2gan_hip.h: f2g_set_option); returns the previous
+    value so that a test can restore it."""
+    old = C.c_int32()
+    if lib.f2g_get_option(name.encode(), C.byref(old)) or lib.f2g_set_option(name.encode(), int(value)):
+        raise F2GError(f"unknown library option {name!r}")
+    return old.value
+
+
+def get_option(name: str) -> int:
+    v = C.c_int32()
+    if lib.f2g_get_option(name.encode(), C.byref(v)):
+        raise F2GError(f"unknown library option {name!r}")
+    return v.value
 
 
 def stream_ptr() -> int:

@@ -8,6 +8,30 @@
 #include "../../include/flow2gan_hip.h"
 
 int f2g_check_launch();
+// Library options (capi.hip): every tunable the dispatch looks at is one int of a table that is initialised
+// ONCE -- defaults, then `F2G_OPTS="name=value,..."` from the environment -- and changed afterwards only through
+// f2g_set_option (tests, lab tools).  No getenv on a launch path.
+enum f2g_opt_id {
+  F2G_OPT_LEAN,             // 1: the lean GEMM kernels (0: generic kernels everywhere they can stand in)
+  F2G_OPT_LEAN_TALL,        // bf16 lean instances on 256 x 128 tiles: 0 never, 1 K >= 640 on >= 400 tall tiles, 2 always
+  F2G_OPT_LEAN_TAP,         // 1: tap-reusing split-bf16 instance for stride-1 conv windows
+  F2G_OPT_LEAN_WGRAD,       // exact-fp32 K-major weight gradient: 0 off, 1 reductions >= 4096 rows per block, 2 always
+  F2G_OPT_X6_TAP,           // 1: tap-walking precision-3 kernel for stride-1 conv windows
+  F2G_OPT_X6_WIDE,          // 1: wide (LDS-turned) epilogue of the precision-3 kernels
+  F2G_OPT_X6P,              // gemm_x6p_kernel: 0 off, 1 chip-filling grids, 2 whatever the grid (tests)
+  F2G_OPT_W6T,              // 1: tap-walking precision-3 weight gradients
+  F2G_OPT_DETERMINISTIC,    // 1: no split / stream-K on the library's own initiative (bit-reproducible forward)
+  F2G_OPT_STREAMK,          // lean kernel stream-K: 0 off, 1 latency regime, 2 every under-filled grid
+  F2G_OPT_CONV2CH_V2,       // 1: persistent first-MRD-layer kernels
+  F2G_OPT_CONV32_V2,        // 1: persistent exact-fp32 band-conv forward / data gradient
+  F2G_OPT_CONV32_WGRAD_V2,  // 1: persistent exact-fp32 band-conv weight gradient
+  F2G_OPT_MLP_RT,           // fused block kernel: rows / 32 per tile (0: the launch decides)
+  F2G_OPT_MLP_SPLIT,        // fused MLP: parts of the hidden dimension (0 / 1: never split)
+  F2G_OPT_MULTI_RT384,      // multi-branch launch: rows / 32 per tile of the 384-channel entries
+  F2G_OPT_MULTI_RT512,      // ... of the 512-channel entries
+  F2G_OPT_COUNT
+};
+int f2g_opt(int id);
 // narrow.hip: VALU path for <= 4 output columns / gradient rows; 1 = handled, 0 = not applicable
 int f2g_gemm_narrow(const f2g_gemm_desc& d, hipStream_t st);
 void f2g_set_error(const char* msg);
@@ -17,10 +41,6 @@ int f2g_launch_x6p(const f2g_gemm_desc& d, int taps, long long a_extent, hipStre
 // tap-walking fp32-class weight gradient of a stride-1 five-tap conv over halo maps (gemm_x6p.hip)
 int f2g_leanw6t_ok(const f2g_gemm_desc& d, int split);
 int f2g_launch_leanw6t(const f2g_gemm_desc& d, int split, hipStream_t st);
-// the same schedule over row operands (plain matrices / strided single-segment windows): split = 0 images, 1 = fp32
-int f2g_x6pr_ok(const f2g_gemm_desc& d);
-int f2g_launch_x6pr(const f2g_gemm_desc& d, int split, int P0, unsigned seq, unsigned step, unsigned off,
-                    unsigned bytes, hipStream_t st);
 // elementwise.hip: out[k][c - begin[k]] += sum_r a[r, c] for up to 3 column ranges (null = skip)
 struct f2g_colsegs {
   float* out[3];

@@ -550,7 +550,7 @@ static bool conv2ch_ok(const f2g_conv2ch_desc* d) {
 extern "C" int f2g_conv2ch_fwd(const f2g_conv2ch_desc* d, f2g_stream_t stream) {
   if (!d || !d->x || !d->w || !d->y || (d->x_line & 1) || (d->x_seq & 1)) return F2G_EINVAL;
   if (!conv2ch_ok(d)) return F2G_OK;
-  static const bool persistent = !(getenv("F2G_CONV2CH_V2") && atoi(getenv("F2G_CONV2CH_V2")) == 0);
+  const bool persistent = f2g_opt(F2G_OPT_CONV2CH_V2) != 0;
   if (persistent && (long long)((d->W + TW - 1) / TW) * d->S >= 256) {   // column tiles x sequences fill the chip
     hipLaunchKernelGGL(conv2ch_fwd_p_kernel, dim3((d->W + TW - 1) / TW, d->S), dim3(256), 0, ST, *d);
     return f2g_check_launch();
@@ -568,7 +568,7 @@ extern "C" int f2g_conv2ch_wgrad(const f2g_conv2ch_desc* d, f2g_stream_t stream)
   const int ntiles = d->S * tiles_h * tiles_w;
   int per = (ntiles + 511) / 512;        // <= 512 blocks: 0.9 M atomics on 1728 addresses per launch
   if (per < 1) per = 1;
-  static const bool persistent = !(getenv("F2G_CONV2CH_V2") && atoi(getenv("F2G_CONV2CH_V2")) == 0);
+  const bool persistent = f2g_opt(F2G_OPT_CONV2CH_V2) != 0;
   if (persistent)
     hipLaunchKernelGGL(conv2ch_wgrad_p_kernel, dim3((ntiles + per - 1) / per), dim3(256), 0, ST, *d,
                        tiles_h, tiles_w, per);

@@ -1141,7 +1141,7 @@ extern "C" int f2g_conv32_s2_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) 
     attr_done = true;
   }
   const int tiles = ((d->H + TH - 1) / TH) * ((d->Wout + TW - 1) / TW);
-  static const bool persistent = !(getenv("F2G_CONV32_V2") && atoi(getenv("F2G_CONV32_V2")) == 0);
+  const bool persistent = f2g_opt(F2G_OPT_CONV32_V2) != 0;
   if (d->precision == 0 && persistent && d->x_line < (1ll << 24)) {
     // tile shape: fewer wasted output pixels wins (8 x 16 on a tie)
     auto waste = [&](int th, int tw) {
@@ -1202,7 +1202,7 @@ extern "C" int f2g_conv32_s2_dgrad(const f2g_conv32_desc* d, f2g_stream_t stream
     attr_done = true;
   }
   const int tiles = ((d->H + TH - 1) / TH) * (((d->Win + 1) / 2 + TW - 1) / TW);
-  static const bool persistent = !(getenv("F2G_CONV32_V2") && atoi(getenv("F2G_CONV32_V2")) == 0);
+  const bool persistent = f2g_opt(F2G_OPT_CONV32_V2) != 0;
   if (d->precision == 0 && persistent && d->x_line < (1ll << 24)) {
     const int Wp0 = (d->Win + 1) / 2, Wp1 = d->Win / 2;
     auto waste = [&](int th, int tw) {
@@ -1274,7 +1274,7 @@ extern "C" int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stre
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_done = true;
   }
-  static const bool persistent = !(getenv("F2G_CONV32_WGRAD_V2") && atoi(getenv("F2G_CONV32_WGRAD_V2")) == 0);
+  const bool persistent = f2g_opt(F2G_OPT_CONV32_WGRAD_V2) != 0;
   if (persistent && d->x_line < (1ll << 24)) {
     auto waste = [&](int th, int tw) {
       return (long long)((d->H + th - 1) / th * th) * ((d->Wout + tw - 1) / tw * tw);

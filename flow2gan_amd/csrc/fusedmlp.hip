@@ -561,8 +561,8 @@ int launch_fused(const f2g_fused_mlp_desc& d, hipStream_t st, const f2g_dwnorm_f
   }
   const int tiles = (d.rows + BM - 1) / BM, S = d.H / HS;
   // hidden-dimension split: as many parts as keep the grid within one round of the 256 CUs, each
-  // part at least 4 slabs long (F2G_MLP_SPLIT=1 turns it off, n forces n parts)
-  static const int env_parts = getenv("F2G_MLP_SPLIT") ? atoi(getenv("F2G_MLP_SPLIT")) : 0;
+  // part at least 4 slabs long (option mlp_split = 1 turns it off, n forces n parts)
+  const int env_parts = f2g_opt(F2G_OPT_MLP_SPLIT);
   const int forced = d.parts > 0 ? d.parts : env_parts;
   // (measured: the atomic accumulation of the partial tiles costs more than the idle CUs -- 6016 x 768:
   // 117 us whole, 127 us in two parts; 24064 x 384: 83 -> 196 us -- so the library never splits on
@@ -589,9 +589,9 @@ int launch_fused(const f2g_fused_mlp_desc& d, hipStream_t st, const f2g_dwnorm_f
 // Rows per tile.  The default tiles (64 / 96 / 128 rows at 768 / 512 / 384 channels: what the 192
 // accumulator registers hold) amortise the weight stream best, but a launch with few rows then has
 // far fewer tiles than the chip has CUs (the condition encoder: 6016 rows x 512 channels = 63 tiles):
-// smaller tiles trade weight traffic for parallelism.  F2G_MLP_RT forces rows / 32.
+// smaller tiles trade weight traffic for parallelism.  option mlp_rt forces rows / 32.
 int pick_rt(int C, int rows) {
-  static const int env_rt = getenv("F2G_MLP_RT") ? atoi(getenv("F2G_MLP_RT")) : 0;
+  const int env_rt = f2g_opt(F2G_OPT_MLP_RT);
   const int rt_max = C == 768 ? 2 : (C == 512 ? 3 : 4);
   if (env_rt > 0) {
     int r = env_rt > rt_max ? rt_max : env_rt;
@@ -690,10 +690,9 @@ extern "C" int f2g_fused_block_multi(const f2g_dwnorm_fwd_desc* wp, const f2g_fu
     if (rc) return rc;
   }
   // entries in order of decreasing cost per tile (12 C^2 FLOPs per row x 32 RT rows)
-  // rows per tile of an entry: the default tiles, or (F2G_MULTI_RT512 / F2G_MULTI_RT384 = 2) 64-row
+  // rows per tile of an entry: the default tiles, or (options multi_rt512 / multi_rt384 = 2) 64-row
   // tiles for the cheaper branches -- finer granularity at the tail of the list schedule
-  static const int rt512 = getenv("F2G_MULTI_RT512") ? atoi(getenv("F2G_MULTI_RT512")) : 3;
-  static const int rt384 = getenv("F2G_MULTI_RT384") ? atoi(getenv("F2G_MULTI_RT384")) : 4;
+  const int rt512 = f2g_opt(F2G_OPT_MULTI_RT512), rt384 = f2g_opt(F2G_OPT_MULTI_RT384);
   auto bm_of = [&](int C) { return C == 768 ? 64 : (C == 512 ? (rt512 == 2 ? 64 : 96) : (rt384 == 2 ? 64 : 128)); };
   int order[MULTI_MAX];
   for (int i = 0; i < n; ++i) order[i] = i;

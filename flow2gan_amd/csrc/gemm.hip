@@ -21,9 +21,6 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
-#include <map>
-#include <mutex>
-#include <utility>
 
 #include "common.h"
 #include "x6_epilogue.h"
@@ -950,24 +947,12 @@ __device__ __forceinline__ unsigned lean_row_offset(const f2g_operand& S, int r,
 // the taps walk over them in LDS (a lane's fragment row = its output row's staged row + tap):
 // 260-320 staged rows instead of 5 x 256 per channel slab, about half the L2 -> CU traffic of
 // the kernel that is bound by exactly that.
-// SK: 0 one tile per block, 1 stream-K with atomic seams (linear epilogues, zeroed output),
-// 2 stream-K with seam FIX-UP (any epilogue, deterministic): the tiles are dealt to the XCDs in
-// contiguous runs of whole tiles, an XCD's blocks cut its run's (tile, slab) units into equal
-// consecutive ranges and walk them from the END: a block's last tile -- when it stops short of that
-// tile's final slab -- is computed first, its accumulators written to the block's workspace slot and
-// a flag raised; its first tile comes last, and when earlier slabs of that tile belong to lower
-// blocks it waits for their flags (raised long ago: they started with exactly that tile), adds
-// their partial sums in block order and runs the normal epilogue.  A block only ever waits for
-// lower-numbered blocks of its own XCD (dispatched before it), which never wait for it.
-struct lean_sk_ws {
-  float* ws;          // [grid][128 * 128] partial tiles
-  unsigned* flags;    // [grid], holds the epoch of the launch that last filled the slot
-  unsigned epoch;
-};
-
+// SK: 0 one tile per block, 1 stream-K with atomic seams (linear epilogues, zeroed output).  (A third mode,
+// stream-K with a seam FIX-UP through a per-stream workspace, was measured flat under the launch lanes in
+// round 4 and removed in round 6: DESIGN.md section 8, "measured and dropped".)
 template <int SK, int EP, int PM, int WM = 2, bool TAP = false>
 __global__ __launch_bounds__(WM * 128, 4 / WM)
-void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb, const lean_sk_ws W) {
+void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, int upb) {
   constexpr bool P3 = PM == 1 || PM == 2, HI = PM == 2, BF = PM == 3;
   constexpr int BKE = BF ? 64 : BK;   // elements per slab
   constexpr int ES = BF ? 2 : 4;      // bytes per element
@@ -1011,21 +996,6 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   const int nt_all = K / BKE;
   const int tiles_n = (N + BN - 1) / BN;
   int u = 0, u_end = 0;
-  int fx_t0 = 0, fx_ub = 0, fx_upb = 1, fx_slot0 = 0, fx_idx = 0;   // (SK == 2)
-  if (SK == 2) {
-    const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;
-    fx_idx = blockIdx.x >> 3;
-    const long long tiles_all = (long long)((M + BM - 1) / BM) * tiles_n;
-    fx_t0 = (int)(tiles_all * xcd / 8);
-    const int t1 = (int)(tiles_all * (xcd + 1) / 8);
-    const int units = (t1 - fx_t0) * nt_all;
-    fx_upb = (units + per - 1) / per;
-    if (upb == 1) fx_upb = (fx_upb + nt_all - 1) / nt_all * nt_all;   // (F2G_SKFIX=3: whole tiles per block, no seams)
-    fx_ub = fx_idx * fx_upb;
-    u_end = fx_ub + fx_upb < units ? fx_ub + fx_upb : units;   // walked downwards
-    fx_slot0 = xcd * per;
-    if (fx_ub >= u_end) return;
-  }
   if (SK == 1) {
     const int G = gridDim.x;
     const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -1039,23 +1009,6 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
   while (more) {
     int m0, n0, s0, nt;
     bool first, partial;
-    bool fx_last = true;
-    int fx_tl = 0;
-    if (SK == 2) {
-      fx_tl = (u_end - 1) / nt_all;
-      const int tstart = fx_tl * nt_all;
-      const int sb = fx_ub > tstart ? fx_ub : tstart;
-      s0 = sb - tstart;
-      nt = u_end - sb;
-      first = s0 == 0;
-      fx_last = u_end == tstart + nt_all;
-      partial = false;
-      const int tg = fx_t0 + fx_tl, tm = tg / tiles_n;
-      m0 = tm * BM;
-      n0 = (tg - tm * tiles_n) * BN;
-      u_end = sb;
-      more = u_end > fx_ub;
-    } else
     if (!SK) {
       tile_of_block(BM, BN, m0, n0);
       const int kbeg = blockIdx.z * kchunk;
@@ -1434,58 +1387,7 @@ void gemm_lean_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk, in
     }
 
     }
-    if constexpr (SK == 2) {
-      // seam of the fix-up stream-K: 64 accumulators per thread as 16 float4 rows of 256 threads
-      // The partial tiles and the flags move as RELAXED agent-scope accesses: written through to / read
-      // from the level all XCDs share, without the L2 write-back and invalidate of a release / acquire
-      // pair (which would throw the operands of every other block of the XCD out of its L2).  Order:
-      // a wave's stores have completed (s_waitcnt) before it reaches the barrier in front of the flag.
-      if (!fx_last) {
-        float* w = W.ws + (size_t)(fx_slot0 + fx_idx) * (BM * BN) + tid;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-              __hip_atomic_store(w + ((mi * 2 + ni) * 16 + e) * 256, acc[mi][ni][e], __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (tid == 0)
-          __hip_atomic_store(W.flags + fx_slot0 + fx_idx, W.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        continue;
-      }
-      if (!first) {
-        for (int bb = (fx_tl * nt_all) / fx_upb; bb < fx_idx; ++bb) {
-          const unsigned* fl = W.flags + fx_slot0 + bb;
-          if (tid == 0)
-            while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch)
-              __builtin_amdgcn_s_sleep(8);
-          __syncthreads();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          const float* w = W.ws + (size_t)(fx_slot0 + bb) * (BM * BN) + tid;
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              float v[16];
-#pragma unroll
-              for (int e = 0; e < 16; ++e)
-                v[e] = __hip_atomic_load(w + ((mi * 2 + ni) * 16 + e) * 256, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-              for (int e = 0; e < 16; ++e) acc[mi][ni][e] += v[e];
-            }
-        }
-        first = true;   // the sums are complete: bias (in the accumulators) and residual enter here
-      }
-    }
-    // (SK == 2: the epilogue sits inside the loop over a block's tiles; opaque copies of the lane
-    // coordinates keep its 64 store addresses from being hoisted out of that loop into registers)
-    int li_e = li, h_e = h;
-    if constexpr (SK == 2) asm volatile("" : "+v"(li_e), "+v"(h_e));
+    const int li_e = li, h_e = h;
     const f2g_epilogue& E = d.E;
     const bool simple = !partial && !E.aux && !E.colsum && !E.colsum_alpha && E.P0o == 0 &&
                         !E.atomic && !E.accumulate && E.scale == 0.f && !E.mask_src;
@@ -1714,47 +1616,7 @@ inline bool lean_b_ok(const f2g_operand& S) {
          (long long)S.rows * S.seq_stride * 4 < 0x7ff00000ll;
 }
 
-// workspace of the fix-up stream-K launches: one per (device, stream) -- launches of a stream run one
-// after the other, launches of different streams must not share partial tiles or flags.  The flags are
-// never reset: every launch raises them to its own epoch.
-struct SkPool {
-  float* ws = nullptr;
-  unsigned* flags = nullptr;
-  unsigned epoch = 0;
-};
-constexpr int SKFIX_GRID = 512;   // two blocks on each of the 256 CUs
-
-inline bool sk_workspace(hipStream_t st, lean_sk_ws& W) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SkPool> pools;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return false;   // a replayed graph would repeat the epoch
-  }
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  std::lock_guard<std::mutex> lock(mu);
-  SkPool& p = pools[{dev, st}];
-  if (!p.ws) {
-    if (hipMalloc(&p.ws, (size_t)SKFIX_GRID * 128 * 128 * sizeof(float)) != hipSuccess ||
-        hipMalloc(&p.flags, SKFIX_GRID * sizeof(unsigned)) != hipSuccess ||
-        hipMemsetAsync(p.flags, 0, SKFIX_GRID * sizeof(unsigned), st) != hipSuccess) {
-      (void)hipGetLastError();
-      p = SkPool();
-      return false;
-    }
-  }
-  if (++p.epoch == 0) ++p.epoch;
-  W.ws = p.ws;
-  W.flags = p.flags;
-  W.epoch = p.epoch;
-  return true;
-}
-
-// skfix: stream-K with seam fix-up on SKFIX_GRID blocks (exact fp32, 128 x 128 tiles) instead of the tile grid
-int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st,
-                bool skfix = false) {
+int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb, hipStream_t st) {
   // operand images: split = 1 -> split-bf16 pairs (precision 1: all three products, 2: high parts),
   // split = 2 -> true bf16 tensors (precision 2 only)
   const int pm = d.A.split == 2 ? 3 : (d.precision == 1 ? 1 : (d.precision == 2 ? 2 : 0));
@@ -1764,14 +1626,14 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
   // 256 x 128 tiles (8 waves) for the bf16 instances when the taller grid still fills the chip
   // and the reduction is long enough to amortise the larger prologue / epilogue (measured: +11 % on
   // the 1024-channel MPD layers, -7 % at K = 384 / 512)
-  // (F2G_LEAN_TALL: 0 never, 1 when K >= 640 and there are >= 400 tall tiles, 2 whenever possible)
-  static const int tall_mode = getenv("F2G_LEAN_TALL") ? atoi(getenv("F2G_LEAN_TALL")) : 1;
+  // (option lean_tall: 0 never, 1 when K >= 640 and there are >= 400 tall tiles, 2 whenever possible)
+  const int tall_mode = f2g_opt(F2G_OPT_LEAN_TALL);
   const long long tall_tiles = (long long)((M + 255) / 256) * ((N + 127) / 128);
   const bool tall = (pm == 1 || pm == 3) && upb == 0 && zs == 1 && tall_mode > 0 &&
                     (tall_mode > 1 || (tall_tiles >= 400 && K >= 640));
   const int bm = tall ? 256 : 128;
-  // tap-reusing variant for stride-1 conv windows (F2G_LEAN_TAP=0 turns it off)
-  static const bool tap_on = !(getenv("F2G_LEAN_TAP") && atoi(getenv("F2G_LEAN_TAP")) == 0);
+  // tap-reusing variant for stride-1 conv windows (option lean_tap = 0 turns it off)
+  const bool tap_on = f2g_opt(F2G_OPT_LEAN_TAP) != 0;
   const bool tap = tall && pm == 1 && tap_on && lean_tap_ok(d.A);
   const size_t smem = tap ? (size_t)(2 * 320 + 2 * 128) * LDR * sizeof(float)
                           : (size_t)(2 * bm + 2 * 128) * LDR * sizeof(float);
@@ -1781,14 +1643,10 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
     const long long total = (long long)grid.x * grid.y * (K / bk);
     grid = dim3((unsigned)((total + upb - 1) / upb), 1, 1);
   }
-  lean_sk_ws W = {nullptr, nullptr, 0u};
-  if (skfix && (pm != 0 || upb > 0 || zs != 1 || tall || !sk_workspace(st, W))) skfix = false;
-  if (skfix) grid = dim3(SKFIX_GRID, 1, 1);
-  const int fx_whole = skfix && getenv("F2G_SKFIX") && atoi(getenv("F2G_SKFIX")) == 3 ? 1 : 0;
   // epilogue instance (see gemm_lean_kernel)
   const f2g_epilogue& E = d.E;
   int ep = 3;
-  if (upb == 0) {   // (the fix-up stream-K instances carry every epilogue)
+  if (upb == 0) {
     const bool plainish = !E.aux && !E.colsum_alpha && !E.atomic && !E.accumulate && E.scale == 0.f;
     if (plainish && !E.colsum && E.P0o == 0 && !E.mask_src) ep = 0;
     else if (E.aux && !E.res && E.P0o == 0 && !E.atomic && !E.accumulate && E.scale == 0.f &&
@@ -1843,48 +1701,43 @@ int launch_lean(const f2g_gemm_desc& d, int M, int N, int K, int split, int upb,
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 320 + 2 * 128) * LDR * 4);
     attr_done = true;
   }
-  g_last_path = (upb > 0 || skfix) ? 2 : 1;
+  g_last_path = upb > 0 ? 2 : 1;
 #define F2G_LEAN(SKV, EPV)                                                                        \
   do {                                                                                            \
     if (pm == 1)                                                                                  \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 1>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb, W);                                                         \
+                         kchunk, upb);                                                         \
     else if (pm == 2)                                                                             \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 2>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb, W);                                                         \
+                         kchunk, upb);                                                         \
     else if (pm == 3)                                                                             \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 3>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb, W);                                                         \
+                         kchunk, upb);                                                         \
     else                                                                                          \
       hipLaunchKernelGGL((gemm_lean_kernel<SKV, EPV, 0>), grid, dim3(256), smem, st, d, M, N, K,  \
-                         kchunk, upb, W);                                                         \
+                         kchunk, upb);                                                         \
   } while (0)
 #define F2G_LEAN_T(EPV)                                                                           \
   do {                                                                                            \
     if (pm == 1)                                                                                  \
       hipLaunchKernelGGL((gemm_lean_kernel<false, EPV, 1, 4>), grid, dim3(512), smem, st, d, M,   \
-                         N, K, kchunk, upb, W);                                                   \
+                         N, K, kchunk, upb);                                                   \
     else                                                                                          \
       hipLaunchKernelGGL((gemm_lean_kernel<false, EPV, 3, 4>), grid, dim3(512), smem, st, d, M,   \
-                         N, K, kchunk, upb, W);                                                   \
+                         N, K, kchunk, upb);                                                   \
   } while (0)
   if (tap && (ep == 2 || ep == 3)) {
     if (ep == 2)
       hipLaunchKernelGGL((gemm_lean_kernel<false, 2, 1, 4, true>), grid, dim3(512), smem, st, d, M, N, K,
-                         kchunk, upb, W);
+                         kchunk, upb);
     else
       hipLaunchKernelGGL((gemm_lean_kernel<false, 3, 1, 4, true>), grid, dim3(512), smem, st, d, M, N, K,
-                         kchunk, upb, W);
+                         kchunk, upb);
   } else if (tall) {
     if (ep == 0) F2G_LEAN_T(0);
     else if (ep == 1) F2G_LEAN_T(1);
     else if (ep == 2) F2G_LEAN_T(2);
     else F2G_LEAN_T(3);
-  } else if (skfix) {
-    if (ep == 0) hipLaunchKernelGGL((gemm_lean_kernel<2, 0, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
-    else if (ep == 1) hipLaunchKernelGGL((gemm_lean_kernel<2, 1, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
-    else if (ep == 2) hipLaunchKernelGGL((gemm_lean_kernel<2, 2, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
-    else hipLaunchKernelGGL((gemm_lean_kernel<2, 3, 0>), grid, dim3(256), smem, st, d, M, N, K, kchunk, fx_whole, W);
   } else
   if (upb > 0) F2G_LEAN(true, 3);
   else if (ep == 0) F2G_LEAN(false, 0);
@@ -2450,11 +2303,10 @@ inline bool leanw_ok(const f2g_gemm_desc& d) {
 // exact fp32 weight gradient (form 2, both operands fp32): the K-major lean kernel where its shape conditions
 // hold and every block walks a long reduction (>= 4096 rows: the MPD weight gradients, 115 -> 125-131
 // TFLOP/s, step 254.5 -> 252.6 ms; on the generator's 6016-row weight gradients the generic kernel's 8 waves
-// hide the short K loops better: 92 vs 83).  F2G_LEAN_WGRAD: 0 off, 1 auto (default), 2 always.  ONE rule for
+// hide the short K loops better: 92 vs 83).  option lean_wgrad: 0 off, 1 auto (default), 2 always.  ONE rule for
 // f2g_gemm's dispatch and for the host's query (f2g_gemm_wgrad_lean).
 inline bool leanw_fp32_takes(const f2g_gemm_desc& d, int split) {
-  static const int leanw_mode = (getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0) ? 0
-                                : (getenv("F2G_LEAN_WGRAD") ? atoi(getenv("F2G_LEAN_WGRAD")) : 1);
+  const int leanw_mode = f2g_opt(F2G_OPT_LEAN) == 0 ? 0 : f2g_opt(F2G_OPT_LEAN_WGRAD);
   if (d.form != 2 || d.A.split || d.B.split || split < 1) return false;
   // (its scalar row walk assumes that a slab crosses at most two sequence ends)
   return leanw_mode > 0 && d.precision == 0 && d.E.atomic && leanw_ok(d) &&
@@ -2534,7 +2386,7 @@ int launch_leanw6(const f2g_gemm_desc& d, int M, int N, int K, int split, hipStr
 // fill one kernel's idle CUs with another lane's work (266.5 -> 269.0 ms: the zero fill and the
 // atomic epilogues remain).  Default: only the latency regime (fewer tiles than half the CUs:
 // batch-1 chunked synthesis, the per-item MLPs), where nothing else runs beside the kernel;
-// F2G_STREAMK=2 applies it to every ragged tile grid.
+// option streamk = 2 applies it to every ragged tile grid.
 inline int lean_stream_k(int M, int N, int K, bool all_grids) {
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
   const int nt = K / BK;
@@ -2549,34 +2401,6 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
   long long upb = (total + 511) / 512;
   if (upb < 8) upb = 8;                          // at least 8 slabs per block (prologue / epilogue)
   return (int)upb;
-}
-
-// Fix-up stream-K decision (exact fp32 lean kernel, chip-filling grids): the classic grid runs
-// ceil(tiles / 512) rounds of two blocks per CU, and a grid that ends in a nearly empty round (the
-// generator's 564-tile and 282-tile 1x1 convs: 1.1 and 0.55 rounds) pays for a whole one on the CUs that
-// hold the extra blocks.  Dealing the (tile, slab) units evenly costs each block one partial tile
-// written and one read (2 x 64 KB beside the megabytes of operands its range streams).
-// Measured alone on the chip (us, classic -> dealt): 6016 x 768 x 2304 286 -> 184, 24064 x 384 x 1152 246 -> 207,
-// 12032 x 512 x 1536 197 -> 169, 6016 x 2304 x 768 214 -> 188; K = 384 (12 slabs a tile: three seams per
-// 40 slabs) 245 -> 255, and grids of many rounds gain nothing (2376 tiles: the thin last round already runs
-// one block per CU, faster).  So the rule: reductions of >= 16 slabs whose rounds are less than 90 % full.
-// In the training steps it is worth -6 ms with the launch lanes off (stage 2: 258.5 -> 252.5 ms, stage 1
-// 46.9 -> 43.6) and NOTHING with them on (231 +- 0.5 / 40.6 ms either way, gpurun_out/r4_skfix_step.txt):
-// the lanes already fill a ragged round's idle CUs with another lane's blocks, and a kernel that holds all
-// 512 slots for its whole duration leaves them nothing to fill.  Hence off by default.
-// F2G_SKFIX: 0 off (default), 1 that rule (F2G_SKFIX_EFF / F2G_SKFIX_MIN_SLABS move it), 2 every chip-filling grid.
-// (3: as 2 with block ranges rounded up to whole tiles = a persistent tile walk without seams: slower than the
-// classic grid on every shape measured -- the dispatcher's dynamic balance beats the saved block turnover)
-inline bool lean_sk_fix(int M, int N, int K, int mode) {
-  static const double thr = getenv("F2G_SKFIX_EFF") ? atof(getenv("F2G_SKFIX_EFF")) : 0.90;
-  static const int min_nt = getenv("F2G_SKFIX_MIN_SLABS") ? atoi(getenv("F2G_SKFIX_MIN_SLABS")) : 16;
-  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
-  const int nt = K / BK;
-  if (tiles * 2 <= 256 || tiles * nt < 512ll * 12) return false;   // (latency regime: lean_stream_k)
-  if (mode > 1) return true;
-  if (nt < min_nt) return false;
-  const double rounds = (double)tiles / 512.0;
-  return rounds / (double)((tiles + 511) / 512) < thr;
 }
 
 }  // namespace
@@ -2764,271 +2588,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const f2g_gemm_desc d, 
   if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
-// Stride-1 conv windows (the 1024-channel MPD layer and its data gradient: K = 5 taps x 1024 channels):
-// tap-major K order makes the kernel above fetch every map row once per tap.  Here the positions a tile's
-// 128 output rows touch -- a contiguous run of the halo map, the halo rows of the sequence ends inside
-// the tile included -- are staged ONCE per 32-channel slab and the taps walk over them in LDS (a lane's
-// fragment row = its output row's staged position + tap): A traffic from L2 drops to a fifth, the
-// kernel's total by 40 %.  K order = channel slab outer, tap inner (the weights' slab t * C/32 + cs).
-struct x6_tap {
-  int P0, HpIn, offpos, C32;
-  unsigned bytes;
-};
-
-template <int TAPS>
-__global__ __launch_bounds__(256, 2) void gemm_x6t_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                          const x6_tap R, const int wide) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-  constexpr int PITCH = 208, LMAX = 160, OPER = LMAX * PITCH, NJA = 8, NJB = 6;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
-  int m0, n0;
-  tile_of_block(128, 128, m0, n0);
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  auto posrow = [&](int r) {
-    const int sq = r / R.P0;
-    return sq * R.HpIn + (r - sq * R.P0) + R.offpos;
-  };
-  const int pbase = posrow(m0);
-  const int rlast = m0 + 127 < M ? m0 + 127 : M - 1;
-  const int L = posrow(rlast) - pbase + TAPS;            // staged positions (<= LMAX: host check)
-  const unsigned rowbytesA = (unsigned)R.C32 * 192u;     // one position of the map image
-  const unsigned rowbytesW = (unsigned)(K / 32) * 192u;
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytesW, 0x00020000);
-  unsigned voA[NJA], voW[NJB];
-#pragma unroll
-  for (int j = 0; j < NJA; ++j) {
-    const int id = tid + 256 * j, q = id / 12, c = id - q * 12;
-    voA[j] = q < L ? (unsigned)(pbase + q) * rowbytesA + c * 16 : 0xf0000000u;
-  }
-#pragma unroll
-  for (int j = 0; j < NJB; ++j) {
-    const int id = tid + 256 * j, row = id / 12, c = id - row * 12;
-    voW[j] = (unsigned)(n0 + row) * rowbytesW + c * 16;
-  }
-  u32x4 xa[NJA], xw[NJB];
-  auto gloadA = [&](int cs) {
-#pragma unroll
-    for (int j = 0; j < NJA; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], cs * 192, 0);
-  };
-  auto gloadB = [&](int slab) {
-#pragma unroll
-    for (int j = 0; j < NJB; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], slab * 192, 0);
-  };
-  // fragment rows of this lane: output rows wm * 64 + i * 32 + li -> staged position
-  const unsigned char* rA[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = m0 + wm * 64 + i * 32 + li;
-    rA[i] = smem6 + (r < M ? posrow(r) - pbase : 0) * PITCH + h * 16;
-  }
-  const unsigned char* rB = smem6 + OPER + (wn * 64 + li) * PITCH + h * 16;
-  gloadA(0);
-  gloadB(0);
-  for (int cs = 0; cs < R.C32; ++cs) {
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-#pragma unroll
-      for (int j = 0; j < NJB; ++j) {
-        const int id = tid + 256 * j, row = id / 12, c = id - row * 12;
-        *reinterpret_cast<u32x4*>(smem6 + OPER + row * PITCH + c * 16) = xw[j];
-      }
-      if (t == 0) {
-#pragma unroll
-        for (int j = 0; j < NJA; ++j) {
-          const int id = tid + 256 * j, q = id / 12, c = id - q * 12;
-          if (q < LMAX) *reinterpret_cast<u32x4*>(smem6 + q * PITCH + c * 16) = xa[j];
-        }
-        gloadA(cs + 1 < R.C32 ? cs + 1 : 0);      // (past the end: re-read, never used)
-      }
-      {
-        const int tn = t + 1 < TAPS ? t + 1 : 0, cn = t + 1 < TAPS ? cs : (cs + 1 < R.C32 ? cs + 1 : 0);
-        gloadB(tn * R.C32 + cn);
-      }
-      X6_LDS_BARRIER();
-      bf16x8 fa[2][3][2], fb[2][3][2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA[i] + t * PITCH + p * 64 + ks * 32);
-            fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
-          }
-      X6_LDS_BARRIER();
-      __builtin_amdgcn_s_setprio(X6_MFMA_PRIO);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int sdeg = 2; sdeg >= 0; --sdeg)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const int j = sdeg - i;
-            if (j < 0 || j > 2) continue;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
-          }
-      __builtin_amdgcn_s_setprio(0);
-    }
-  }
-  if (wide) {
-    // (every fragment read of the main loop lies before its last barrier: a wave that is through its MFMAs
-    // may overlay the operand buffers with its private patch)
-    X6LAB_EPI x6e::wide_epilogue(d.E, acc, M, N, m0 + wm * 64, n0 + wn * 64, lane, smem6 + wave * x6e::ESZ);
-    return;
-  }
-  X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
-  if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
-}
-
-// ---- the tap-walking instance on a 256 x 128 tile (round 4) -------------------------------------------
-// gemm_x6t_kernel keeps the matrix pipe ~45 % busy: two blocks per CU whose store / barrier / read /
-// barrier phases meet at random, 31 KB from L2 per 128 x 128 x 32 tap (6 TB/s over the chip at 210 TFLOP/s
-// equivalent).  Here ONE block of 8 waves per CU owns 256 output rows: the weight slab of a tap is
-// double-buffered in LDS (stored behind the fragment reads of the tap before, into the buffer nobody
-// reads), the staged map positions are exchanged once per 32-channel slab, so a tap costs ONE barrier;
-// L2 -> LDS traffic per product drops by 40 % (the weight slab serves twice the rows).
-template <int TAPS>
-__global__ __launch_bounds__(512, 1) void gemm_x6t8_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                           const x6_tap R) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-  constexpr int PITCH = 208, LMAX = 304, OPERA = LMAX * PITCH, OPERB = 128 * PITCH;
-  constexpr int NJA = (LMAX * 12 + 511) / 512, NJB = 128 * 12 / 512;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
-  int m0, n0;
-  tile_of_block(256, 128, m0, n0);
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  auto posrow = [&](int r) {
-    const int sq = r / R.P0;
-    return sq * R.HpIn + (r - sq * R.P0) + R.offpos;
-  };
-  const int pbase = posrow(m0);
-  const int rlast = m0 + 255 < M ? m0 + 255 : M - 1;
-  const int L = posrow(rlast) - pbase + TAPS;            // staged positions (<= LMAX: host check)
-  const unsigned rowbytesA = (unsigned)R.C32 * 192u;     // one position of the map image
-  const unsigned rowbytesW = (unsigned)(K / 32) * 192u;
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytesW, 0x00020000);
-  unsigned voA[NJA], voW[NJB];
-  int loA[NJA], loW[NJB];
-#pragma unroll
-  for (int j = 0; j < NJA; ++j) {
-    const int id = tid + 512 * j, q = id / 12, c = id - q * 12;
-    voA[j] = q < L ? (unsigned)(pbase + q) * rowbytesA + c * 16 : 0xf0000000u;
-    loA[j] = q < LMAX ? q * PITCH + c * 16 : -1;
-  }
-#pragma unroll
-  for (int j = 0; j < NJB; ++j) {
-    const int id = tid + 512 * j, row = id / 12, c = id - row * 12;
-    voW[j] = (unsigned)(n0 + row) * rowbytesW + c * 16;
-    loW[j] = OPERA + row * PITCH + c * 16;
-  }
-  u32x4 xa[NJA], xw[NJB];
-  auto gloadA = [&](int cs) {
-#pragma unroll
-    for (int j = 0; j < NJA; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], cs * 192, 0);
-  };
-  auto gloadB = [&](int slab) {
-#pragma unroll
-    for (int j = 0; j < NJB; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], slab * 192, 0);
-  };
-  auto storeA = [&]() {
-#pragma unroll
-    for (int j = 0; j < NJA; ++j)
-      if (loA[j] >= 0) *reinterpret_cast<u32x4*>(smem6 + loA[j]) = xa[j];
-  };
-  auto storeB = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NJB; ++j) *reinterpret_cast<u32x4*>(smem6 + buf * OPERB + loW[j]) = xw[j];
-  };
-  // fragment rows of this lane: output rows wm * 64 + i * 32 + li -> staged position
-  const unsigned char* rA[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = m0 + wm * 64 + i * 32 + li;
-    rA[i] = smem6 + (r < M ? posrow(r) - pbase : 0) * PITCH + h * 16;
-  }
-  const unsigned char* rB = smem6 + OPERA + (wn * 64 + li) * PITCH + h * 16;
-  // weight slab of step s = (cs, t): K order = channel slab outer, tap inner -> image slab t * C32 + cs
-  const int nsteps = R.C32 * TAPS;
-  gloadA(0);
-  gloadB(0);
-  storeA();
-  storeB(0);
-  gloadA(1 < R.C32 ? 1 : 0);
-  gloadB(TAPS > 1 ? R.C32 : (1 < R.C32 ? 1 : 0));          // step 1
-  __syncthreads();
-  // (Measured and dropped: a software pipeline over half slabs -- the fragments of one k step requested under
-  // the MFMAs of the other, the barrier between the two halves: 187 against 211 TFLOP/s equivalent.)
-  int step = 0;
-  for (int cs = 0; cs < R.C32; ++cs) {
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t, ++step) {
-      const int buf = step & 1;
-      bf16x8 fa[2][3][2], fb[2][3][2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA[i] + t * PITCH + p * 64 + ks * 32);
-            fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + buf * OPERB + p * 64 + i * 32 * PITCH + ks * 32);
-          }
-      // the next step's weight slab goes into the buffer nobody reads (its readers left through the barrier
-      // that closed the step before); then the slab after it is requested
-      storeB(buf ^ 1);
-      {
-        const int s2 = step + 2 < nsteps ? step + 2 : 0;       // (past the end: re-read, never used)
-        const int c2 = s2 / TAPS, t2 = s2 - c2 * TAPS;
-        gloadB(t2 * R.C32 + c2);
-      }
-      if (t == TAPS - 1) {
-        // last tap of this channel slab: once every wave has its fragments, the staged positions are replaced
-        __syncthreads();
-        storeA();
-        gloadA(cs + 2 < R.C32 ? cs + 2 : 0);
-      }
-      __builtin_amdgcn_s_setprio(X6_MFMA_PRIO);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int sdeg = 2; sdeg >= 0; --sdeg)
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const int j = sdeg - i;
-            if (j < 0 || j > 2) continue;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-              for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
-          }
-      __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
-    }
-  }
-  X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
-  if (X6LAB_X3 d.E.x3_out) x3_tile_readback<256, 512>(d.E, M, N, m0, n0, tid);
-}
+// (Stride-1 conv windows -- the (5, 1) MPD layers and the two-tap residues of their stride-3 data gradients --
+// run on the tap-walking ping-pong kernel of gemm_x6p.hip; its 128-row and single-group 256-row predecessors
+// gemm_x6t_kernel / gemm_x6t8_kernel were removed in round 6.  Windows gemm_x6p_kernel does not take -- fewer
+// than 64 channels per position, grids that do not fill the chip -- read their rows through the kernel above.)
 
 // The same tile and schedule over the fp32 operands themselves (f2g_operand.split = 0): every thread
 // splits the 4-float chunks it loads into the three pieces on their way into LDS, as gemm_leanw6_kernel
@@ -3183,7 +2746,7 @@ static bool x6_shape_ok(const f2g_gemm_desc& d) {
 // stride-1 conv windows of TAPS positions x C channels over a halo map image (gemm_x6t_kernel)
 static bool x6_tap_ok(const f2g_gemm_desc& d, int taps) {
   const f2g_operand& A = d.A;
-  static const bool on = !(getenv("F2G_X6_TAP") && atoi(getenv("F2G_X6_TAP")) == 0);
+  const bool on = f2g_opt(F2G_OPT_X6_TAP) != 0;
   if (!on || host_plain(A) || A.P1 != 1 || A.step0 != 1 || A.unit < 32 || (A.unit % 32)) return false;
   if (A.cols != taps * A.unit || A.seglen < A.cols || (A.seq_stride % A.unit) || (A.pad0 > 0)) return false;
   const int HpIn = (int)(A.seq_stride / A.unit);
@@ -3192,68 +2755,9 @@ static bool x6_tap_ok(const f2g_gemm_desc& d, int taps) {
   return 128 + taps - 1 + (HpIn - A.P0) * (128 / A.P0 + 1) <= 160;
 }
 
-// 1: the launch takes the wide epilogue (x6_epilogue.h; F2G_X6_WIDE=0: the generic one + image read-back)
+// 1: the launch takes the wide epilogue (x6_epilogue.h; option x6_wide = 0: the generic one + image read-back)
 static int x6_wide(const f2g_gemm_desc& d) {
-  const char* ev = getenv("F2G_X6_WIDE");          // (read per call so that a test can switch it)
-  return (!ev || atoi(ev) != 0) && x6e::wide_ok(d.E, d.B.rows) ? 1 : 0;
-}
-
-static int launch_x6t(const f2g_gemm_desc& d, int taps, hipStream_t st) {
-  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
-  constexpr size_t smem = (160 + 128) * 208;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t_kernel<5>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
-  }
-  x6_tap R;
-  R.P0 = d.A.P0, R.HpIn = (int)(d.A.seq_stride / d.A.unit), R.offpos = -d.A.pad0, R.C32 = d.A.unit / 32;
-  R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
-  dim3 grid((M + 127) / 128, (N + 127) / 128);
-  if (taps == 5) hipLaunchKernelGGL(gemm_x6t_kernel<5>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
-  else hipLaunchKernelGGL(gemm_x6t_kernel<2>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
-  g_last_path = 4;
-  return f2g_check_launch();
-}
-
-// the 256-row instance: the same windows, the staged run of a 256-row tile within 304 positions, and a
-// tile grid that still gives every CU a block (F2G_X6_TAP8=0: off)
-static bool x6_tap8_ok(const f2g_gemm_desc& d, int taps) {
-  // F2G_X6_TAP8: 0 off, 1 (default) where the taller grid still gives every CU a block, 2 wherever the
-  // geometry allows (tests; read per call so that a test can switch it)
-  const char* ev = getenv("F2G_X6_TAP8");
-  const int mode = ev ? atoi(ev) : 1;
-  if (mode == 0 || !x6_tap_ok(d, taps)) return false;
-  const f2g_operand& A = d.A;
-  const int HpIn = (int)(A.seq_stride / A.unit);
-  if (256 + taps - 1 + (HpIn - A.P0) * (256 / A.P0 + 1) > 304) return false;
-  if (d.A.unit / 32 < 2) return false;
-  const long long tiles = (long long)((d.A.rows + 255) / 256) * ((d.B.rows + 127) / 128);
-  return mode >= 2 || tiles >= 256;
-}
-
-static int launch_x6t8(const f2g_gemm_desc& d, int taps, hipStream_t st) {
-  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
-  constexpr size_t smem = (size_t)(304 + 2 * 128) * 208;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t8_kernel<5>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6t8_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
-  }
-  x6_tap R;
-  R.P0 = d.A.P0, R.HpIn = (int)(d.A.seq_stride / d.A.unit), R.offpos = -d.A.pad0, R.C32 = d.A.unit / 32;
-  R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
-  dim3 grid((M + 255) / 256, (N + 127) / 128);
-  if (taps == 5) hipLaunchKernelGGL(gemm_x6t8_kernel<5>, grid, dim3(512), smem, st, d, M, N, K, R);
-  else hipLaunchKernelGGL(gemm_x6t8_kernel<2>, grid, dim3(512), smem, st, d, M, N, K, R);
-  g_last_path = 4;
-  return f2g_check_launch();
+  return f2g_opt(F2G_OPT_X6_WIDE) != 0 && x6e::wide_ok(d.E, d.B.rows) ? 1 : 0;
 }
 
 static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
@@ -3263,10 +2767,6 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
       g_last_path = 4;
       return f2g_launch_x6p(d, taps, x6_a_extent(d.A), st);
     }
-  if (x6_tap8_ok(d, 5)) return launch_x6t8(d, 5, st);
-  if (x6_tap8_ok(d, 2)) return launch_x6t8(d, 2, st);
-  if (x6_tap_ok(d, 5)) return launch_x6t(d, 5, st);
-  if (x6_tap_ok(d, 2)) return launch_x6t(d, 2, st);     // (the stride-3 layers' residue data gradients)
   const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
   constexpr size_t smem = 2 * 128 * 208;
   static bool attr_done = false;
@@ -3283,10 +2783,6 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
     R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 6), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 6);
   }
   R.bytes = (unsigned)(x6_a_extent(d.A) * 6);
-  if (f2g_x6pr_ok(d)) {     // round 5: ping-pong wave groups on a 256 x 128 tile (gemm_x6p.hip)
-    g_last_path = 4;
-    return f2g_launch_x6pr(d, 0, R.P0, R.seq6, R.step6, R.off6, R.bytes, st);
-  }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
   hipLaunchKernelGGL(gemm_x6_kernel, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   g_last_path = 4;
@@ -3322,10 +2818,6 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
     R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 4), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 4);
     R.bytes = (unsigned)(x6_a_extent(d.A) * 4);
   }
-  if (d.B.split == 0 && f2g_x6pr_ok(d)) {     // round 5: ping-pong wave groups, the split under the other group's MFMAs
-    g_last_path = 4;
-    return f2g_launch_x6pr(d, 1, R.P0, R.seq6, R.step6, R.off6, R.bytes, st);
-  }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
   if (d.B.split == 3) hipLaunchKernelGGL(gemm_x6f_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   else hipLaunchKernelGGL(gemm_x6f_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
@@ -3341,6 +2833,23 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
 extern "C" int f2g_gemm_x6_ok(const f2g_gemm_desc* d) {
   if (!d || !x6_shape_ok(*d)) return 0;
   return 1 | ((x6_tap_ok(*d, 5) || x6_tap_ok(*d, 2)) ? 2 : 0) | (x6f_ok(*d) ? 4 : 0);
+}
+
+// Rows of the partial column-sum matrices (E.colsum_part_ld > 0) the launch of `d` writes: one per 64 output
+// rows of whole tiles -- or 0 when the kernel f2g_gemm's dispatch picks has no wide epilogue (the SAME tests
+// in the same order as launch_x6f / launch_x6).
+extern "C" int32_t f2g_gemm_colsum_part_rows(const f2g_gemm_desc* dp) {
+  if (!dp || dp->precision != 3 || dp->form != 0) return 0;
+  f2g_gemm_desc d = *dp;
+  if (d.E.colsum_part_ld <= 0) d.E.colsum_part_ld = 4;          // (alignment of the pointers is the caller's)
+  if (!x6_wide(d)) return 0;
+  const int M = d.A.rows;
+  const int rows128 = 2 * ((M + 127) / 128), rows256 = 4 * ((M + 255) / 256);
+  if (x6f_ok(d)) return rows128;
+  if (d.A.split != 3 || d.B.split != 3 || !x6_shape_ok(d)) return 0;
+  for (int taps = 5; taps >= 2; taps -= 3)
+    if (x6_tap_ok(d, taps) && f2g_x6p_ok(d, taps)) return rows256;
+  return rows128;
 }
 
 extern "C" int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K) { return (int64_t)rows * K * 6; }
@@ -3370,7 +2879,7 @@ extern "C" int f2g_gemm_wgrad_lean(const f2g_gemm_desc* dp) {
 
 extern "C" int f2g_gemm_lean_ok(const f2g_gemm_desc* dp) {
   if (!dp || !dp->A.base || !dp->B.base) return 0;
-  static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
+  const bool lean_on = f2g_opt(F2G_OPT_LEAN) != 0;
   const f2g_gemm_desc& d = *dp;
   if (d.form == 2) return lean_on && leanw_ok(d) ? 1 : 0;   // split-bf16 weight-gradient kernel
   if (d.form != 0) return 0;
@@ -3441,6 +2950,11 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
   const f2g_gemm_desc& d = *dp;
   hipStream_t st = (hipStream_t)stream;
   int split = d.split_k > 0 ? d.split_k : 1;
+  if (d.E.colsum_part_ld > 0 && f2g_gemm_colsum_part_rows(dp) == 0) {
+    f2g_set_error("f2g_gemm: E.colsum_part_ld needs a precision-3 launch with the wide epilogue "
+                  "(f2g_gemm_colsum_part_rows(d) == 0 for this descriptor)");
+    return F2G_EINVAL;
+  }
   if (d.precision == 3 && d.form == 2) {
     // fp32-class weight gradient: fp32 operands, split into three pieces inside the kernel
     if (d.A.split || d.B.split || d.A.rows != d.B.rows || !leanw_ok(d) || d.E.x3_out ||
@@ -3484,9 +2998,9 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     int s = d.split_k;
     // (STFT framing GEMMs are never split: atomics would make the spectra -- the input of every
     // discriminator and loss -- differ in the last bit from run to run)
-    // F2G_DETERMINISTIC=1: never split on the library's own initiative (bit-reproducible forward)
-    static const bool no_auto = getenv("F2G_DETERMINISTIC") && atoi(getenv("F2G_DETERMINISTIC")) != 0;
-    static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
+    // option deterministic = 1 (F2G_DETERMINISTIC=1): never split on the library's own initiative (bit-reproducible forward)
+    const bool no_auto = f2g_opt(F2G_OPT_DETERMINISTIC) != 0;
+    const bool lean_on = f2g_opt(F2G_OPT_LEAN) != 0;
     // pre-split operands (f2g_split_bf16) are understood by the lean kernel's split-bf16 instances only
     const bool presplit = d.A.split != 0 && d.B.split == d.A.split;
     const bool bf16img = d.A.split == 2;
@@ -3497,12 +3011,8 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     if (d.E.c_bf16 && !lean) return F2G_EINVAL;
     if (lean && d.split_k == 0) {
       // library-chosen work split on the lean kernel: stream-K (same linear-epilogue condition as
-      // split-K; F2G_DETERMINISTIC=1 keeps the plain tile grid)
-      static const int sk_mode = getenv("F2G_STREAMK") ? atoi(getenv("F2G_STREAMK")) : 1;
-      const char* skfix_env = getenv("F2G_SKFIX");   // (read per call: the tests switch it)
-      const int skfix_mode = skfix_env ? atoi(skfix_env) : 0;
-      if (skfix_mode > 0 && d.precision == 0 && !d.A.split && !d.E.atomic && lean_sk_fix(M, N, K, skfix_mode))
-        return launch_lean(d, M, N, K, 1, 0, st, true);   // (deterministic: F2G_DETERMINISTIC keeps it)
+      // split-K; option deterministic = 1 (F2G_DETERMINISTIC=1) keeps the plain tile grid)
+      const int sk_mode = f2g_opt(F2G_OPT_STREAMK);
       int upb = 0;
       if (sk_mode > 0 && linear && !no_auto && !d.E.atomic && !d.E.c_bf16)
         upb = lean_stream_k(M, N, bf16img ? K / 2 : K, sk_mode > 1);   // (64-element slabs)
@@ -3539,7 +3049,7 @@ extern "C" int f2g_gemm(const f2g_gemm_desc* dp, f2g_stream_t stream) {
     if (split > 1 && !d.E.atomic) return F2G_EINVAL;
     const int M = d.A.cols, N = d.B.cols, K = d.A.rows;
     if (d.A.split || d.B.split) {   // pre-split images: the lean weight-gradient kernel only
-      static const bool lean_on = !(getenv("F2G_LEAN") && atoi(getenv("F2G_LEAN")) == 0);
+      const bool lean_on = f2g_opt(F2G_OPT_LEAN) != 0;
       if (!(d.precision == 1 && d.A.split && d.B.split && lean_on && leanw_ok(d))) return F2G_EINVAL;
       return launch_leanw3(d, M, N, K, split, st);
     }

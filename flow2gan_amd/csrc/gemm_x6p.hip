@@ -1,10 +1,10 @@
 // fp32-class GEMM over stride-1 conv windows of a halo-map image (the 1024-channel MPD layer, its data
 // gradient and the residue data gradients of the stride-3 layers; reference discriminators.py:65-76) --
-// round 5 successor of gemm_x6t8_kernel (gemm.hip): the same 256 x 128 tile, operand images and K order
+// round 5 successor of the single-group tap-walking kernels of rounds 3-4 (removed in round 6): a 256 x 128 tile, operand images and K order
 // (channel slab outer, tap inner; six v_mfma_f32_32x32x16_bf16 with i + j <= 2 per product, smallest terms
 // first), but
 //
-//  * PING-PONG wave groups.  PMC on gemm_x6t8_kernel (profiles/r05_pmc_busy_x6.txt): matrix pipe busy 56 % of
+//  * PING-PONG wave groups.  PMC on that predecessor (profiles/r05_pmc_busy_x6_before.txt): matrix pipe busy 56 % of
 //    the kernel's life at K = 5120, 29 % at K = 2048 -- its eight waves run in lockstep (all read their 24
 //    fragments, barrier, all issue their 48 MFMAs, barrier), so the pipe idles through every read phase.  Here
 //    the block's waves form two groups of four (one wave per SIMD each): group 0 owns rows 0..127 of the tile,
@@ -198,20 +198,9 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(const f2g_gemm_desc d,
 }
 
 
-// ---- the same ping-pong schedule over ROW operands -----------------------------------------------------
-// Plain (rows x K) matrices or single-segment windows whose rows lie a stride apart (the stride-3 MPD layers'
-// forward GEMMs, K = 640 / 2560): no positions to share between taps, so a group stages the 128 x 32 slab of
-// its OWN rows per step -- double-buffered (stored in the group's read slot into the buffer it read one step
-// earlier), which keeps the MFMA slot free of anything but MFMAs.  SPLIT = false: both operands are
-// f2g_split_bf16x3 images (192 bytes per row and slab, stored to LDS as they come); SPLIT = true: the fp32
-// tensors themselves (128 bytes per row and slab), every 4-float chunk split into its three bf16 pieces on
-// the way into LDS -- VALU work of the read slot, under the other group's MFMAs (gemm_x6f_kernel does it in
-// front of its own).  LDS: 2 groups x 2 buffers x 26 KB + 2 weight slabs = 156 KB, one block per CU.
-struct x6pr_rows {
-  int P0;
-  unsigned seq, step, off, bytes;     // bytes of the operand's memory format (6 or 4 per element)
-  unsigned wrow, wbytes;              // weights: bytes per row, extent
-};
+// (A ping-pong instance over ROW operands -- gemm_x6pr_kernel, 256 x 128 tiles for plain matrices and strided
+// windows -- was measured no faster than two free-running 128 x 128 blocks in round 5, 188 : 190 and 147 : 149
+// TFLOP/s equivalent, and removed in round 6.)
 
 // three bf16 pieces of four floats (as gemm.hip's split3x4: round to nearest even at every step)
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -234,120 +223,6 @@ __device__ __forceinline__ void split3x4(const u32x4& v, u32x2& p0, u32x2& p1, u
   p1 = u32x2{q[1][0] | ((unsigned)q[1][1] << 16), q[1][2] | ((unsigned)q[1][3] << 16)};
   p2 = u32x2{q[2][0] | ((unsigned)q[2][1] << 16), q[2][2] | ((unsigned)q[2][3] << 16)};
 }
-
-template <bool SPLIT>
-__global__ __launch_bounds__(512, 1) void gemm_x6pr_kernel(const f2g_gemm_desc d, int M, int N, int K,
-                                                           const x6pr_rows R) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-  constexpr int OPER = 128 * PITCH;                 // one 128-row slab
-  constexpr int WOFF = 4 * OPER;                    // [A g0 b0][A g0 b1][A g1 b0][A g1 b1][W b0][W b1]
-  constexpr int CPR = SPLIT ? 8 : 12;               // 16-byte chunks per row and slab in memory
-  constexpr int SB = CPR * 16;                      // bytes per row and slab in memory
-  constexpr int NJA = 128 * CPR / 256, NJW = 128 * CPR / 512;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = wave >> 2, gt = tid & 255;
-  const int wm = (wave >> 1) & 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
-  int m0, n0;
-  tile_of_block(256, 128, m0, n0);
-  const int mg = m0 + 128 * grp;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, R.wbytes, 0x00020000);
-  unsigned char* myA = smem6 + grp * (2 * OPER);
-  unsigned voA[NJA], voW[NJW];
-  int loA[NJA], loW[NJW];
-#pragma unroll
-  for (int j = 0; j < NJA; ++j) {
-    const int id = gt + 256 * j, row = id / CPR, c = id - row * CPR;
-    const int r = mg + row, sq = r / R.P0;
-    voA[j] = r < M ? (unsigned)sq * R.seq + (unsigned)(r - sq * R.P0) * R.step + R.off + c * 16
-                   : 0xf0000000u;                 // (outside the resource: zeros)
-    loA[j] = row * PITCH + c * (SPLIT ? 8 : 16);
-  }
-#pragma unroll
-  for (int j = 0; j < NJW; ++j) {
-    const int id = tid + 512 * j, row = id / CPR, c = id - row * CPR;
-    voW[j] = n0 + row < N ? (unsigned)(n0 + row) * R.wrow + c * 16 : 0xf0000000u;
-    loW[j] = WOFF + row * PITCH + c * (SPLIT ? 8 : 16);
-  }
-  u32x4 xa[NJA], xw[NJW];
-  auto gload = [&](int t) {
-    const int so = t * SB;
-#pragma unroll
-    for (int j = 0; j < NJA; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], so, 0);
-#pragma unroll
-    for (int j = 0; j < NJW; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], so, 0);
-  };
-  auto put = [&](unsigned char* p, const u32x4& v) {
-    if (SPLIT) {
-      u32x2 p0, p1, p2;
-      split3x4(v, p0, p1, p2);
-      *reinterpret_cast<u32x2*>(p) = p0;
-      *reinterpret_cast<u32x2*>(p + 64) = p1;
-      *reinterpret_cast<u32x2*>(p + 128) = p2;
-    } else {
-      *reinterpret_cast<u32x4*>(p) = v;
-    }
-  };
-  auto store = [&](int buf) {        // this thread's chunks of its group's A slab and of the weight slab
-#pragma unroll
-    for (int j = 0; j < NJA; ++j) put(myA + buf * OPER + loA[j], xa[j]);
-#pragma unroll
-    for (int j = 0; j < NJW; ++j) put(smem6 + buf * OPER + loW[j], xw[j]);
-  };
-  const unsigned char* rA = myA + (wm * 64 + li) * PITCH + h * 16;
-  const unsigned char* rB = smem6 + WOFF + (wn * 64 + li) * PITCH + h * 16;
-  const int nt = K / 32;
-  gload(0);
-  store(0);
-  gload(1 < nt ? 1 : 0);
-  lds_barrier();
-  if (grp == 1) lds_barrier();                   // group 1 runs one slot behind
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    // ---- read slot: this step's fragments; the next slab into the other buffers (the group's own A buffer
-    // was last read one step ago, the weight buffer by group 1 one slot ago); request the slab after
-    bf16x8 fa[2][3][2], fb[2][3][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + buf * OPER + p * 64 + i * 32 * PITCH + ks * 32);
-          fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + buf * OPER + p * 64 + i * 32 * PITCH + ks * 32);
-        }
-    store(buf ^ 1);
-    gload(t + 2 < nt ? t + 2 : 0);       // (past the end: re-read, never used)
-    lds_barrier();
-    // ---- MFMA slot (the other group reads meanwhile)
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int sdeg = 2; sdeg >= 0; --sdeg)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int j = sdeg - i;
-          if (j < 0 || j > 2) continue;
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
-        }
-    __builtin_amdgcn_s_setprio(0);
-    if (!(grp == 1 && t == nt - 1)) lds_barrier();
-  }
-  x6e::wide_epilogue(d.E, acc, M, N, mg + wm * 64, n0 + wn * 64, lane, smem6 + wave * ESZ);
-}
-
 
 // ---- tap-walking weight gradient of a stride-1 conv layer over halo maps (round 5) ----------------------
 // gw[co][t][ci] += sum_r g[r][co] * x[r + t - pad][ci]  (the 1024-channel MPD layer: t = 0..4; reference
@@ -652,8 +527,7 @@ __global__ __launch_bounds__(512, 1) void gemm_leanw6s_kernel(const f2g_gemm_des
 // d: a precision-3 descriptor that passed gemm.hip's x6_tap_ok(d, taps) (stride-1 windows of `taps` positions
 // over a halo-map image, <= 160 staged positions per 128 rows).  0 = not taken.
 int f2g_x6p_ok(const f2g_gemm_desc& d, int taps) {
-  const char* ev = getenv("F2G_X6P");       // 0 off, 1 (default) chip-filling grids, 2 whatever the grid
-  const int mode = ev ? atoi(ev) : 1;       // (read per call so that a test can switch it, as F2G_X6_TAP8)
+  const int mode = f2g_opt(F2G_OPT_X6P);    // 0 off, 1 (default) chip-filling grids, 2 whatever the grid
   if (mode == 0 || (taps != 5 && taps != 2)) return 0;
   if (d.A.unit / 32 < 2) return 0;
   if (!x6e::wide_ok(d.E, d.B.rows)) return 0;
@@ -682,53 +556,9 @@ int f2g_launch_x6p(const f2g_gemm_desc& d, int taps, long long a_extent, hipStre
   return f2g_check_launch();
 }
 
-// Row operands (gemm.hip: launch_x6 / launch_x6f after their own checks).  split = 0: three-piece images,
-// 1: the fp32 tensors.  seq / step / off / bytes: the A operand's row addressing in BYTES of its memory format.
-int f2g_x6pr_ok(const f2g_gemm_desc& d) {
-  // 0 (default) off, 1 chip-filling grids, 2 whatever the grid (tests).  Measured in the bf16x6 step: no gain
-  // over the 128 x 128 two-blocks-per-CU kernels with the same wide epilogue (38016 x 1024 x 2560: 188 : 190
-  // TFLOP/s equivalent, 114048 x 512 x 640: 147 : 149; laned step +1 ms) -- without positions shared between
-  // taps a 256 x 128 x 32 step pulls 80 KB through L2 -> LDS per CU, 14 TB/s over the chip: operand delivery,
-  // not the schedule, bounds the row kernels.  Kept opt-in with its tests.
-  const char* ev = getenv("F2G_X6PR");
-  const int mode = ev ? atoi(ev) : 0;       // (read per call so that a test can switch it)
-  if (mode == 0 || !x6e::wide_ok(d.E, d.B.rows) || d.A.cols < 64) return 0;
-  const long long tiles = (long long)((d.A.rows + 255) / 256) * ((d.B.rows + 127) / 128);
-  return (mode >= 2 || tiles >= 320) ? 1 : 0;
-}
-
-int f2g_launch_x6pr(const f2g_gemm_desc& d, int split, int P0, unsigned seq, unsigned step, unsigned off,
-                    unsigned bytes, hipStream_t st) {
-  const int M = d.A.rows, N = d.B.rows, K = d.A.cols;
-  constexpr size_t smem = (size_t)6 * 128 * PITCH;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6pr_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6pr_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_done = true;
-  }
-  x6pr_rows R;
-  R.P0 = P0, R.seq = seq, R.step = step, R.off = off, R.bytes = bytes;
-  if (split) {
-    R.wrow = (unsigned)(d.B.seq_stride * 4);
-    R.wbytes = (unsigned)((long long)N * d.B.seq_stride * 4);
-  } else {
-    R.wrow = (unsigned)(K / 32) * 192u;
-    R.wbytes = (unsigned)N * R.wrow;
-  }
-  dim3 grid((M + 255) / 256, (N + 127) / 128);
-  if (split) hipLaunchKernelGGL(gemm_x6pr_kernel<true>, grid, dim3(512), smem, st, d, M, N, K, R);
-  else hipLaunchKernelGGL(gemm_x6pr_kernel<false>, grid, dim3(512), smem, st, d, M, N, K, R);
-  return f2g_check_launch();
-}
-
-// Weight gradient of a stride-1 conv layer over halo maps on the tap-walking kernel (gemm.hip: launch_leanw6
-// after leanw_ok).  0 = not taken.
+// ---- tap-walking weight gradients: host side
 int f2g_leanw6t_ok(const f2g_gemm_desc& d, int split) {
-  const char* ev = getenv("F2G_W6T");       // 0 off (read per call so that a test can switch it)
-  if (ev && atoi(ev) == 0) return 0;
+  if (f2g_opt(F2G_OPT_W6T) == 0) return 0;
   const f2g_operand& A = d.A;
   const f2g_operand& B = d.B;
   if (d.form != 2 || d.precision != 3 || !d.E.atomic || d.E.P0o > 0 || d.E.bias || d.E.res) return 0;

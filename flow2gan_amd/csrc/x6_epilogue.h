@@ -79,6 +79,27 @@ __device__ __forceinline__ void wide_epilogue(const f2g_epilogue& E, f32x16 (&ac
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = (E.bias && cok) ? E.bias[col + e] : 0.f, cs[e] = 0.f, csa[e] = 0.f;
   const float fmw = E.fm_ref ? E.fm_w * (E.fm_wdev ? E.fm_wdev[0] : 1.f) : 0.f;
+  // The tile's elementwise operand (PReLU pre-activation / residual / leaky-ReLU mask source), all 64 rows of
+  // it, requested BEFORE the accumulators go through the patch: loaded inside the row loop below, every one
+  // of the eight (mi, j) steps put a full memory round trip behind its LDS read (the fragment registers of
+  // the main loop are dead here, so the 64 values per lane cost no occupancy).  One operand is prefetched --
+  // aux, else the residual, else the mask source -- which covers every epilogue the path builds but the
+  // G-step's mask + feature-matching pair (its second operand is still loaded in the loop).
+  const float* pre_src = E.aux ? E.aux : (E.res ? E.res : E.mask_src);
+  const int pre_kind = E.aux ? 1 : (E.res ? 2 : (E.mask_src ? 3 : 0));
+  float pre[2][4][8];
+  if (pre_kind) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = mi * 32 + (lane >> 3) + 8 * j;
+        const long long ro = rowoff[r];
+        const long long row = r0 + r;
+        const long long po = pre_kind == 1 ? row * E.ldaux + col : (pre_kind == 2 ? row * E.ldres + col : ro + col);
+        if (ro >= 0 && cok) ld8(pre_src + po, pre[mi][j]);
+      }
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     // (the patch's previous readers are this wave itself, earlier in program order: the LDS executes a
@@ -102,13 +123,19 @@ __device__ __forceinline__ void wide_epilogue(const f2g_epilogue& E, f32x16 (&ac
       for (int e = 0; e < 8; ++e) v[e] = v[e] * scale + bias[e];
       if (E.res) {
         float rv[8];
-        ld8(E.res + row * E.ldres + col, rv);
+        if (pre_kind == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = pre[mi][j][e];
+        } else {
+          ld8(E.res + row * E.ldres + col, rv);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (E.gamma ? E.gamma[col + e] : 1.f) * rv[e];
       }
       if (E.aux) {      // PReLU backward against the pre-activation, with the slope's gradient sums
         float av[8];
-        ld8(E.aux + row * E.ldaux + col, av);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = pre[mi][j][e];       // (pre_kind == 1 whenever aux is set)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           csa[e] += v[e] * fminf(av[e], 0.f);
@@ -132,7 +159,12 @@ __device__ __forceinline__ void wide_epilogue(const f2g_epilogue& E, f32x16 (&ac
       }
       if (E.mask_src) {   // leaky-ReLU backward of the layer below (+ feature-matching term)
         float y[8];
-        ld8(E.mask_src + off, y);
+        if (pre_kind == 3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = pre[mi][j][e];
+        } else {
+          ld8(E.mask_src + off, y);
+        }
         if (E.fm_ref) {
           float f[8];
           ld8(E.fm_ref + off, f);
@@ -166,15 +198,27 @@ __device__ __forceinline__ void wide_epilogue(const f2g_epilogue& E, f32x16 (&ac
     __builtin_amdgcn_wave_barrier();
   }
   if (E.colsum || E.colsum_alpha) {
+    float ps[8], pa[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float s = cs[e], sa = csa[e];
       s += __shfl_xor(s, 8), sa += __shfl_xor(sa, 8);
       s += __shfl_xor(s, 16), sa += __shfl_xor(sa, 16);
       s += __shfl_xor(s, 32), sa += __shfl_xor(sa, 32);
-      if (lane < 8 && cok) {
-        if (E.colsum) atomicAdd(E.colsum + col + e, s);
-        if (E.colsum_alpha) atomicAdd(E.colsum_alpha + col + e, sa);
+      ps[e] = s, pa[e] = sa;
+    }
+    if (lane < 8 && cok) {
+      if (E.colsum_part_ld > 0) {
+        // partial-sum matrices: this wave's row (r0 / 64), plain 16-byte stores, no atomics
+        const long long po = (long long)(r0 >> 6) * E.colsum_part_ld + col;
+        if (E.colsum) st8(E.colsum + po, ps);
+        if (E.colsum_alpha) st8(E.colsum_alpha + po, pa);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (E.colsum) atomicAdd(E.colsum + col + e, ps[e]);
+          if (E.colsum_alpha) atomicAdd(E.colsum_alpha + col + e, pa[e]);
+        }
       }
     }
   }
@@ -192,6 +236,7 @@ static inline bool wide_ok(const f2g_epilogue& E, int N) {
   if (E.prelu_out && (!a16(E.prelu_out) || (E.ld_prelu_out & 3))) return false;
   if (E.mask_src && !a16(E.mask_src)) return false;
   if (E.fm_ref && (!a16(E.fm_ref) || !E.mask_src)) return false;
+  if (E.colsum_part_ld > 0 && ((E.colsum_part_ld & 3) || !a16(E.colsum) || !a16(E.colsum_alpha))) return false;
   return true;
 }
 

@@ -16,6 +16,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
+from ._opts import opt
 from .models.modules import dft_matrices
 from .ops import gemm, mat, win1d
 
@@ -476,7 +477,7 @@ class _BranchView:
 # of 64 columns that are ZERO BY CONSTRUCTION -- the producing GEMM runs against weights / DFT
 # tables with zero rows appended, so it writes the zeros itself -- and the consumers reduce over the
 # padded width against zero-padded weights: same sums (plus exact zeros), lean kernels.
-SPEC_PAD = os.environ.get("F2G_SPEC_PAD", "1") != "0" and os.environ.get("F2G_LEAN", "1") != "0"
+SPEC_PAD = opt("spec_pad", True) and ops.L.get_option("lean") != 0
 
 
 def _spec_ld(Cin: int) -> int:

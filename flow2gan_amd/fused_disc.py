@@ -18,6 +18,7 @@ from typing import List
 import torch
 
 from . import ops
+from ._opts import opt
 from .fused import filterbank_spec, filterbank_spec_bwd
 from .models.modules import dft_matrices
 from .ops import gemm, mat, win1d, win2d
@@ -417,22 +418,22 @@ N_MRD_PARAMS = 5 * 5 * 2 + 2
 import os as _os
 
 # F2G_DIRECT_CONV=0 routes the band layers through the implicit GEMM again (A/B switch)
-DIRECT_CONV32 = _os.environ.get("F2G_DIRECT_CONV", "1") != "0"
+DIRECT_CONV32 = opt("direct_conv", True)
 # leaky-ReLU backward fused into the data-gradient epilogue that lands on a map (1) or run as its
 # own pass over the map afterwards (0): bit 0 = MPD, bit 1 = MRD.  Measured on the stage-2 step
 # (B = 64, 10 steps each): separate passes 257.5 ms, MPD fused 258.6, MRD fused 260.6, both 261.2 --
 # the HBM-bound passes overlap with other lanes' MFMA work, while masking in the epilogue (two more
 # loads per element, strided by the row map) holds an MFMA wave's registers and LDS idle.  Default 0.
-FUSE_LRELU = int(_os.environ.get("F2G_FUSE_LRELU", "0"))
+FUSE_LRELU = opt("fuse_lrelu", 0)
 # the five frequency bands of a resolution as nested launch lanes (their conv stacks are independent
 # until conv_post; the narrow bands' launches fill a fraction of the chip): 0 = one after the other
-BAND_LANES = _os.environ.get("F2G_BAND_LANES", "0") != "0"
+BAND_LANES = opt("band_lanes", False)
 # D-step of the MRD on the direct fp32-class kernels: leaky-ReLU backward mask + bias-gradient sums fused into
 # the data gradients (conv32x6.hip requests a tile's mask before its MFMAs); 0 = the separate passes
-MRD_FUSE_MASK = _os.environ.get("F2G_MRD_FUSE_MASK", "1") != "0"
+MRD_FUSE_MASK = opt("mrd_fuse_mask", True)
 # conv_post's data gradient (mpd0.hip stream kernel) with the leaky-ReLU backward of the layer below, its bias
 # sums and the result's image fused; 0 = the separate pass over the 1024-channel map
-MPDPOST_FUSE = _os.environ.get("F2G_MPDPOST_FUSE", "1") != "0"
+MPDPOST_FUSE = opt("mpdpost_fuse", True)
 
 
 def _band_edges(n_fft: int):

@@ -13,8 +13,9 @@ import os
 
 from .. import fused_disc as FD
 from .. import ops
+from .._opts import opt
 
-DISC_LANES = os.environ.get("F2G_DISC_LANES", "1") == "1"
+DISC_LANES = opt("disc_lanes", True)
 from .discriminators import MultiPeriodDiscriminator, MultiResolutionDiscriminator
 from .modules import MelSpectrogram
 

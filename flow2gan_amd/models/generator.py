@@ -15,10 +15,11 @@ import torch
 from torch import Tensor, nn
 
 from .. import fused, ops
+from .._opts import opt
 from .modules import AudioConvNeXt, CondEncoder, LinearFilterSpectrogram
 
 # inference: the time paths of all Euler steps are computed once, ahead of the loop (0: per step)
-TIME_AHEAD = os.environ.get("F2G_TIME_AHEAD", "1") != "0"
+TIME_AHEAD = opt("time_ahead", True)
 
 
 class CondRows:

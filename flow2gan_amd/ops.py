@@ -11,6 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib as L
+from ._opts import opt
 from ._lib import DwconvBwd, DwnormBwd, DwnormFwd, Epilogue, GemmDesc, Operand, call, ptr
 
 
@@ -363,18 +364,45 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
             # split-bf16 on the lean kernel: both operands as pre-split images (no conversion in
             # the K loop); weights come from the derived-weight cache, activations are split here
             d.A, d.B = _split_operand(A), _split_operand(Bm)
+    parts = None
+    if COLSUM_PARTS and d.precision == 3 and form == 0 and (colsum is not None or colsum_alpha is not None) \
+            and A.rows >= COLSUM_PARTS_MIN_ROWS:
+        # d(bias) / d(PReLU slope) column sums of a precision-3 forward-form launch as PARTIAL rows (one per 64
+        # output rows, plain stores) summed by one f2g_colsum per vector, instead of rows / 64 same-address
+        # atomics per column from the epilogues (13-24 % of the generator's PReLU-backward data gradients)
+        nrows = L.lib.f2g_gemm_colsum_part_rows(C.byref(d))
+        if nrows > 0:
+            ncol = Bm.rows
+            both = colsum is not None and colsum_alpha is not None
+            parts = torch.empty(nrows, (2 if both else 1) * ncol, device=out.device, dtype=torch.float32)
+            d.E.colsum_part_ld = parts.stride(0)
+            if colsum_alpha is not None:
+                d.E.colsum_alpha = ptr(parts)
+            if colsum is not None:
+                d.E.colsum = ptr(parts) + (4 * ncol if both else 0)
     if GEMM_TIMER is not None:
         GEMM_TIMER.launch(d, A, Bm, form, true_k, true_n)
     else:
         call("f2g_gemm", C.byref(d))
+    if parts is not None:
+        nrows, ncol = parts.shape[0], Bm.rows
+        if colsum_alpha is not None:
+            call("f2g_colsum", ptr(colsum_alpha), ptr(parts), parts.stride(0), None, 0, nrows, ncol)
+        if colsum is not None:
+            call("f2g_colsum", ptr(colsum), ptr(parts) + (4 * ncol if colsum_alpha is not None else 0),
+                 parts.stride(0), None, 0, nrows, ncol)
     return out
 
 
 import os as _os
 
-LEAN_DGRAD = _os.environ.get("F2G_LEAN_DGRAD", "1") != "0"
-LEAN_SPLIT = _os.environ.get("F2G_LEAN_SPLIT", "1") != "0"
-CONV32_SPLIT = _os.environ.get("F2G_CONV32_SPLIT", "1") != "0"   # split-bf16 direct MRD convs
+# column sums of precision-3 epilogues through partial rows instead of atomics (gemm() above)
+COLSUM_PARTS = opt("colsum_parts", True)
+COLSUM_PARTS_MIN_ROWS = 2048
+
+LEAN_DGRAD = opt("lean_dgrad", True)
+LEAN_SPLIT = opt("lean_split", True)
+CONV32_SPLIT = opt("conv32_split", True)   # split-bf16 direct MRD convs
 
 
 def split_bf16(t):
@@ -428,7 +456,7 @@ class split_sharing:
         return img
 
 
-BF16_IMAGES = _os.environ.get("F2G_BF16_IMAGES", "1") != "0"   # precision 2: true bf16 operands
+BF16_IMAGES = opt("bf16_images", True)   # precision 2: true bf16 operands
 
 
 def to_bf16(t):
@@ -469,11 +497,11 @@ def _bf16_operand(o: Operand) -> Operand:
     return n
 
 
-WGRAD_SPLIT512 = _os.environ.get("F2G_WGRAD_SPLIT512", "1") != "0"
-X6_MIN_ROWS = int(_os.environ.get("F2G_X6_MIN_ROWS", "1024"))
+WGRAD_SPLIT512 = opt("wgrad_split512", True)
+X6_MIN_ROWS = opt("x6_min_rows", 1024)
 # measured in the step (profiles/r03_x6_step.txt): the six-product kernel beats the fp32 lean kernel from
 # reductions of ~2000 on (184 against 131 TFLOP/s at K = 5120, 137 : 121 at 2048) and loses below ~1200
-X6_MIN_K = int(_os.environ.get("F2G_X6_MIN_K", "2048"))
+X6_MIN_K = opt("x6_min_k", 2048)
 
 
 def _x3_operand(o: Operand) -> Operand:
@@ -495,7 +523,7 @@ def _x3_operand(o: Operand) -> Operand:
         img = getattr(t, "_f2g_x3", None)      # left by the producers' epilogues (gemm(x3_out=True))
         if img is None or getattr(t, "_f2g_x3_bad", False):
             img = x3_flat_image(t)
-        elif _os.environ.get("F2G_X3_CHECK"):
+        elif X3_CHECK:
             ref = x3_flat_image(t)
             torch.cuda.synchronize()
             neq = img.view(torch.int16) != ref.view(torch.int16)
@@ -539,25 +567,26 @@ def x3_reserve(t, halo=None):
     return t
 
 
-X3_PRODUCERS = _os.environ.get("F2G_X3_PRODUCERS", "1") != "0"
-X6_WGRAD = _os.environ.get("F2G_X6_WGRAD", "1") != "0"
+X3_PRODUCERS = opt("x3_producers", True)
+X3_CHECK = opt("x3_check", False)       # (debug: compare every producer-written image with a fresh split)
+X6_WGRAD = opt("x6_wgrad", True)
 # gemm_x6f_kernel (the forward kernel over the fp32 operands, pieces made inside the kernel): 0 never,
 # 1 instead of the image kernel everywhere, 2 (default) where it was measured faster than both the image
 # kernel and the exact-fp32 lean kernel -- reductions of 640 <= K < X6_MIN_K with >= 512 output columns
 # and a tile grid that fills the chip (113920 x 512 x 640: 131 against 114 / 115 TFLOP/s;
 # 12032 x 512 x 1536: 109 : 111 : 95; 6016 x 2304 x 768: 103 : 109 : 96 -- profiles/r03_x6_step.txt),
 # or very tall GEMMs from 128 columns on (113920 x 128 x 1024: 129 against 98; 24064 x 384 x 1152 loses: 88 : 95)
-X6F = int(_os.environ.get("F2G_X6F", "2"))
+X6F = opt("x6f", 2)
 # (round 5: with the wide epilogue -- x6_epilogue.h -- the in-kernel-split kernel also wins on the generator's
 # short reductions: K >= 384, >= 384 columns, >= 180 tiles; same-box step 183.4 -> 178.2 ms, profiles/r05_x6_rules.txt)
-X6F_MIN_K = int(_os.environ.get("F2G_X6F_MIN_K", "384"))
-X6F_MIN_N = int(_os.environ.get("F2G_X6F_MIN_N", "384"))
-X6F_TALL_ROWS = int(_os.environ.get("F2G_X6F_TALL_ROWS", "50000"))     # (round 5: the G-step halves of the MPD layer-3 data gradients too)
-X6F_MIN_TILES = int(_os.environ.get("F2G_X6F_MIN_TILES", "180"))
+X6F_MIN_K = opt("x6f_min_k", 384)
+X6F_MIN_N = opt("x6f_min_n", 384)
+X6F_TALL_ROWS = opt("x6f_tall_rows", 50000)     # (round 5: the G-step halves of the MPD layer-3 data gradients too)
+X6F_MIN_TILES = opt("x6f_min_tiles", 180)
 # long reductions over a PLAIN activation matrix (the generator's K = 2304 GEMMs): below this K the in-kernel
 # split instead of an image pass (f2g_split_bf16x3: 10 bytes per element) in front of the image kernel
-X6_NOPASS_K = int(_os.environ.get("F2G_X6_NOPASS_K", "4096"))
-X6F_WIMG = _os.environ.get("F2G_X6F_WIMG", "1") != "0"     # in-kernel-split kernel: weights from their cached image
+X6_NOPASS_K = opt("x6_nopass_k", 4096)
+X6F_WIMG = opt("x6f_wimg", True)     # in-kernel-split kernel: weights from their cached image
 
 
 def _x3_window_ok(o: Operand) -> bool:
@@ -572,7 +601,7 @@ def operand_formats_ok(Cc: int, Hh: int) -> int:
     """Can the producers of a ConvNeXt block write its GEMM operands directly in the format the
     lean kernels consume?  2: bf16 tensors (precision 2: plain-bf16 inference), 1: split-bf16
     images (precision 1), 0: no (fp32 tensors, converted per GEMM where a lean kernel applies)."""
-    if not LEAN_SPLIT or _os.environ.get("F2G_LEAN", "1") == "0" or not OPERAND_PRODUCERS:
+    if not LEAN_SPLIT or not L.get_option("lean") or not OPERAND_PRODUCERS:
         return 0
     if GEMM_PRECISION == 2 and BF16_IMAGES and Cc % 64 == 0 and Hh % 64 == 0 and Cc > 64:
         return 2
@@ -581,7 +610,7 @@ def operand_formats_ok(Cc: int, Hh: int) -> int:
     return 0
 
 
-OPERAND_PRODUCERS = _os.environ.get("F2G_OPERAND_PRODUCERS", "1") != "0"
+OPERAND_PRODUCERS = opt("operand_producers", True)
 
 
 def _is_const(t) -> bool:
@@ -626,7 +655,7 @@ def _split_operand(o: Operand) -> Operand:
     return n
 
 
-CONV32_X6 = _os.environ.get("F2G_CONV32_X6", "1") != "0"    # bf16x6 mode: fp32-class direct MRD convs
+CONV32_X6 = opt("conv32_x6", True)    # bf16x6 mode: fp32-class direct MRD convs
 
 
 def x3_image(t2d):
@@ -664,7 +693,7 @@ def conv32_s2_fwd(x, S: int, H: int, Win: int, Wout: int, w_packed, bias, slope:
     return y
 
 
-CONV33_X6 = _os.environ.get("F2G_CONV33_X6", "1") != "0"    # bf16x6 mode: direct (3, 3) band layer
+CONV33_X6 = opt("conv33_x6", True)    # bf16x6 mode: direct (3, 3) band layer
 CONV33_MAX_W = 112     # one image row + its border must fit the kernel's 352 staged pixels: 3 * (W + 2) <= 352
 
 
@@ -828,6 +857,8 @@ class GemmTimer:
         self.shapes = []
         self.paths = []       # kernel family per record
         self.hbm = []         # (start, end, algorithmic bytes, kernel name): HBM-bound kernels
+        self.epis = []        # epilogue kind per record (report only)
+        self.report_by_epilogue = False
 
     def time_hbm(self, fn, nbytes: float, name: str):
         s = torch.cuda.Event(enable_timing=True)
@@ -880,6 +911,12 @@ class GemmTimer:
         if self.paths[-1] == "x6" and form == 0 and d.A.split == 3 and (L.lib.f2g_gemm_x6_ok(C.byref(d)) & 2):
             self.x6_tap = getattr(self, "x6_tap", 0) + 1      # (launches on the tap-walking instance)
         self.shapes.append((form, mm, nn, kk))
+        e_ = d.E
+        self.epis.append("+".join(k for k, on in (
+            ("prelu2", bool(e_.prelu_out)), ("prelu", bool(e_.prelu_slope) and not e_.prelu_out),
+            ("dprelu", bool(e_.aux)), ("res", bool(e_.res)), ("x3", bool(e_.x3_out)), ("map", e_.P0o > 0),
+            ("mask", bool(e_.mask_src)), ("lrelu", e_.lrelu_slope != 0.0), ("bf16", bool(e_.c_bf16)),
+            ("atomic", bool(e_.atomic))) if on) or "plain")
 
     def time(self, fn, flops: float, shape, path: str = "direct-conv"):
         """Any other launch that stands in for an f2g_gemm (the direct band-conv kernel)."""
@@ -891,12 +928,14 @@ class GemmTimer:
         self.records.append((s, e, flops))
         self.paths.append(path)
         self.shapes.append(shape)
+        self.epis.append("")
 
     def report(self, top: int = 25) -> str:
         """Per-shape table (form, M, N, K, kernel family): calls, total ms, TFLOP/s -- after a synchronise."""
         agg = {}
-        for (s, e, f), shp, pth in zip(self.records, self.shapes, self.paths):
-            a = agg.setdefault(tuple(shp) + (pth,), [0, 0.0, 0.0])
+        by_epi = self.report_by_epilogue                        # (split the rows by epilogue kind as well)
+        for (s, e, f), shp, pth, ep in zip(self.records, self.shapes, self.paths, self.epis):
+            a = agg.setdefault(tuple(shp) + ((pth + " " + ep) if by_epi else pth,), [0, 0.0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e)
             a[2] += f
@@ -943,10 +982,11 @@ def set_gemm_precision(name: str) -> None:
 # kernels in isolation) runs the lanes one after the other on the caller's stream.
 CONCURRENT = _os.environ.get("F2G_STREAMS", "1") != "0"
 _SIDE_STREAMS: dict = {}
-# F2G_LANE_CAP="mpd=3,mrd=2": at most that many streams behind the lanes of a pool (lane i -> stream i % cap;
-# a measurement aid: how much concurrency the step wants)
-_LANE_CAP = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in _os.environ.get("F2G_LANE_CAP", "").split(",")
-             if "=" in kv}
+# F2G_OPTS="lane_cap_mpd=3,lane_cap_mrd=2": at most that many streams behind the lanes of a pool (lane i ->
+# stream i % cap; a measurement aid: how much concurrency the step wants)
+_LANE_CAP = {pool: opt("lane_cap_" + pool, 0) for pool in ("branch", "disc", "mpd", "mrd", "mel", "condpath",
+                                                           "timepath", "band")}
+_LANE_CAP = {k: v for k, v in _LANE_CAP.items() if v > 0}
 
 
 def _side_streams(device, n: int, pool_name: str):
@@ -1055,7 +1095,7 @@ def wgrad(dY, M: int, ldy: int, X: Operand, g_out, ldg: Optional[int] = None, ou
 
 
 # ------------------------------------------------------------------ fused pointwise MLP (bf16)
-FUSED_MLP = _os.environ.get("F2G_FUSED_MLP", "1") != "0"
+FUSED_MLP = opt("fused_mlp", True)
 
 
 def fused_mlp_applies(Cc: int, Hh: int) -> bool:
@@ -1147,9 +1187,9 @@ def fused_block_multi(entries):
     return [e["out"] for e in entries]
 
 
-FUSED_BLOCK = _os.environ.get("F2G_FUSED_BLOCK", "1") != "0"
+FUSED_BLOCK = opt("fused_block", True)
 # all Fourier branches' blocks of a layer in one launch (bf16 inference; 0: one launch per branch and lane)
-FUSED_MULTI = _os.environ.get("F2G_FUSED_MULTI", "1") != "0"
+FUSED_MULTI = opt("fused_multi", True)
 
 
 # ------------------------------------------------------------------ fused block kernels
@@ -1426,7 +1466,7 @@ def zeros_many(shapes, device):
 
 
 # ------------------------------------------------------------------ first MPD layer (1 -> 32 channels)
-MPD0_DIRECT = _os.environ.get("F2G_MPD0_DIRECT", "1") != "0"
+MPD0_DIRECT = opt("mpd0_direct", True)
 
 
 def _mpd0_desc(x, S, H, Hout, halo, w=None, bias=None, slope=0.0, y=None, x_off=0, y_off=0):
@@ -1505,10 +1545,10 @@ def mpdpost_wgrad(y, S, H, halo, g, gw):
 
 
 # ------------------------------------------------------------------ LDS-butterfly FFT (n_fft >= 1024)
-USE_FFT = _os.environ.get("F2G_FFT", "1") != "0"
+USE_FFT = opt("fft", True)
 # transforms below FFT_MIN stay on the DFT GEMM (the 32- / 64-point mel-reconstruction scales: a
 # handful of MFMAs per frame).  F2G_FFT_MIN=1024 restores round 2's split (LDS FFT for n_fft >= 1024 only).
-FFT_MIN = int(_os.environ.get("F2G_FFT_MIN", "128"))
+FFT_MIN = opt("fft_min", 128)
 _FFT_TABLES = {}
 
 
@@ -1533,7 +1573,7 @@ def _spec_flags(spec, interleaved: bool) -> int:
     return (1 if interleaved else 0) | (2 if spec.dtype == torch.bfloat16 else 0)
 
 
-FFT_REFLECT = _os.environ.get("F2G_FFT_REFLECT", "1") != "0"   # center / reflect padding inside the FFT kernel
+FFT_REFLECT = opt("fft_reflect", True)   # center / reflect padding inside the FFT kernel
 
 
 def stft_fft(x, n_fft: int, hop: int, F: int, spec, interleaved: bool = False, zero_pad: bool = False):

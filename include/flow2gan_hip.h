@@ -37,6 +37,16 @@ const char* f2g_version(void);
 /* Text of the last hip error seen by this library (thread-unsafe, diagnostics only). */
 const char* f2g_last_error(void);
 
+/* Library options: every tunable of the dispatch (which kernel family may take a launch, tile rules, the
+ * bit-reproducible mode) is an int in one table, initialised once -- built-in defaults, then
+ * F2G_OPTS="name=value,..." and F2G_DETERMINISTIC from the environment -- and changed afterwards only through
+ * this setter; nothing reads the environment on a launch path.  Names: lean, lean_tall, lean_tap, lean_wgrad,
+ * x6_tap, x6_wide, x6p, w6t, deterministic, streamk, conv2ch_v2, conv32_v2, conv32_wgrad_v2, mlp_rt, mlp_split,
+ * multi_rt384, multi_rt512 (meanings: csrc/common.h).  Unknown name: F2G_EINVAL.  Not thread safe against
+ * concurrent launches. */
+int f2g_set_option(const char* name, int32_t value);
+int f2g_get_option(const char* name, int32_t* value);
+
 /* ------------------------------------------------------------------------------------------
  * Implicit-GEMM operand: a matrix whose rows are "pixels" and whose columns are a contiguous
  * window of the channels-last source -- i.e. an im2col view that is never materialised.
@@ -125,6 +135,14 @@ typedef struct {
    * operand without an image pass.  C must sit on a 32-element boundary of that buffer; plain /
    * row-mapped / accumulating stores (no atomics, no prelu_out). */
   void* x3_out;
+  /* > 0 (precision 3, form 0, the wide epilogue only -- ask f2g_gemm_colsum_part_rows first): `colsum` /
+   * `colsum_alpha` point at PARTIAL-sum matrices with one row per 64 output rows, `colsum_part_ld` floats
+   * apart (16-byte aligned, ld % 4 == 0): the wave that owns output rows [64 i, 64 i + 64) STORES its column
+   * sums into row i instead of adding them atomically to a shared vector, and the caller sums the rows
+   * (f2g_colsum).  The d(bias) / d(PReLU slope) sums of a 24064-row data gradient are 376 same-address
+   * atomics per column otherwise -- 13-24 % of those launches.  f2g_gemm refuses the descriptor (F2G_EINVAL)
+   * when the kernel it would pick cannot do this. */
+  int64_t colsum_part_ld;
 } f2g_epilogue;
 
 /* form: 0 = C[r,n] = sum_k A[r,k] * B[n,k]   (forward; B = weights [n][k])
@@ -195,6 +213,12 @@ int f2g_to_bf16(void* dst, const float* src, int64_t n, f2g_stream_t stream);
 int64_t f2g_split_bf16x3_bytes(int32_t rows, int32_t K);
 int f2g_split_bf16x3(void* dst, const float* src, int64_t ld, int32_t rows, int32_t K, f2g_stream_t stream);
 int f2g_gemm_x6_ok(const f2g_gemm_desc* d);
+/* Number of partial-sum rows (= output rows / 64, rounded up to whole tiles) the launch of this descriptor
+ * would write when E.colsum_part_ld > 0, or 0 when the kernel f2g_gemm picks for it cannot store partial
+ * column sums (then leave colsum_part_ld at 0: atomics).  Ask with the descriptor exactly as it will be
+ * launched (precision, operand formats); E.colsum / colsum_alpha / colsum_part_ld may still be unset. */
+int32_t f2g_gemm_colsum_part_rows(const f2g_gemm_desc* d);
+
 /* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
  * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels,
  * 4 the precision-3 kernels. */

@@ -116,3 +116,21 @@ def gemm_mode_exact(request):
         yield request.param
     finally:
         ops.GEMM_PRECISION = was
+
+
+@pytest.fixture
+def lib_option():
+    """Set dispatch options of the library for one test (f2g_set_option; restored afterwards):
+    `lib_option("x6p", 2)`."""
+    from flow2gan_amd import _lib
+
+    saved = []
+
+    def setter(name, value):
+        saved.append((name, _lib.set_option(name, value)))
+
+    try:
+        yield setter
+    finally:
+        for name, old in reversed(saved):
+            _lib.set_option(name, old)

@@ -129,7 +129,8 @@ def leaky_relu_sign_flips(gan, ogan, real, fake_h, fake_o):
                          ids=["24k", "44k"])
 @pytest.mark.parametrize("tag,n", [("n1", 1), ("n2", 2)])
 @pytest.mark.parametrize("pingpong", [False, True], ids=["rule", "pingpong"])
-def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, pingpong, gemm_mode, monkeypatch):
+def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, pingpong, gemm_mode, monkeypatch,
+                                             lib_option):
     """D-step / G-step losses and gradients against the REFERENCE's recorded vectors; the 44k
     fixture is BASELINE config 5's geometry (sr 44100 in the seven mel-recon filterbanks and the
     128-band / n_fft 2048 / hop 512 front end, config.py:64-95, gan.py:44-55).
@@ -139,8 +140,7 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, 
     if pingpong:
         if gemm_mode not in ("bf16x6", "3"):
             pytest.skip("the ping-pong kernels are six-product kernels")
-        monkeypatch.setenv("F2G_X6P", "2")
-        monkeypatch.setenv("F2G_X6PR", "2")
+        lib_option("x6p", 2)
     g = golden(fixture)
     gan = build_gan(f2g, g, cfg)
     assert gan.generator.sampling_rate == cfg["sampling_rate"]

@@ -122,11 +122,11 @@ def test_gemm_split_bf16_on_the_lean_kernel(ops, R, K, N):
 
 def _lean_wgrad_expected(mode):
     # split-bf16: always the K-major kernel; exact fp32: only long reductions per block by default
-    # (F2G_LEAN_WGRAD=2 forces it -- the kernel tests below run under that setting as well)
-    import os
+    # (library option lean_wgrad = 2 forces it -- the kernel tests below run under that setting as well)
+    from flow2gan_amd import _lib
     if mode == "bf16x6":      # gemm_leanw6_kernel (reported as the six-product family)
         return 4
-    return 1 if (mode == "bf16x3" or os.environ.get("F2G_LEAN_WGRAD", "1") == "2") else 0
+    return 1 if (mode == "bf16x3" or _lib.get_option("lean_wgrad") == 2) else 0
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16x6"])
@@ -299,70 +299,6 @@ def test_gemm_dgrad_with_prelu_grad(ops, R, K, N):
     auxd = g(aux)
     ops.gemm(ops.mat(g(G)), ops.mat(g(W)), auxd, form=1, aux=auxd, alpha_n=g(alpha))
     close(auxd, want, name="dgrad-inplace")
-
-
-@pytest.mark.parametrize("R,K,N,force", [(6011, 2304, 768, False), (4100, 1024, 700, True), (9000, 384, 1100, True),
-                                         (24064, 1152, 384, False)])
-def test_lean_streamk_with_seam_fixup(ops, R, K, N, force, monkeypatch):
-    """Exact-fp32 lean GEMM dealt out as equal (tile, slab) ranges over 512 blocks (F2G_SKFIX=1: ragged tile
-    grids such as the generator's 282- and 564-tile 1x1 convs, F2G_SKFIX=2 everywhere): tiles cut between blocks
-    are completed from the lower blocks' partial sums BEFORE the epilogue, so every epilogue stays
-    available -- bias, two-output PReLU, (in-place) residual * gamma, PReLU backward with column sums,
-    row-mapped store with leaky ReLU, accumulate -- and the result does not depend on timing."""
-    if ops.GEMM_PRECISION != 0:
-        pytest.skip("a test of the exact-fp32 kernel (the suite runs under F2G_GEMM=" + str(ops.GEMM_PRECISION) + ")")
-    monkeypatch.setenv("F2G_SKFIX", "2" if force else "1")   # (off by default: the launch lanes make it moot)
-    lib = ops.L.lib
-    A, W, b = rnd(R, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3)
-    res, gam, ps = rnd(R, N, seed=4), rnd(N, seed=5), rnd(N, seed=6) * 0.3
-    Ad, Wd = g(A), g(W)
-    ref = (g(A).double() @ g(W).double().t() + g(b).double()).cpu()
-    out = torch.empty(R, N, device=DEV)
-    ops.gemm(ops.mat(Ad), ops.mat(Wd), out, bias=g(b))
-    assert lib.f2g_gemm_last_path() == 2, "the ragged grid did not take the stream-K instance"
-    close(out, ref, name="skfix plain")
-    again = torch.empty(R, N, device=DEV)
-    ops.gemm(ops.mat(Ad), ops.mat(Wd), again, bias=g(b))
-    assert torch.equal(out, again), "seam fix-up must be deterministic"
-    monkeypatch.setenv("F2G_SKFIX", "0")
-    ops.gemm(ops.mat(Ad), ops.mat(Wd), again, bias=g(b))
-    assert lib.f2g_gemm_last_path() == 1
-    monkeypatch.setenv("F2G_SKFIX", "2" if force else "1")
-    assert float((out - again).abs().max()) <= 2e-5 * float(ref.abs().max())
-    pre, act = torch.empty(R, N, device=DEV), torch.empty(R, N, device=DEV)
-    ops.gemm(ops.mat(Ad), ops.mat(Wd), pre, bias=g(b), prelu=g(ps), prelu_out=act)
-    assert lib.f2g_gemm_last_path() == 2
-    close(pre, ref, name="skfix pre")
-    close(act, torch.where(ref > 0, ref, ref * ps.double()[None]), name="skfix prelu")
-    io = g(res)
-    ops.gemm(ops.mat(Ad), ops.mat(Wd), io, bias=g(b), res=io, gamma=g(gam))
-    assert lib.f2g_gemm_last_path() == 2
-    close(io, ref + gam.double() * res.double(), name="skfix residual in place")
-    # PReLU backward + both column sums (the generator's data gradient through pw2)
-    aux, alpha = rnd(R, N, seed=7), rnd(N, seed=8) * 0.3
-    cs, cs_a = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
-    dg = torch.empty(R, N, device=DEV)
-    ops.gemm(ops.mat(Ad), ops.mat(Wd), dg, aux=g(aux), alpha_n=g(alpha), colsum=cs, colsum_alpha=cs_a)
-    assert lib.f2g_gemm_last_path() == 2
-    dp = ref - b.double()
-    want = dp * torch.where(aux > 0, torch.ones_like(aux), alpha[None].expand_as(aux)).double()
-    close(dg, want, name="skfix prelu-bwd")
-    close(cs, want.sum(0), rtol=1e-4, name="skfix colsum")
-    close(cs_a, (dp * aux.clamp(max=0).double()).sum(0), rtol=1e-4, name="skfix colsum_alpha")
-    # row-mapped store into a halo layout with leaky ReLU (the MPD maps)
-    P0 = 50 if R % 50 == 0 else 47
-    if R % P0 == 0:
-        S, HALO = R // P0, 2
-        halo = torch.full((S, P0 + 2 * HALO, N), 3.0, device=DEV)
-        ops.gemm(ops.mat(Ad), ops.mat(Wd), halo, bias=g(b), lrelu=0.1,
-                 rowmap=(P0, (P0 + 2 * HALO) * N, N, HALO * N))
-        assert lib.f2g_gemm_last_path() == 2
-        close(halo[:, HALO:HALO + P0].reshape(R, N), F.leaky_relu(ref, 0.1), name="skfix rowmap")
-        assert float(halo[:, :HALO].min()) == 3.0 and float(halo[:, HALO + P0:].max()) == 3.0
-    # accumulate (generic epilogue)
-    acc = g(res)
-    ops.gemm(ops.mat(Ad), ops.mat(Wd), acc, accumulate=True, split_k=0)
-    close(acc, res.double() + dp, name="skfix accumulate")
 
 
 @pytest.mark.parametrize("R,M,N", [(3000, 96, 40), (700, 514, 48), (5000, 32, 864), (130, 1536, 512)])
@@ -1268,17 +1204,14 @@ def test_fused_mlp_matches_the_two_gemm_arithmetic(ops, C, rows):
     assert float((out2.cpu().double() - want2).abs().max()) < 2e-3 * float(want2.abs().max())
 
 
-@pytest.mark.parametrize("tile", ["tile128", "pingpong"])
 @pytest.mark.parametrize("kernel", ["images", "in-kernel split"])
 @pytest.mark.parametrize("M,N,K", [(6016, 768, 2304), (1500, 200, 96), (4099, 1152, 384)])
-def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, tile, monkeypatch):
+def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, monkeypatch):
     """precision 3 (`bf16x6`): three bf16 pieces per operand, six MFMAs per product.  Against float64 its
     error must be of the class of the exact-fp32 kernel's on the same operands (max over ALL entries of
     |err| / sum |a w| below 1e-6 and within 3x of the fp32 MFMA's; plain bf16 is at 1e-3), on ragged extents, with bias / residual / PReLU epilogues
-    and as a data gradient (form 1 through the cached transpose).  tile128: gemm_x6_kernel / gemm_x6f_kernel
-    (128 x 128 tiles, two blocks per CU); pingpong: gemm_x6pr_kernel (round 5: 256 x 128 tiles, two wave groups
-    half a step apart) whatever the grid size."""
-    monkeypatch.setenv("F2G_X6PR", "2" if tile == "pingpong" else "0")
+    and as a data gradient (form 1 through the cached transpose): gemm_x6_kernel / gemm_x6f_kernel (128 x 128
+    tiles, two blocks per CU)."""
     gen = torch.Generator().manual_seed(M + K)
     a = torch.randn(M, K, generator=gen) * (1.0 + 3.0 * torch.rand(M, K, generator=gen))
     w = torch.randn(N, K, generator=gen) * 0.05
@@ -1347,21 +1280,20 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, tile, monkeypatc
         ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS = was
 
 
-@pytest.mark.parametrize("tap8", [0, 2, 3], ids=["tile128", "tile256", "pingpong"])
+@pytest.mark.parametrize("x6p", [0, 2], ids=["rows", "pingpong"])
 @pytest.mark.parametrize("B2,T,p", [(4, 24000, 3), (2, 11025, 11), (6, 6000, 2)])
-def test_fp32_class_gemm_over_halo_windows_and_producer_images(ops, B2, T, p, tap8, monkeypatch):
+def test_fp32_class_gemm_over_halo_windows_and_producer_images(ops, B2, T, p, x6p, monkeypatch, lib_option):
     """precision 3 over the MPD stack's operands: conv windows into the halo maps (rows a stride apart, K
     contiguous over the taps) read from the flat three-piece image of the map, and that image written by
     the PRODUCING GEMM (E.x3_out: bias + leaky ReLU forward, leaky-ReLU-backward mask in the data
     gradients, stride residues interleaving rows).  Every produced image must equal f2g_split_bf16x3 of the
     stored map bit for bit (zero halo rows included), and maps / gradients must agree with the exact-fp32
-    path to fp32 rounding.  tile256: the tap-walking windows on gemm_x6t8_kernel (one block of 8 waves per
-    CU, 256 output rows, double-buffered weight slabs) wherever its geometry allows, whatever the grid size;
-    pingpong: gemm_x6p_kernel (round 5: two wave groups half a step apart, wide epilogue that writes map and
-    image from the same registers) wherever ITS geometry allows -- the other two ids switch it off."""
+    path to fp32 rounding.  pingpong: the tap-walking gemm_x6p_kernel (two wave groups half a step apart, wide
+    epilogue that writes map and image from the same registers) wherever its geometry allows, whatever the
+    grid size; rows: switched off -- the windows are read row by row through gemm_x6_kernel (what grids that do
+    not fill the chip and layers of fewer than 64 channels get)."""
     from flow2gan_amd import fused_disc as fd
-    monkeypatch.setenv("F2G_X6_TAP8", str(min(tap8, 2)))
-    monkeypatch.setenv("F2G_X6P", "2" if tap8 == 3 else "0")
+    lib_option("x6p", x6p)
     gen = torch.Generator().manual_seed(T + p)
     x2 = g(0.1 * torch.randn(B2, T, generator=gen))
     ch = fd.MPD_CH
@@ -1562,3 +1494,60 @@ def test_fused_block_matches_dwnorm_plus_fused_mlp(ops, C, B, Fr, up):
         # nothing but the compiler's contraction choices inside the prologue
         assert err < 2e-3 * scale, (use_cond, err, scale)
         assert float((got - want).pow(2).mean().sqrt()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("kernel", ["images", "in-kernel split"])
+@pytest.mark.parametrize("M,N,K", [(6016, 1152, 384), (4099, 264, 96), (300, 128, 64)])
+def test_fp32_class_column_sums_as_partial_rows(ops, M, N, K, kernel, monkeypatch):
+    """Round 6: the d(bias) / d(PReLU slope) column sums of a precision-3 data gradient leave the wide
+    epilogue as one partial row per 64 output rows (f2g_epilogue.colsum_part_ld, plain stores) and are summed
+    by f2g_colsum -- same sums as the atomic path (ragged M, N not a multiple of 128, in place over aux), and
+    f2g_gemm refuses the field where no wide epilogue would run."""
+    import ctypes as C
+    gen = torch.Generator().manual_seed(M + N)
+    G, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) * 0.05
+    aux, alpha = torch.randn(M, N, generator=gen), torch.randn(N, generator=gen) * 0.3
+    dp = G.double() @ W.double().t()
+    want = dp * torch.where(aux > 0, torch.ones_like(aux), alpha[None].expand_as(aux)).double()
+    want_cs, want_csa = want.sum(0), (dp * aux.clamp(max=0).double()).sum(0)
+    Wd = torch.nn.Parameter(g(W))
+    monkeypatch.setattr(ops, "X6F", 0 if kernel == "images" else 1)
+    was = ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS
+    res = {}
+    try:
+        ops.set_gemm_precision("bf16x6")
+        ops.X6_MIN_K, ops.X6_MIN_ROWS = 32, 1
+        monkeypatch.setattr(ops, "COLSUM_PARTS_MIN_ROWS", 1)
+        for parts in (True, False):
+            monkeypatch.setattr(ops, "COLSUM_PARTS", parts)
+            a = g(aux)
+            cs, csa = torch.zeros(N, device=DEV), torch.full((N,), 2.0, device=DEV)     # (csa: accumulates onto 2)
+            calls = []
+            real_call = ops.call
+            monkeypatch.setattr(ops, "call", lambda name, *args: (calls.append(name), real_call(name, *args))[1])
+            ops.gemm(ops.mat(g(G)), ops.mat(Wd), a, aux=a, alpha_n=g(alpha), colsum=cs, colsum_alpha=csa)
+            monkeypatch.setattr(ops, "call", real_call)
+            assert ops.L.lib.f2g_gemm_last_path() == 4
+            assert (calls.count("f2g_colsum") == 2) == parts, calls      # (partial rows were used / were not)
+            close(a, want, name=f"dgrad parts={parts}")
+            close(cs, want_cs, rtol=1e-4, name=f"colsum parts={parts}")
+            close(csa - 2.0, want_csa, rtol=1e-4, name=f"colsum_alpha parts={parts}")
+            res[parts] = (cs.clone(), csa.clone())
+        # only one of the two vectors
+        monkeypatch.setattr(ops, "COLSUM_PARTS", True)
+        cs1 = torch.zeros(N, device=DEV)
+        o1 = torch.empty(M, N, device=DEV)
+        ops.gemm(ops.mat(g(G)), ops.mat(Wd), o1, colsum=cs1)
+        close(cs1, dp.sum(0), rtol=1e-4, name="colsum alone")
+    finally:
+        ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS = was
+    # exact fp32 has no wide epilogue: the library refuses partial rows loudly
+    d = ops.GemmDesc()
+    d.A, d.B = ops.mat(g(G)), ops.mat(g(W))
+    o = torch.empty(M, N, device=DEV)
+    ws = torch.zeros(2 * ((M + 127) // 128), N, device=DEV)
+    e = ops.Epilogue()
+    e.C, e.ldc, e.colsum, e.colsum_part_ld = o.data_ptr(), N, ws.data_ptr(), N
+    d.E, d.form, d.split_k, d.precision = e, 0, 1, 0
+    assert ops.L.lib.f2g_gemm_colsum_part_rows(C.byref(d)) == 0
+    assert ops.L.lib.f2g_gemm(C.byref(d), ops.L.stream_ptr()) != 0
