@@ -244,7 +244,7 @@ def test_half_precision_arena_keeps_the_dtype_agnostic_path():
         assert b.flat.dtype == dt and b.flat.numel() == 33 * 5 + 7 + 2
         assert float(b.flat[:b.n].float().abs().max()) == 0.0
         assert b.flat[b.n:].float().tolist() == [1.0, 1.0]
-        assert all(p.grad is v for p, v in zip(ps, b.views))
+        assert all(p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape for p, v in zip(b.params, b.views))
         st = b.flag_staging()
         assert st.dtype == dt and st.is_pinned() and b.flag_staging() is st
     assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
