@@ -163,6 +163,7 @@ def main():
             sch.step_batch()
         elif not FROZEN[0]:
             ops.bump_weight_epoch(params)
+            ops.rebuild_derived(params)      # (batched: what ScaledAdam.step does behind its update)
 
     audio_d = synthetic_batch(B, T, 1234 + rank, device)
     audio_g = synthetic_batch(B, T, 4321 + rank, device)

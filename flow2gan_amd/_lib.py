@@ -46,6 +46,18 @@ class Epilogue(C.Structure):
     ]
 
 
+class MultiEntry(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("inp", C.c_void_p), ("kind", C.c_int32), ("blocks", C.c_int32),
+                ("n", C.c_int32 * 4), ("s", C.c_int64 * 4)]
+
+
+MULTI_MAX = 48
+
+
+class MultiDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("_pad", C.c_int32), ("e", MultiEntry * MULTI_MAX)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("A", Operand), ("B", Operand), ("E", Epilogue), ("form", C.c_int32),
                 ("split_k", C.c_int32), ("precision", C.c_int32), ("_pad3", C.c_int32)]
@@ -222,6 +234,7 @@ _SIGS = {
     "f2g_fused_block_multi": [C.POINTER(DwnormFwd), C.POINTER(FusedMlpDesc), C.c_int32],
     "f2g_istft_ola_multi": [C.POINTER(OlaMultiDesc), _P, _I, _I, _F, _I],
     "f2g_split_bf16x3": [_P, _P, _L, _I, _I],
+    "f2g_multi": [C.POINTER(MultiDesc)],
 }
 EXPORTS = sorted(list(_SIGS) + ["f2g_version", "f2g_last_error", "f2g_gemm_last_path",
                                  "f2g_gemm_lean_ok", "f2g_gemm_wgrad_lean", "f2g_fused_mlp_ok",
@@ -314,7 +327,14 @@ def ptr(t) -> int | None:
 _DRYRUN = os.environ.get("F2G_DRYRUN", "0") == "1"
 
 
+# Set by ops.WeightBatch while re-layout operations are being collected for one f2g_multi launch: any OTHER
+# kernel call first flushes what is pending (program order between the batch and everything else is kept).
+PRE_CALL = None
+
+
 def call(name: str, *args):
+    if PRE_CALL is not None and name != "f2g_multi":
+        PRE_CALL()
     if _DRYRUN:
         stream_ptr()
         return

@@ -1119,6 +1119,14 @@ extern "C" int f2g_conv33_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
   if (d->S <= 0 || d->H <= 0 || d->Win <= 0) return F2G_OK;
   const int W = d->Win;
   if (W > 112 || d->x_line >= (1ll << 24)) return F2G_EINVAL;     // 3 * (W + 2) staged pixels <= P33
+  // geometry of the output map and of the two roles (forward: bias / slope; data gradient: mask_src + colsum,
+  // whose source shares y's geometry by construction -- it is addressed with y's strides)
+  if (d->y_line < (long long)W * C || (d->y != d->x && d->y_seq < (long long)d->H * d->y_line)) return F2G_EINVAL;
+  if ((d->y_line & 3) || (d->y_seq & 3) || (((uintptr_t)d->y) & 15)) return F2G_EINVAL;
+  if (d->mask_src && (d->lrelu_slope != 0.f || d->bias || (((uintptr_t)d->mask_src) & 15))) {
+    f2g_set_error("f2g_conv33_fwd: mask_src (data-gradient role) excludes bias / lrelu_slope (forward role)");
+    return F2G_EINVAL;
+  }
   int R = 256 / W;                                   // whole rows per tile
   if (R > d->H) R = d->H;
   while (R > 1 && (R + 2) * (W + 2) > P33) --R;

@@ -562,6 +562,12 @@ int f2g_leanw6t_ok(const f2g_gemm_desc& d, int split) {
   const f2g_operand& A = d.A;
   const f2g_operand& B = d.B;
   if (d.form != 2 || d.precision != 3 || !d.E.atomic || d.E.P0o > 0 || d.E.bias || d.E.res) return 0;
+  // the kernels end in a bare atomic accumulation of the accumulators: any other epilogue term goes back to
+  // gemm_leanw6_kernel (which runs the full epilogue)
+  const f2g_epilogue& E = d.E;
+  if ((E.scale != 0.f && E.scale != 1.f) || E.colsum || E.colsum_alpha || E.lrelu_slope != 0.f || E.mask_src ||
+      E.aux || E.prelu_slope || E.c_bf16 || E.x3_out || E.accumulate || A.lrelu_src || A.alpha || B.lrelu_src || B.alpha)
+    return 0;
   if (B.P1 != 1 || B.P0 < 1 || (B.step0 != 1 && B.step0 != 3) || B.unit < 128 || (B.unit % 128) || !B.unbounded) return 0;
   if (B.cols != 5 * B.unit || B.seglen < B.cols || (B.seq_stride % B.unit) || (B.rows % B.P0)) return 0;
   if (A.cols % 128 || A.rows != B.rows || B.pad0 < 0 || B.pad0 > 8) return 0;

@@ -184,8 +184,10 @@ def block_bwd(bp: _Blk, x, z, a, gout, B, F, lens, limit_norm: bool, limit_scale
         share = ops.split_sharing()
     dev = x.device
     rows, Cc, Hh = B * F, bp.C, bp.H
-    (g_w2, g_b2, g_alpha, g_w1, g_b1, g_beta, g_ls, g_wdw, g_bdw, g_gamma) = ops.zeros_many(
-        [(Cc, Hh), (Cc,), (Hh,), (Hh, Cc), (Hh,), (Cc,), (1,), (Cc, 1, bp.K), (Cc,), (Cc, 1)], dev)
+    # (g_alpha and g_b1 side by side: the partial column sums of the PReLU-backward GEMM are then reduced into
+    # both by ONE f2g_colsum, ops.gemm)
+    (g_w2, g_b2, g_alpha, g_b1, g_w1, g_beta, g_ls, g_wdw, g_bdw, g_gamma) = ops.zeros_many(
+        [(Cc, Hh), (Cc,), (Hh,), (Hh,), (Hh, Cc), (Cc,), (1,), (Cc, 1, bp.K), (Cc,), (Cc, 1)], dev)
     # pwconv2: out = W2 prelu(a) + b2 + gamma*x
     ops.colsum(g_b2, gout, rows, Cc)
     with share, ops.split_sharing(gout):   # one split-bf16 image of gout for both GEMMs

@@ -26,6 +26,12 @@ def zeros(*shape, device):
 
 
 def fill_(t, v: float):
+    if BATCH is not None and t.numel() > 0:
+        import struct
+        n = t.numel()
+        BATCH.add(0, ptr(t), 4 * n, None, 0, (n & 0xffffffff, n >> 32, 0, 0),
+                  (struct.unpack("<i", struct.pack("<f", float(v)))[0], 0, 0, 0), n, (t,))
+        return t
     call("f2g_fill", ptr(t), float(v), t.numel())
     return t
 
@@ -103,9 +109,10 @@ def _derived(t, tag, build):
     oid = id(owner)          # (tensors compare element-wise: never use them as dictionary keys)
     ent = _DERIVED.get(oid)
     if ent is None or ent[0]() is not owner:
-        def _gone(_r, oid=oid, d=_DERIVED, e=_OWNER_EPOCH):   # (bound now: globals are gone at exit)
+        def _gone(_r, oid=oid, d=_DERIVED, e=_OWNER_EPOCH, rc=_RECIPES):   # (bound now: globals are gone at exit)
             d.pop(oid, None)
             e.pop(oid, None)
+            rc.pop(oid, None)
         ent = (weakref.ref(owner, _gone), {})
         _DERIVED[oid] = ent
         # (the epoch of a dead tensor whose id was recycled is dropped by ITS weakref callback above;
@@ -116,11 +123,32 @@ def _derived(t, tag, build):
     stamp = _stamp(owner)
     hit = slot.get(key)
     if hit is not None and hit[0] == stamp:
+        if hit[2] is not None and not _REPLAYING:
+            hit[2][2] = True          # (this chain is in use: the next rebuild_derived replays it)
         return hit[1]
     out = build(t)
+    rec = None
     if isinstance(out, torch.Tensor):
         out._f2g_const = True     # a cached re-layout of a parameter (see _split_operand)
-    slot[key] = (stamp, out)
+        # how to make it again: the chain of (tag, builder, view) from the root parameter
+        spec = (tuple(t.shape), tuple(t.stride()), t.storage_offset() - owner.storage_offset())
+        parent = getattr(owner, "_f2g_recipe", None)
+        if isinstance(owner, torch.nn.Parameter) or parent is not None:
+            root_ref, chain = (weakref.ref(owner), ()) if parent is None else parent
+            chain = chain + ((tag, build, spec),)
+            root = root_ref()
+            if root is not None and len(chain) <= 4:
+                ckey = tuple((c[0], c[2]) for c in chain)
+                rec = _RECIPES.setdefault(id(root), {}).get(ckey)
+                if rec is None or rec[0]() is not root:
+                    rec = [root_ref, chain, False]
+                    _RECIPES[id(root)][ckey] = rec
+                else:
+                    rec[1] = chain
+                if not _REPLAYING:
+                    rec[2] = True
+                out._f2g_recipe = (root_ref, chain)
+    slot[key] = (stamp, out, rec)
     return out
 
 
@@ -150,6 +178,154 @@ def _derived_multi(ts, tag, build):
         _DERIVED_MULTI.clear()
     _DERIVED_MULTI[key] = (stamp, out, [weakref.ref(t) for t in ts])
     return out
+
+
+
+# ------------------------------------------------------------------ batched rebuild of the weight images
+# A train step writes every parameter of the sub-model it stepped, so all copies derived from them are stale at
+# the next use: ~830 launches of 3-6 us per mel_24k_base GAN step when each is rebuilt by its own permute4 /
+# copy3 / fill / split launch at first use.  Instead (round 6) every cache entry remembers HOW it was made -- the
+# chain (tag, builder, view) from its root parameter -- and `rebuild_derived(params)`, called by the optimizer
+# (or by bench.py's stand-in for it) right after the weights changed, replays the chains that were USED since
+# the last rebuild with the builders' launches recorded into a WeightBatch: the recorded operations are levelled
+# by their data dependencies (an image of a transposed copy comes after the transpose) and every level leaves
+# as f2g_multi launches of up to 48 operations each.
+BATCH = None
+EAGER_REBUILD = opt("eager_rebuild", True)
+_RECIPES: dict = {}          # id(root parameter) -> {chain key: [weakref(root), chain, used]}
+_REPLAYING = False
+
+
+class WeightBatch:
+    """Records fill / permute4 / copy3 / split3 operations (ops.fill_, permute4, copy3, split3 while
+    ops.BATCH is this object) and launches them as f2g_multi tables, dependency level by level."""
+
+    MAX_BLOCKS = 512
+
+    def __init__(self):
+        self.ops = []          # (level, kind, out_ptr, in_ptr, n, s, items)
+        self.keep = []         # tensors of the recorded operations (alive until the launches are issued)
+        self.starts = []       # sorted start addresses of written ranges
+        self.ranges = {}       # start -> (end, level)
+        self.rstarts = []      # ... of read ranges (write-after-read ordering when memory is reused)
+        self.rranges = {}
+
+    @staticmethod
+    def _level_over(starts, ranges, lo, hi):
+        import bisect
+        lvl = -1
+        i = bisect.bisect_left(starts, hi)
+        while i > 0:
+            i -= 1
+            st = starts[i]
+            end, l = ranges[st]
+            if end > lo:
+                lvl = max(lvl, l)
+            elif lo - st > (1 << 31):      # (no range is longer than 2 GB: nothing further left can reach lo)
+                break
+        return lvl
+
+    def add(self, kind, out_ptr, out_bytes, rd_ptr, rd_bytes, n, s, items, tensors, in_ptr=None, reads_out=False):
+        import bisect
+        lvl = self._level_over(self.starts, self.ranges, out_ptr, out_ptr + out_bytes)           # write after write
+        lvl = max(lvl, self._level_over(self.rstarts, self.rranges, out_ptr, out_ptr + out_bytes))   # ... after read
+        if rd_ptr is not None:
+            lvl = max(lvl, self._level_over(self.starts, self.ranges, rd_ptr, rd_ptr + rd_bytes))    # read after write
+        lvl += 1
+        old = self.ranges.get(out_ptr)
+        if old is None:
+            bisect.insort(self.starts, out_ptr)
+        self.ranges[out_ptr] = (max(out_ptr + out_bytes, old[0] if old else 0), max(lvl, old[1] if old else 0))
+        if rd_ptr is not None:
+            oldr = self.rranges.get(rd_ptr)
+            if oldr is None:
+                bisect.insort(self.rstarts, rd_ptr)
+            self.rranges[rd_ptr] = (max(rd_ptr + rd_bytes, oldr[0] if oldr else 0), max(lvl, oldr[1] if oldr else 0))
+        self.ops.append((lvl, kind, out_ptr, in_ptr if in_ptr is not None else rd_ptr, tuple(n), tuple(s), items))
+        self.keep.extend(tensors)
+
+    def flush(self):
+        if not self.ops:
+            return 0
+        launches = 0
+        ops_, self.ops = sorted(self.ops, key=lambda o: o[0]), []
+        i = 0
+        while i < len(ops_):
+            lvl = ops_[i][0]
+            d = L.MultiDesc()
+            k = 0
+            while i < len(ops_) and ops_[i][0] == lvl and k < L.MULTI_MAX:
+                _, kind, out_ptr, in_ptr, n, s, items = ops_[i]
+                e = d.e[k]
+                e.out, e.inp, e.kind = out_ptr, in_ptr, kind
+                e.blocks = max(1, min(self.MAX_BLOCKS, (items + 255) // 256))
+                for j in range(4):
+                    e.n[j], e.s[j] = int(n[j]), int(s[j])
+                k += 1
+                i += 1
+            d.n = k
+            call("f2g_multi", C.byref(d))
+            launches += 1
+        self.keep = []
+        self.starts, self.ranges, self.rstarts, self.rranges = [], {}, [], {}
+        return launches
+
+
+class weight_batch:
+    """Context: collect the re-layout launches issued inside into f2g_multi launches (flushed on exit, and
+    before any other kernel call made inside)."""
+
+    def __enter__(self):
+        global BATCH
+        self.prev = BATCH
+        if self.prev is None:
+            BATCH = WeightBatch()
+            L.PRE_CALL = BATCH.flush
+        return BATCH
+
+    def __exit__(self, *exc):
+        global BATCH
+        if self.prev is None:
+            b, BATCH = BATCH, None
+            L.PRE_CALL = None
+            b.flush()
+        return False
+
+
+def rebuild_derived(params) -> int:
+    """Rebuild -- batched -- the cached copies derived from `params` (tensors just written by an optimizer
+    step) that were used since their last rebuild.  Returns the number of chains replayed."""
+    global _REPLAYING
+    if not EAGER_REBUILD:
+        return 0
+    n = 0
+    roots = {}
+    for p_ in params:
+        o = p_._base if p_._base is not None else p_
+        roots[id(o)] = o
+    _REPLAYING = True
+    try:
+        with torch.no_grad(), weight_batch():
+            for rid, root in roots.items():
+                rec = _RECIPES.get(rid)
+                if not rec:
+                    continue
+                for key in sorted(rec, key=len):          # parents before children
+                    ent = rec[key]
+                    if ent[0]() is not root:
+                        del rec[key]
+                        continue
+                    if not ent[2]:
+                        continue
+                    ent[2] = False
+                    cur = root
+                    for tag, build, spec in ent[1]:
+                        shape, stride, off = spec
+                        cur = _derived(cur.as_strided(shape, stride, cur.storage_offset() + off), tag, build)
+                    n += 1
+    finally:
+        _REPLAYING = False
+    return n
 
 
 def transposed(w2d):
@@ -386,6 +562,10 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
         call("f2g_gemm", C.byref(d))
     if parts is not None:
         nrows, ncol = parts.shape[0], Bm.rows
+        if colsum is not None and colsum_alpha is not None and ptr(colsum) == ptr(colsum_alpha) + 4 * ncol:
+            # (the two vectors lie side by side, as the partial matrices do: one reduction for both)
+            call("f2g_colsum", ptr(colsum_alpha), ptr(parts), parts.stride(0), None, 0, nrows, 2 * ncol)
+            return out
         if colsum_alpha is not None:
             call("f2g_colsum", ptr(colsum_alpha), ptr(parts), parts.stride(0), None, 0, nrows, ncol)
         if colsum is not None:
@@ -403,6 +583,17 @@ COLSUM_PARTS_MIN_ROWS = 2048
 LEAN_DGRAD = opt("lean_dgrad", True)
 LEAN_SPLIT = opt("lean_split", True)
 CONV32_SPLIT = opt("conv32_split", True)   # split-bf16 direct MRD convs
+
+
+def split3(img, src, src_off_bytes: int, ld: int, rows: int, K: int):
+    """f2g_split_bf16x3: img (bf16, rows * K * 3) = three-piece image of the (rows, K) fp32 matrix at
+    src + src_off_bytes with row stride ld (recorded into an open WeightBatch instead of launched)."""
+    if BATCH is not None and rows > 0:
+        BATCH.add(3, ptr(img), rows * K * 6, ptr(src) + src_off_bytes, 4 * ((rows - 1) * ld + K), (rows, K, 0, 0),
+                  (ld, 0, 0, 0), rows * (K // 4), (img, src))
+        return img
+    call("f2g_split_bf16x3", ptr(img), ptr(src) + src_off_bytes, ld, rows, K)
+    return img
 
 
 def split_bf16(t):
@@ -513,7 +704,7 @@ def _x3_operand(o: Operand) -> Operand:
     if o.P0 == 1 and o.P1 == 1:
         def build(tt):
             img = torch.empty(rows * K * 3, device=tt.device, dtype=torch.bfloat16)
-            call("f2g_split_bf16x3", ptr(img), ptr(tt) + off, ld, rows, K)
+            split3(img, tt, off, ld, rows, K)
             return img
         img = derived(t, ("x3", off, rows, K, ld), build) if _is_const(t) else build(t)
         shift = 0
@@ -547,7 +738,7 @@ def x3_flat_image(t):
     n = t.numel()
     assert t.is_contiguous() and n % 32 == 0 and t.dtype == torch.float32
     img = torch.empty(n * 3, device=t.device, dtype=torch.bfloat16)
-    call("f2g_split_bf16x3", ptr(img), ptr(t), 32, n // 32, 32)
+    split3(img, t, 0, 32, n // 32, 32)
     return img
 
 
@@ -663,7 +854,7 @@ def x3_image(t2d):
     def build(t):
         rows, K = t.shape
         img = torch.empty(rows * K * 3, device=t.device, dtype=torch.bfloat16)
-        call("f2g_split_bf16x3", ptr(img), ptr(t), K, rows, K)
+        split3(img, t, 0, K, rows, K)
         return img
     return derived(t2d, "x3img", build) if _is_const(t2d) else build(t2d)
 
@@ -1369,11 +1560,23 @@ def rows_to_bct(out, x, B, Cc, F):
 def permute4(out, x, dims, strides, in_offset=0):
     n0, n1, n2, n3 = dims
     s0, s1, s2, s3 = strides
+    if BATCH is not None and n0 * n1 * n2 * n3 > 0:
+        lo = sum(min(0, (n - 1) * st) for n, st in zip(dims, strides))
+        hi = sum(max(0, (n - 1) * st) for n, st in zip(dims, strides)) + 1
+        BATCH.add(1, ptr(out), 4 * n0 * n1 * n2 * n3, ptr(x) + 4 * (in_offset + lo), 4 * (hi - lo), dims, strides,
+                  n0 * n1 * n2 * n3, (out, x), in_ptr=ptr(x) + 4 * in_offset)
+        return out
     call("f2g_permute4", ptr(out), ptr(x) + 4 * in_offset, n0, n1, n2, n3, s0, s1, s2, s3)
     return out
 
 
 def copy3(out, so0, so1, x, si0, si1, n0, n1, n2, accumulate=False, out_offset=0, in_offset=0):
+    if BATCH is not None and n0 * n1 * n2 > 0 and min(so0, so1, si0, si1) >= 0:
+        BATCH.add(2, ptr(out) + 4 * out_offset, 4 * ((n0 - 1) * so0 + (n1 - 1) * so1 + n2),
+                  ptr(x) + 4 * in_offset, 4 * ((n0 - 1) * si0 + (n1 - 1) * si1 + n2),
+                  (n0, n1, n2, 1 if accumulate else 0), (so0, so1, si0, si1), n0 * n1 * n2, (out, x),
+                  reads_out=bool(accumulate))
+        return out
     call("f2g_copy3", ptr(out) + 4 * out_offset, so0, so1, ptr(x) + 4 * in_offset, si0, si1, n0,
          n1, n2, 1 if accumulate else 0)
     return out

@@ -164,7 +164,9 @@ class ScaledAdam(Optimizer):
         # derived-weight cache (transposes, window-major conv weights) that THESE tensors changed
         # (the other network's cached copies stay valid)
         from . import ops
-        ops.bump_weight_epoch([p for p, _ in plan["tensors"]])
+        written = [p for p, _ in plan["tensors"]]
+        ops.bump_weight_epoch(written)
+        ops.rebuild_derived(written)     # (the copies in use since the last step, as a few f2g_multi launches)
         return loss
 
     # ---------------------------------------------------------------- introspection / checkpoints

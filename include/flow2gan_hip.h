@@ -497,6 +497,31 @@ int f2g_period_fold_bwd(float* gx, const float* gout, int32_t B, int32_t T, int3
 int f2g_log_clip(float* x, int64_t n, float clip, f2g_stream_t stream);
 /* fill */
 int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
+/* A table of small, mutually INDEPENDENT re-layout operations as one launch (csrc/multi.hip): what rebuilding the
+ * derived weight images of a sub-model after an optimizer step consists of (reference: the optimizer writes
+ * every parameter each step, optim.py:451-507, so transposes / window-major copies / operand images cannot be
+ * kept across steps).  kind: F2G_MULTI_FILL     out[0..n) = v            n = n[0] | n[1] << 32, v = bits s[0]
+ *                          F2G_MULTI_PERMUTE4 f2g_permute4             n = dims, s = input strides
+ *                          F2G_MULTI_COPY3    f2g_copy3                n = {n0, n1, n2, accumulate},
+ *                                                                      s = {so0, so1, si0, si1}
+ *                          F2G_MULTI_SPLIT3   f2g_split_bf16x3         n = {rows, K}, s[0] = ld
+ * `blocks` = blocks of 256 threads the entry gets (>= 1; its elements are walked grid-stride). */
+enum { F2G_MULTI_FILL = 0, F2G_MULTI_PERMUTE4 = 1, F2G_MULTI_COPY3 = 2, F2G_MULTI_SPLIT3 = 3 };
+#define F2G_MULTI_MAX 48
+typedef struct {
+  void* out;
+  const void* in;
+  int32_t kind;
+  int32_t blocks;
+  int32_t n[4];
+  int64_t s[4];
+} f2g_multi_entry;
+typedef struct {
+  int32_t n;
+  int32_t _pad;
+  f2g_multi_entry e[F2G_MULTI_MAX];
+} f2g_multi_desc;
+int f2g_multi(const f2g_multi_desc* d, f2g_stream_t stream);
 /* Gradient-exchange arenas of the data-parallel step (reference finetune.py:913-915: DDP with
  * find_unused_parameters; here flow2gan_amd/dist.py): an arena is [n gradients | nflags "used" flags], summed
  * over the ranks by ONE all-reduce.  f2g_bucket_arm zeroes the gradients and sets every flag to 1 (one launch

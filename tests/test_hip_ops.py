@@ -1551,3 +1551,60 @@ def test_fp32_class_column_sums_as_partial_rows(ops, M, N, K, kernel, monkeypatc
     d.E, d.form, d.split_k, d.precision = e, 0, 1, 0
     assert ops.L.lib.f2g_gemm_colsum_part_rows(C.byref(d)) == 0
     assert ops.L.lib.f2g_gemm(C.byref(d), ops.L.stream_ptr()) != 0
+
+
+def test_batched_rebuild_of_derived_weight_images(ops, monkeypatch):
+    """Round 6: after a weight changed, ops.rebuild_derived replays the recipes of the cached copies that were in
+    use -- transposes, padded copies, three-piece images of both, window-major conv weights -- with their
+    launches collected into f2g_multi tables (one per dependency level).  The rebuilt copies must equal what the
+    one-launch-per-copy path builds, bit for bit, and must replace the stale ones in the cache."""
+    from flow2gan_amd import fused, fused_disc as fd
+    monkeypatch.setattr(ops, "EAGER_REBUILD", True)
+    gen = torch.Generator().manual_seed(3)
+    w = torch.nn.Parameter(g(torch.randn(96, 64, generator=gen)))          # (N, K)
+    wc = torch.nn.Parameter(g(torch.randn(32, 32, 5, 1, generator=gen)))   # conv weight
+    wb = torch.nn.Parameter(g(torch.randn(40, generator=gen)))
+
+    def copies():
+        t = ops.transposed(w)                                # permute4
+        return dict(T=t, Timg=ops.x3_image(t),               # split3 of the transposed copy (second level)
+                    img=ops.x3_image(w), padc=fused._pad_cols(w, 128), padr=fused._pad_rows(w, 128),
+                    padv=fused._pad_vec(wb, 64), pack=ops.derived(wc, "pack", fd.pack_conv_weight),
+                    dg=fd._dgrad_weight(wc, 1, 0, 5))
+
+    first = copies()
+    assert all(first[k] is v for k, v in copies().items()), "second call must hit the cache"
+    with torch.no_grad():      # an optimizer step written behind autograd's back
+        w.data.mul_(1.5)
+        wc.data.add_(0.25)
+        wb.data.sub_(1.0)
+    ops.bump_weight_epoch([w, wc, wb])
+    names = []
+    real_call = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (names.append(name), real_call(name, *a))[1])
+    n = ops.rebuild_derived([w, wc, wb])
+    monkeypatch.setattr(ops, "call", real_call)
+    assert n >= 8, n
+    assert set(names) == {"f2g_multi"} and 2 <= len(names) <= 4, names     # (levels: fill / copies / images)
+    batched = copies()
+    names.clear()
+    assert all(batched[k] is not first[k] for k in first)
+    # the same copies built one launch at a time
+    monkeypatch.setattr(ops, "EAGER_REBUILD", False)
+    ops.bump_weight_epoch([w, wc, wb])
+    single = copies()
+    torch.cuda.synchronize()
+    for k in first:
+        assert batched[k] is not single[k]
+        a, b = batched[k], single[k]
+        assert a.dtype == b.dtype and a.shape == b.shape
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a,
+                           b.view(torch.int16) if b.dtype == torch.bfloat16 else b), k
+    assert torch.equal(batched["T"], w.detach().t().contiguous())
+    # a chain that was NOT used since its last rebuild is left to the lazy path
+    monkeypatch.setattr(ops, "EAGER_REBUILD", True)
+    ops.bump_weight_epoch([w])
+    assert ops.rebuild_derived([w]) == 5          # (T, its image, img, padc, padr: all used by `single`)
+    ops.transposed(w)                             # the only copy used in this "step"
+    ops.bump_weight_epoch([w])
+    assert ops.rebuild_derived([w]) == 1
