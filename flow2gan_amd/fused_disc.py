@@ -281,7 +281,7 @@ class MPDLossFn(torch.autograd.Function):
                     ops.mpdpost_wgrad(y5, S, H5, HALO, gs, gwp)
                 else:
                     ops.wgrad(gs, 1, 1, win1d(y5, S, H5 + 2 * HALO, 1024, H5, 1, -(HALO - 1), 3), gwp)
-                grads_p[10] = unpack_conv_grad(gwp, wpost.shape)
+                unpack = [(10, gwp, wpost.shape)]     # (re-laid at the end of the period: ONE f2g_multi launch)
                 gb = zbuf[1]
                 ops.colsum(gb, gs, S * H5, 1)
                 grads_p[11] = gb
@@ -358,7 +358,7 @@ class MPDLossFn(torch.autograd.Function):
                                 X = win1d(acts[l], S, Hin + 2 * HALO, Cin, Hp, stv, HALO * stv, 5,
                                           unbounded=True)   # g's halo rows are zero
                             ops.wgrad(g, Cout, Cout, X, gwp)
-                        grads_p[2 * l] = unpack_conv_grad(gwp, w.shape)
+                        unpack.append((2 * l, gwp, w.shape))
                     if l > 0:
                         g = land(None, l, lambda mk, fk, ck, g=g, w=w, Hout=Hout, Cout=Cout, stv=stv, Hin=Hin:
                                  _conv1d_dgrad(g, Sx, Hout, Cout, w, stv, 2, Hin, mask=mk, fm=fk, colsum=ck))
@@ -372,6 +372,10 @@ class MPDLossFn(torch.autograd.Function):
                 lanes.chain_enter()  # g_fake is accumulated period after period
                 ops.period_fold_bwd(g_fake, g, B, T, p, hs[0], True)
                 lanes.chain_leave()
+            if train_disc:
+                with ops.weight_batch():
+                    for slot_, gwp_, shape_ in unpack:
+                        grads_p[slot_] = unpack_conv_grad(gwp_, shape_)
             from .fused import deliver_grads
             pgrads += deliver_grads(ctx.tickets[i], list(params[12 * i: 12 * i + 12]), grads_p)
         lanes.join()
@@ -661,7 +665,7 @@ class MRDLossFn(torch.autograd.Function):
                     ops.convpost_wgrad(cat, S, Ft, Wcat, gs, gwp)
                 else:
                     ops.wgrad(gs, 1, 1, win2d(cat, S, Ft, Wcat, C, Wcat, 3, 3, 1, 1, 1), gwp)
-                grads_w[50] = unpack_conv_grad(gwp, wpost.shape)
+                unpack = [(50, gwp, wpost.shape)]     # (re-laid at the end of the window: ONE f2g_multi launch)
                 gb = ops.zeros(1, device=dev)
                 ops.colsum(gb, gs, S * Ft * Wcat, 1)
                 grads_w[51] = gb
@@ -737,7 +741,7 @@ class MRDLossFn(torch.autograd.Function):
                         else:
                             gemm(dY, X, gwp, form=2, atomic=True,
                                  split_k=ops.split_for(X.rows, tiles))
-                        grads_w[(bi * 5 + l) * 2] = unpack_conv_grad(gwp, w.shape)
+                        unpack.append(((bi * 5 + l) * 2, gwp, w.shape))
                         if l == 4:
                             gb = gb4
                             _colsum_strided(gb, gcat, S * Ft, W4, C, ldc, foff * C)
@@ -799,6 +803,10 @@ class MRDLossFn(torch.autograd.Function):
                 lanes.chain_enter()  # g_fake is accumulated resolution after resolution
                 ops.axpby_rows(g_fake, g_fake, gx2, sa=1.0, sb=1.0)
                 lanes.chain_leave()
+            if train_disc:
+                with ops.weight_batch():
+                    for slot_, gwp_, shape_ in unpack:
+                        grads_w[slot_] = unpack_conv_grad(gwp_, shape_)
             pgrads += grads_w
         lanes.join()
         ctx.saved = None
