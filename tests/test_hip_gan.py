@@ -125,6 +125,75 @@ def leaky_relu_sign_flips(gan, ogan, real, fake_h, fake_o):
     return tainted
 
 
+class _KinkResolved:
+    """The oracle's discriminators with the SIDE of every leaky-ReLU taken from the HIP path's own activations.
+    Leaky-ReLU has no derivative at 0; a handful of pre-activations (|x| ~ 1e-9 against a forward disagreement
+    of ~4e-8) land on different sides in the two implementations, and the gradient through such a pixel differs
+    by the factor 10 between the slopes.  Re-running the oracle with the HIP path's sign pattern (forward
+    values change by < 1e-8) removes exactly that ambiguity: against THESE gradients every parameter -- the
+    ones downstream of a kink pixel included -- is held to the plain 5e-3 (round-5 verdict, weak 1a).
+    Test infrastructure: patches `leaky_relu` inside oracle/flow2gan_oracle.py for the duration of a call."""
+
+    def __init__(self, gan, real, fake_h):
+        from flow2gan_amd import fused_disc as FD
+        B = real.shape[0]
+        x2 = torch.cat([real, fake_h.detach()], 0).contiguous()
+        self.masks = {}          # (disc, sub, half) -> list of bool masks in the oracle's call order
+        mp, mr = gan.discriminator
+        with torch.no_grad():
+            prm = FD.mpd_params(mp)
+            for i, p in enumerate(mp.periods):
+                st = FD._mpd_forward_one(x2, p, prm[12 * i: 12 * i + 12])
+                ms = []
+                for l in range(1, 6):
+                    a = FD.unhalo(st["acts"][l], 2 * B * p, st["hs"][l])
+                    ms.append((a.reshape(2 * B, p, st["hs"][l], a.shape[-1]).permute(0, 3, 2, 1) > 0).cpu())
+                for h, sl in (("real", slice(0, B)), ("fake", slice(B, 2 * B))):
+                    self.masks[(0, i, h)] = [m[sl] for m in ms]
+            prm = FD.mrd_params(mr)
+            for i, win in enumerate(mr.fft_sizes):
+                st = FD._mrd_forward_one(x2, win, prm[FD.N_MRD_PARAMS * i: FD.N_MRD_PARAMS * (i + 1)])
+                Ft, Wcat, C = st["Ft"], st["Wcat"], FD.MRD_CH
+                cat = st["cat"].view(2 * B, Ft, Wcat, C)
+                ms, foff = [], 0
+                for bi in range(5):
+                    ws = st["widths"][bi]
+                    for l in range(4):
+                        ms.append((st["acts"][bi][l].view(2 * B, Ft, ws[l + 1], C).permute(0, 3, 1, 2) > 0).cpu())
+                    ms.append((cat[:, :, foff:foff + ws[5]].permute(0, 3, 1, 2) > 0).cpu())
+                    foff += ws[5]
+                for h, sl in (("real", slice(0, B)), ("fake", slice(B, 2 * B))):
+                    self.masks[(1, i, h)] = [m[sl] for m in ms]
+
+    def run(self, ogan, fn):
+        """fn() runs the oracle GAN; inside it every discriminator call consumes the recorded masks (the
+        oracle runs sub-discriminator i on the real batch, then on the generated one: _MultiD.forward)."""
+        import collections
+        import types
+        import flow2gan_oracle as O
+        queue = collections.deque()
+        for d in (0, 1):
+            nsub = len(ogan.discriminator[d].discriminators)
+            for i in range(nsub):
+                for h in ("real", "fake"):
+                    queue.extend(self.masks[(d, i, h)])
+
+        def leaky(x, slope):
+            m = queue.popleft()
+            assert m.shape == x.shape, (m.shape, x.shape)
+            return torch.where(m, x, slope * x)
+
+        proxy = types.SimpleNamespace(**{k: getattr(O.F, k) for k in dir(O.F) if not k.startswith("__")})
+        proxy.leaky_relu = leaky
+        real_F, O.F = O.F, proxy
+        try:
+            out = fn()
+        finally:
+            O.F = real_F
+        assert not queue, len(queue)
+        return out
+
+
 @pytest.mark.parametrize("fixture,cfg", [("tiny_stage2", TINY), ("tiny_stage2_44k", TINY44)],
                          ids=["24k", "44k"])
 @pytest.mark.parametrize("tag,n", [("n1", 1), ("n2", 2)])
@@ -168,7 +237,7 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, 
     # ---- discriminator step
     d = gan(mel, audio, lens, n, True, noise=noise)
     want = g[f"{tag}/D/losses"]
-    assert np.allclose([float(v) for v in d], want, rtol=2e-5, atol=2e-5), ([float(v) for v in d], want)
+    assert np.allclose([float(v.detach()) for v in d], want, rtol=2e-5, atol=2e-5), ([float(v.detach()) for v in d], want)
     gan.zero_grad()
     (1.0 * d[0] + 0.1 * d[1]).backward()
     worst = []
@@ -190,11 +259,32 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, 
     assert worst[0][0] < 1.0, worst[:5]
     for p in gan.generator.parameters():
         assert p.grad is None
+    # the parameters whose gradient passes through a kink pixel: against the oracle with the HIP path's
+    # leaky-ReLU sides they are held to the plain 5e-3 as well (exact fp32 and fp32-class arithmetic)
+    resolved = None
+    # (two more CPU passes of the oracle: the n = 1 cases only, ~20 s each)
+    if (d_flipped or flips["fake"]) and _ops0.GEMM_PRECISION != 1 and not pingpong and n == 1:
+        resolved = _KinkResolved(gan, audio, fake_h)
+        ogan.discriminator.load_state_dict({k: v.cpu() for k, v in gan.discriminator.state_dict().items()},
+                                           strict=False)
+    if resolved is not None and d_flipped:
+        def oracle_d():
+            ogan.zero_grad()
+            omp, omr = ogan(mel.cpu(), audio.cpu(), lens, n, True, noise=noise.cpu())
+            (1.0 * omp + 0.1 * omr).backward()
+            return {k: p.grad.clone() for k, p in ogan.discriminator.named_parameters()}
+        og = resolved.run(ogan, oracle_d)
+        kinked = [k for k, _ in gan.discriminator.named_parameters() if d_tol(k) > 5e-3]
+        assert kinked
+        for k, p in gan.discriminator.named_parameters():
+            if k in kinked:
+                err = float((p.grad.cpu().double() - og[k].double()).abs().max())
+                assert err < 5e-3 * float(og[k].abs().max()) + 2e-5, ("kink-resolved", k, err)
     # ---- generator step
     gan.zero_grad()
     ls = gan(mel, audio, lens, n, False, noise=noise)
     want = g[f"{tag}/G/losses"]
-    assert np.allclose([float(v) for v in ls], want, rtol=5e-5, atol=2e-5), ([float(v) for v in ls], want)
+    assert np.allclose([float(v.detach()) for v in ls], want, rtol=5e-5, atol=2e-5), ([float(v.detach()) for v in ls], want)
     total = sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ls))
     total.backward()
     from flow2gan_amd import ops as _ops
@@ -210,6 +300,16 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, 
         # the generated input's path sits on a leaky-ReLU kink: it reaches every generator gradient)
         g_tol = 5e-2 if flips["fake"] else 5e-3
         assert worst[0][0] < g_tol, (worst[:8], sorted(flips["fake"]))
+        if resolved is not None and flips["fake"]:
+            # ... and against the kink-resolved oracle every generator gradient to the plain 5e-3
+            def oracle_g():
+                ogan.zero_grad()
+                ols = ogan(mel.cpu(), audio.cpu(), lens, n, False, noise=noise.cpu())
+                sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ols)).backward()
+                return {k: p.grad.clone() for k, p in ogan.generator.named_parameters()}
+            og = resolved.run(ogan, oracle_g)
+            wr = sorted(((relerr(p.grad, og[k]), k) for k, p in gan.generator.named_parameters()), reverse=True)
+            assert wr[0][0] < 5e-3, ("kink-resolved", wr[:6])
         return
     # The opt-in split-bf16 mode perturbs the generated waveform by ~1e-5, which flips sign() terms of
     # the L1 / hinge / leaky-ReLU gradients (they are discontinuous).  What a flipped pixel adds to a
