@@ -398,7 +398,7 @@ def main():
         # the same step with the weights frozen (derived weight images free after warm-up): what rounds 1-5
         # reported as `value`; a side field now
         FROZEN[0] = True
-        af, ef = timed(1, half)
+        af, ef = timed(2, half)
         FROZEN[0] = False
         frozen = {"value": round(world * af / ef, 2), "unit": "audio-s/s", "ms_per_step": round(1e3 * ef / half, 2),
                   "note": "weights never change, derived weight images cached across steps (--frozen-weights)"}
@@ -406,7 +406,7 @@ def main():
         # the reference's own arithmetic (exact fp32 MFMA, v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered
         # fmaf chain) measured in the same run, with its own per-launch roofline pass
         ops.set_gemm_precision("fp32")
-        a0, e0 = timed(1, half)
+        a0, e0 = timed(2, half)      # (two warm-up steps: the first one after a mode switch builds that mode's weight copies)
         exact = {"gemm": "exact fp32 MFMA for every GEMM and direct conv", "arithmetic": "fp32",
                  "value": round(world * a0 / e0, 2), "unit": "audio-s/s",
                  "ms_per_step": round(1e3 * e0 / half, 2), "dtype": "f32"}
@@ -420,7 +420,7 @@ def main():
         # also report the split-bf16 GEMM mode (3 bf16 MFMAs per product, fp32 accumulate): same
         # <= 1e-4 RMS waveform parity (tests/test_hip_generator.py passes in both modes), not fp32-exact
         ops.set_gemm_precision("bf16x3")
-        a2, e2 = timed(1, half)
+        a2, e2 = timed(2, half)
         fast = {"gemm": "split-bf16 (pre-split hi/lo operand images, 3x v_mfma_f32_32x32x16_bf16 per "
                         "product, fp32 accumulate; lean / K-major weight-gradient / direct-conv kernels): "
                         "a THROUGHPUT mode, not a parity mode",
@@ -446,7 +446,7 @@ def main():
             # fp32-CLASS products on the bf16 matrix pipe (the default headline mode), beside an explicit
             # --gemm fp32 headline
             ops.set_gemm_precision("bf16x6")
-            a6, e6 = timed(1, half)
+            a6, e6 = timed(2, half)
             fast["fp32_class"] = {"gemm": DTYPES["bf16x6"], "value": round(world * a6 / e6, 2),
                                   "unit": "audio-s/s", "ms_per_step": round(1e3 * e6 / half, 2)}
             if not args.no_roofline:
@@ -456,7 +456,7 @@ def main():
             # BASELINE config 2 names bf16 for the generator-only forward: plain bf16 operands,
             # fp32 accumulation and fp32 activations -- a throughput mode, not a parity mode
             ops.set_gemm_precision("bf16")
-            a3, e3 = timed(1, half)
+            a3, e3 = timed(2, half)
             fast["bf16"] = {"gemm": "plain bf16 (1x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate): "
                                     "z and the hidden activation of every block live in HBM as bf16, "
                                     "written by dwnorm / the pwconv1 epilogue; other operands converted",

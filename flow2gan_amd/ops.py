@@ -296,7 +296,11 @@ def rebuild_derived(params) -> int:
     """Rebuild -- batched -- the cached copies derived from `params` (tensors just written by an optimizer
     step) that were used since their last rebuild.  Returns the number of chains replayed."""
     global _REPLAYING
-    if not EAGER_REBUILD:
+    if not EAGER_REBUILD or GEMM_PRECISION in (1, 2):
+        # (the split-bf16 / plain-bf16 modes build their images with f2g_split_bf16 / f2g_to_bf16 / f2g_mlp_pack,
+        # which are not f2g_multi operations -- each would flush the batch in front of itself: measured 29.9
+        # vs 27.0 ms per stage-1 step against the lazy path -- so those throughput modes keep rebuilding at
+        # first use)
         return 0
     n = 0
     roots = {}
