@@ -442,3 +442,38 @@ def test_weight_gradient_split_rule():
         assert 1 <= s <= 512 and rows // s >= 16 * 32, (rows, tiles, s)                 # a chunk keeps >= 16 slabs
         s2 = ops.split_for(rows, tiles, True)
         assert s2 == 1 or rows // s2 >= 4096, (rows, tiles, s2)                          # never below the kernel's rule
+
+
+def test_library_options_and_python_tunables(monkeypatch):
+    """Round 6: one options table in the library (f2g_set_option / f2g_get_option; nothing reads the environment
+    on a launch path) and one override variable for the Python tunables (F2G_OPTS, flow2gan_amd/_opts.py)."""
+    from flow2gan_amd import _lib, _opts
+    names = ("lean", "lean_tall", "lean_tap", "lean_wgrad", "x6_tap", "x6_wide", "x6p", "w6t", "deterministic",
+             "streamk", "conv2ch_v2", "conv32_v2", "conv32_wgrad_v2", "mlp_rt", "mlp_split", "multi_rt384",
+             "multi_rt512")
+    for n in names:
+        v = _lib.get_option(n)
+        assert _lib.set_option(n, v + 5) == v and _lib.get_option(n) == v + 5
+        assert _lib.set_option(n, v) == v + 5 and _lib.get_option(n) == v
+    with pytest.raises(_lib.F2GError):
+        _lib.set_option("no_such_option", 1)
+    with pytest.raises(_lib.F2GError):
+        _lib.get_option("x6pr")            # (a removed kernel's switch is not an option any more)
+    assert _lib.lib.f2g_set_option(None, 1) != 0
+    # Python side: typed like the default, unknown names ignored, booleans from 0 / 1
+    monkeypatch.setattr(_opts, "_OPTS", _opts._parse("x6f_min_k=160, fuse_lrelu=3,disc_lanes=0,  x6p=2,junk"))
+    assert _opts.opt("x6f_min_k", 384) == 160 and _opts.opt("fuse_lrelu", 0) == 3
+    assert _opts.opt("disc_lanes", True) is False and _opts.opt("spec_pad", True) is True
+    assert _opts.opt("x6_min_k", 2048) == 2048
+    # no per-feature environment switch is left in the package (the kept ones are listed in _opts.py's docstring)
+    import glob
+    kept = {"F2G_GEMM", "F2G_STREAMS", "F2G_DETERMINISTIC", "F2G_WEIGHT_CACHE", "F2G_LIB_PATH", "F2G_DRYRUN",
+            "F2G_DIST_TIMEOUT_S", "F2G_OPTS"}
+    for f in glob.glob(os.path.join(ROOT, "flow2gan_amd", "**", "*.py"), recursive=True):
+        for m in re.finditer(r'environ(?:\.get)?\(\s*"(F2G_[A-Z0-9_]+)"', open(f).read()):
+            assert m.group(1) in kept, (f, m.group(1))
+    for f in glob.glob(os.path.join(ROOT, "flow2gan_amd", "csrc", "*.hip")) + \
+            glob.glob(os.path.join(ROOT, "flow2gan_amd", "csrc", "*.h")):
+        src = open(f).read()
+        if not f.endswith("capi.hip"):
+            assert "getenv(" not in src, f
