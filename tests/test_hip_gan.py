@@ -262,8 +262,8 @@ def test_gan_steps_against_reference_vectors(f2g, golden, tag, n, fixture, cfg, 
     # the parameters whose gradient passes through a kink pixel: against the oracle with the HIP path's
     # leaky-ReLU sides they are held to the plain 5e-3 as well (exact fp32 and fp32-class arithmetic)
     resolved = None
-    # (two more CPU passes of the oracle: the n = 1 cases only, ~20 s each)
-    if (d_flipped or flips["fake"]) and _ops0.GEMM_PRECISION != 1 and not pingpong and n == 1:
+    # (two more CPU passes of the oracle, ~20 s: the 24 kHz n = 1 case of the two parity arithmetics)
+    if (d_flipped or flips["fake"]) and _ops0.GEMM_PRECISION != 1 and not pingpong and n == 1 and fixture == "tiny_stage2":
         resolved = _KinkResolved(gan, audio, fake_h)
         ogan.discriminator.load_state_dict({k: v.cpu() for k, v in gan.discriminator.state_dict().items()},
                                            strict=False)
@@ -356,12 +356,12 @@ def test_concurrent_lanes_match_serial_launch_order(f2g, golden, monkeypatch):
         gan.zero_grad()
         d = gan(mel, audio, lens, 2, True, noise=noise)
         (d[0] + 0.1 * d[1]).backward()
-        out["D"] = [float(v) for v in d]
+        out["D"] = [float(v.detach()) for v in d]
         out["gD"] = {k: p.grad.clone() for k, p in gan.discriminator.named_parameters()}
         gan.zero_grad()
         ls = gan(mel, audio, lens, 2, False, noise=noise)
         sum(w * l for w, l in zip((1.0, 0.1, 1.0, 0.1, 45.0), ls)).backward()
-        out["G"] = [float(v) for v in ls]
+        out["G"] = [float(v.detach()) for v in ls]
         out["gG"] = {k: p.grad.clone() for k, p in gan.generator.named_parameters()}
         torch.cuda.synchronize()
         return out
