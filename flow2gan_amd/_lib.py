@@ -214,6 +214,7 @@ _SIGS = {
     "f2g_conv32_s2_fwd": [C.POINTER(Conv32Desc)],
     "f2g_conv32_s2_dgrad": [C.POINTER(Conv32Desc)],
     "f2g_conv33_fwd": [C.POINTER(Conv32Desc)],
+    "f2g_conv33_wgrad": [C.POINTER(Conv32Desc), _P],
     "f2g_conv32_s2_wgrad": [C.POINTER(Conv32Desc), _P],
     "f2g_conv2ch_fwd": [C.POINTER(Conv2chDesc)],
     "f2g_conv2ch_wgrad": [C.POINTER(Conv2chDesc)],

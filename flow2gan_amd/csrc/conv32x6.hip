@@ -997,6 +997,139 @@ __global__ __launch_bounds__(512, 1) void conv33_x6_kernel(const f2g_conv32_desc
   }
 }
 
+
+// ---- weight gradient of the (3, 3) fifth layer (round 6) -------------------------------------------------
+// gw[co][tap][ci] += sum_px g[px][co] * x[px + tap][ci]   (discriminators.py:171-181 backward; as an implicit
+// GEMM on the generic fp32 kernel -- 32 x 288 outputs over 10^5 pixels through bounds-tested windows -- it ran at
+// 31 TFLOP/s).  Same tile as conv33_x6_kernel: R whole rows of a 7-112 column band image, staged with a zero
+// column on either side and a row above / below, so that in the FLAT order of the staged patch the nine taps are
+// nine constant offsets.  The gradient rows are staged in that same padded flat order (zeros in the border
+// columns), which makes the reduction a plain walk over flat positions p: gw[tap] += G[p] * X[p + off(tap)], the
+// border positions contributing G = 0.  k = pixels is the slow axis of both operands, so they are staged as
+// three bf16 planes with 64-byte pixels (split once while staging) and the fragments come from
+// ds_read_b64_tr_b16 (conv32_s2_wgrad6_kernel's scheme).  A k step = 16 consecutive flat positions; the block's
+// 8 waves take the k steps round-robin and keep all nine 32 x 32 tap tiles (144 accumulator registers) over ALL
+// tiles of their persistent block -- 3 gradient + 27 input fragments per 54 MFMAs -- and meet once at the end:
+// tap by tap through LDS, one atomic per output and block.
+constexpr int W33_GP = 352;      // gradient positions of a tile: R * (W + 2) rounded up to a k step
+constexpr int W33_XP = 384;      // input positions: 1 + (R + 2) * (W + 2) + the last k step's overhang
+constexpr int W33_GPL = W33_GP * 64, W33_XPL = W33_XP * 64;
+
+__global__ __launch_bounds__(512, 1) void conv33_wgrad6_kernel(const f2g_conv32_desc d, float* gw, int R,
+                                                               int tiles_h, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+  unsigned char* Xp = smb;                      // [3 pieces][W33_XP] pixels x 32 bf16; position 0 = slack
+  unsigned char* Gp = smb + 3 * W33_XPL;        // [3 pieces][W33_GP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hh = lane >> 5;
+  const int W = d.Win, PW = W + 2, npx = (R + 2) * PW, ngp = R * PW, nks = (ngp + 15) >> 4;
+  const unsigned mgPW = magic_of(PW);
+  // everything a fragment may touch and a tile does not rewrite (slack position, k-step overhang) is zero
+  for (int o = tid * 16; o < 3 * (W33_XPL + W33_GPL); o += 512 * 16) *reinterpret_cast<u32x4*>(smb + o) = u32x4{0u, 0u, 0u, 0u};
+  // chunk id = tid + 512 q -> (flat position, 4 channels)
+  constexpr int NQ = (W33_GP * 8 + 511) / 512;          // 6: covers the patch (<= 352 positions) and the gradient rows
+  const int c4 = tid & 7;
+  int xrow[NQ], xoff[NQ], grow[NQ], goff[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int px = (tid + 512 * q) >> 3;
+    {   // input patch position px = (pr + 1) * PW + (pc + 1)
+      const int pr = fast_div(px, PW, mgPW), pc = px - pr * PW;
+      const bool ok = px < npx && pc >= 1 && pc <= W;
+      xrow[q] = px < npx ? (ok ? pr - 1 : -(1 << 20)) : -(1 << 21);     // (< -2^20: border = zeros; < -2^21: not staged)
+      xoff[q] = (pr - 1) * (int)d.x_line + (pc - 1) * C + c4 * 4;
+    }
+    {   // gradient position px = r * PW + (c + 1)
+      const int r = fast_div(px, PW, mgPW), pc = px - r * PW;
+      const bool ok = px < ngp && pc >= 1 && pc <= W;
+      grow[q] = px < ngp ? (ok ? r : -(1 << 20)) : -(1 << 21);
+      goff[q] = r * (int)d.y_line + (pc - 1) * C + c4 * 4;
+    }
+  }
+  // transposed-read lane roles (conv32_s2_wgrad6_kernel): 16-lane group g4 = (channel half, k half)
+  const int g4 = lane >> 4, i16 = lane & 15;
+  const int kpix = (g4 >> 1) * 8 + (i16 >> 2);
+  const int chb = (g4 & 1) * 32 + (i16 & 3) * 8;
+  const int go = kpix * 64 + chb;
+  int xo[T33];
+#pragma unroll
+  for (int t = 0; t < T33; ++t) xo[t] = (1 + PW + (t / 3 - 1) * PW + (t % 3 - 1) + kpix) * 64 + chb;
+  f32x16 acc[T33];
+#pragma unroll
+  for (int t = 0; t < T33; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  auto mfma6 = [&](const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  };
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int sq = tile / tiles_h, h0 = (tile - sq * tiles_h) * R;
+    const float* xs = d.x + (long long)sq * d.x_seq + (long long)h0 * d.x_line;
+    const float* gs = d.y + (long long)sq * d.y_seq + (long long)h0 * d.y_line;
+    f32x4 px_[NQ], pg_[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int hx = h0 + xrow[q], hg = h0 + grow[q];
+      px_[q] = *reinterpret_cast<const f32x4*>((xrow[q] > -(1 << 20) && hx >= 0 && hx < d.H) ? xs + xoff[q] : c6_zero);
+      pg_[q] = *reinterpret_cast<const f32x4*>((grow[q] > -(1 << 20) && hg < d.H) ? gs + goff[q] : c6_zero);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int px = (tid + 512 * q) >> 3;
+      u32x2 pk[3];
+      if (xrow[q] > -(1 << 21)) {
+        split3(px_[q], pk[0], pk[1], pk[2]);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x2*>(Xp + pc * W33_XPL + (px + 1) * 64 + c4 * 8) = pk[pc];
+      }
+      if (grow[q] > -(1 << 21)) {
+        split3(pg_[q], pk[0], pk[1], pk[2]);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x2*>(Gp + pc * W33_GPL + px * 64 + c4 * 8) = pk[pc];
+      }
+    }
+    __syncthreads();
+    for (int ks = wave; ks < nks; ks += 8) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[q] = tr_pix8(Gp + q * W33_GPL + ks * (16 * 64) + go);
+#pragma unroll
+      for (int t = 0; t < T33; ++t) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[q] = tr_pix8(Xp + q * W33_XPL + ks * (16 * 64) + xo[t]);
+        mfma6(a, b, acc[t]);
+      }
+    }
+    __syncthreads();   // every wave is done with this tile's planes
+  }
+  // ---- flush: the waves' partial tap tiles are summed through LDS, one tap at a time
+  float* red = reinterpret_cast<float*>(smb);   // [8 waves][16][64]
+#pragma unroll
+  for (int t = 0; t < T33; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[t][e];
+    __syncthreads();
+    if (wave == (t & 7)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) v += red[(w8 * 16 + e) * 64 + lane];
+        const int co = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        atomicAdd(gw + co * (T33 * C) + t * C + li, v);
+      }
+    }
+  }
+}
+
 template <int TH_, int TW_>
 constexpr size_t fwd6_smem() {
   return (size_t)2 * ((TH_ + 2) * (TW_ + 4) * PB + 64) + 2 * TG * WBB + 4 * 16 * 64 * sizeof(float);
@@ -1143,5 +1276,40 @@ extern "C" int f2g_conv33_fwd(const f2g_conv32_desc* d, f2g_stream_t stream) {
   }
   const int grid = (int)(nt < 256 ? nt : 256);          // one resident block per CU
   hipLaunchKernelGGL(conv33_x6_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, *d, R, tiles_h, (int)nt);
+  return f2g_check_launch();
+}
+
+// Weight gradient of that layer, fp32 class: x = the layer's input (S, H, W, 32), y = the gradient of its
+// pre-activation (S, H, W, 32; both optionally strided slices of wider maps), gw (32, 9 * 32) [co][tap][ci] +=.
+extern "C" int f2g_conv33_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stream_t stream) {
+  if (!d || !d->x || !d->y || !gw || d->precision != 3 || d->Win != d->Wout) return F2G_EINVAL;
+  if ((((uintptr_t)d->x) & 15) || (((uintptr_t)d->y) & 15) || (d->x_line & 3) || (d->x_seq & 3) || (d->y_line & 3) ||
+      (d->y_seq & 3))
+    return F2G_EINVAL;
+  if (d->S <= 0 || d->H <= 0 || d->Win <= 0) return F2G_OK;
+  const int W = d->Win;
+  if (W > 112 || d->x_line >= (1ll << 24) || d->y_line >= (1ll << 24) || d->x_line < (long long)W * C ||
+      d->y_line < (long long)W * C)
+    return F2G_EINVAL;
+  int R = 256 / W;                                   // whole rows per tile (conv33_x6_kernel's rule)
+  if (R > d->H) R = d->H;
+  while (R > 1 && (R + 2) * (W + 2) > P33) --R;
+  if (R < 1 || (R + 2) * (W + 2) > P33) return F2G_EINVAL;
+  const int tiles_h = (d->H + R - 1) / R;
+  const long long nt = (long long)tiles_h * d->S;
+  if (nt >= (1ll << 30)) return F2G_EINVAL;
+  constexpr size_t smem = (size_t)3 * (W33_XPL + W33_GPL);
+  static_assert(smem >= (size_t)8 * 16 * 64 * 4, "the flush reuses the planes as its reduction buffer");
+  // (largest input position a fragment touches: (R + 2) * (W + 2) + 17; gradient positions: R * (W + 2) + 15)
+  static_assert(P33 + 18 <= W33_XP && P33 <= W33_GP, "plane sizes");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv33_wgrad6_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = true;
+  }
+  const int grid = (int)(nt < 256 ? nt : 256);          // one resident block per CU: 256 x 9216 atomics at most
+  hipLaunchKernelGGL(conv33_wgrad6_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, *d, gw, R, tiles_h,
+                     (int)nt);
   return f2g_check_launch();
 }

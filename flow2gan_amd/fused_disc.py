@@ -738,6 +738,11 @@ class MRDLossFn(torch.autograd.Function):
                             ops.conv2ch_wgrad(packed, Ft * ldp, ldp, lo * 2, S, Ft, Win, g, gwp)
                         elif l in (1, 2, 3) and DIRECT_CONV32 and ops.GEMM_PRECISION in (0, 1, 3):
                             ops.conv32_s2_wgrad(x_in, g, S, Ft, Win, Wout, gwp)
+                        elif (l == 4 and DIRECT_CONV32 and ops.GEMM_PRECISION == 3 and ops.CONV33_X6
+                              and Wout <= ops.CONV33_MAX_W):
+                            # (round 6) the (3, 3) layer's weight gradient as a direct fp32-class kernel over the
+                            # band's slice of the concatenated gradient map (31 TFLOP/s as an implicit GEMM)
+                            ops.conv33_wgrad(x_in, gcat, S, Ft, Wout, gwp, g_off=foff * C, g_line=ldc, g_seq=Ft * ldc)
                         else:
                             gemm(dY, X, gwp, form=2, atomic=True,
                                  split_k=ops.split_for(X.rows, tiles))

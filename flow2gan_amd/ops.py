@@ -922,6 +922,25 @@ def conv33(x, S: int, H: int, W: int, w_packed, bias, slope: float, y, x_off: in
     return y
 
 
+def conv33_wgrad(x, g, S: int, H: int, W: int, gw, g_off: int = 0, g_line=None, g_seq=None):
+    """Weight gradient of the (3, 3) band layer, fp32 class (conv32x6.hip: conv33_wgrad6_kernel): x (S, H, W, 32)
+    the layer's input, g the gradient of its pre-activation -- a band's slice of the concatenated gradient map
+    (g_off floats in, line / sequence strides in floats) --, gw (32, 9 * 32) [co][tap][ci] +=."""
+    d = L.Conv32Desc()
+    d.x, d.x_line, d.x_seq = ptr(x), W * 32, H * W * 32
+    d.S, d.H, d.Win, d.Wout = S, H, W, W
+    d.precision = 3
+    d.y = ptr(g) + 4 * g_off
+    d.y_line = g_line if g_line is not None else W * 32
+    d.y_seq = g_seq if g_seq is not None else H * d.y_line
+    if GEMM_TIMER is not None:
+        GEMM_TIMER.time(lambda: call("f2g_conv33_wgrad", C.byref(d), ptr(gw)),
+                        2.0 * S * H * W * 32 * 9 * 32, (2, 32, 9 * 32, S * H * W))
+    else:
+        call("f2g_conv33_wgrad", C.byref(d), ptr(gw))
+    return gw
+
+
 def conv32_s2_dgrad(g, S: int, H: int, Win: int, Wout: int, wT, gx, g_seq=None, g_line=None,
                     g_off: int = 0, mask=None, fm=None, colsum=None):
     """Data gradient of Conv2d(32, 32, (3, 9), stride (1, 2), padding (1, 4)): g (S, H, Wout, 32)

@@ -636,6 +636,11 @@ int f2g_conv32_s2_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stream_t stream
  * the layer below and leave the column sums of the stored gradient as in f2g_conv32_s2_dgrad (fm_ref must
  * be NULL). */
 int f2g_conv33_fwd(const f2g_conv32_desc* d, f2g_stream_t stream);
+/* Weight gradient of that layer (discriminators.py:171-181 backward), fp32 class (precision = 3): x = the layer's
+ * input (S, H, W, 32), y = the gradient of its pre-activation (S, H, W, 32) -- both optionally strided slices of
+ * wider maps through x_line / x_seq, y_line / y_seq --, gw (32, 9 * 32) [co][tap][ci] += sum over the pixels; W <= 112.
+ * The caller zero-initialises gw (blocks accumulate atomically).  w / bias / slope / mask fields unused. */
+int f2g_conv33_wgrad(const f2g_conv32_desc* d, float* gw, f2g_stream_t stream);
 
 /* First layer of every MRD band stack, Conv2d(2, 32, (3, 9), stride 1, padding (1, 4))
  * (discriminators.py:171,195-203), as direct kernels (conv2ch.hip).  The input is a frequency band

@@ -1072,6 +1072,15 @@ def test_direct_conv33_fp32_class(ops, S, H, W):
         want_m = gref * torch.where(yact > 0, 1.0, 0.1).double()
         close(gm.cpu().double(), want_m, rtol=2e-5, name="conv33 masked data gradient")
         close(cs.cpu().double(), want_m.sum(0), rtol=1e-4, name="conv33 column sums")
+        # (round 6) the weight gradient as a direct kernel: x = the layer's input, the gradient = the band's slice
+        # of the concatenated gradient map; accumulates onto what gw holds
+        gwref = torch.autograd.grad(torch.nn.functional.conv2d(xd, (wq := w.double().requires_grad_(True)),
+                                                               padding=(1, 1)),
+                                    wq, gy.permute(0, 3, 1, 2).double())[0]          # (co, ci, 3, 3)
+        gwp = torch.full((32, 9 * 32), 0.5, device=DEV)
+        ops.conv33_wgrad(g(x), g(gcat), S, H, W, gwp, g_off=foff * 32, g_line=Wcat * 32, g_seq=H * Wcat * 32)
+        got = fd.unpack_conv_grad(gwp, (32, 32, 3, 3)).cpu().double() - 0.5
+        close(got, gwref, rtol=3e-5, name="conv33 weight gradient")
     finally:
         ops.GEMM_PRECISION = was
 
