@@ -2714,6 +2714,87 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
   if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
+// The in-kernel-split kernel for N <= 32 output columns (round 6): the data gradients that land on a 32-channel
+// map -- the second MPD layer's stride residues, 341376 x 32 x 256 -- ran on the generic fp32 kernel's 128 x 32
+// tiles at 50 TFLOP/s (matrix pipe 0.29 busy behind bounds-tested window loads).  Same schedule as
+// gemm_x6f_kernel<true> on a 128 x 32 tile: four waves of 32 x 32, the weight slab (32 rows of the cached image)
+// stored as it comes, six fragment reads each way per 12 MFMAs, generic epilogue (row maps, masks, column sums).
+__global__ __launch_bounds__(256, 2) void gemm_x6n_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                          const x6_rows R) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int PITCH = 208, OPER = 128 * PITCH, NJ = 4, NJW = 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128, n0 = 0;
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
+  const unsigned rowbytesW = (unsigned)(K / 32) * 192u;
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)N * rowbytesW, 0x00020000);
+  unsigned voA[NJ], voW[NJW];
+  int lo[NJ], loW[NJW];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int id = tid + 256 * j, row = id >> 3, c = id & 7;
+    const int r = m0 + row, sq = r / R.P0;
+    voA[j] = r < M ? (unsigned)sq * R.seq6 + (unsigned)(r - sq * R.P0) * R.step6 + R.off6 + c * 16 : 0xf0000000u;
+    lo[j] = row * PITCH + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < NJW; ++j) {
+    const int id = tid + 256 * j, row = id / 12, c = id - row * 12;      // 32 rows x 12 chunks = 384 chunks
+    voW[j] = (id < 384 && row < N) ? (unsigned)row * rowbytesW + c * 16 : 0xf0000000u;
+    loW[j] = id < 384 ? row * PITCH + c * 16 : -1;
+  }
+  u32x4 xa[NJ], xw[NJW];
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], t * 128, 0);
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) xw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[j], t * 192, 0);
+  };
+  const unsigned char* rA = smem6 + (wave * 32 + li) * PITCH + h * 16;
+  const unsigned char* rB = smem6 + OPER + li * PITCH + h * 16;
+  const int nt = K / 32;
+  gload(0);
+  for (int t = 0; t < nt; ++t) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      u32x2 p0, p1, p2;
+      split3x4(xa[j], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(smem6 + lo[j]) = p0;
+      *reinterpret_cast<u32x2*>(smem6 + lo[j] + 64) = p1;
+      *reinterpret_cast<u32x2*>(smem6 + lo[j] + 128) = p2;
+    }
+#pragma unroll
+    for (int j = 0; j < NJW; ++j)
+      if (loW[j] >= 0) *reinterpret_cast<u32x4*>(smem6 + OPER + loW[j]) = xw[j];
+    gload(t + 1 < nt ? t + 1 : 0);       // (past the end: re-read, never used)
+    X6_LDS_BARRIER();
+    bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[ks][p] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + ks * 32);
+        fb[ks][p] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + ks * 32);
+      }
+    X6_LDS_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int sdeg = 2; sdeg >= 0; --sdeg)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int j = sdeg - i;
+          if (j < 0 || j > 2) continue;
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[0][0], 0, 0, 0);
+        }
+  }
+  gemm_epilogue<1, 1>(d.E, acc, M, N, m0, n0, wave, 0, li, h, true);
+}
+
 // 1 if a form-0 descriptor over fp32 tensors could run as precision 3 once both operands are handed
 // over as f2g_split_bf16x3 images
 // extent in elements of what the A operand's rows may touch, or 0 if precision 3 cannot read it
@@ -2818,6 +2899,12 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
     R.step6 = (unsigned)((long long)d.A.step0 * d.A.unit * 4), R.off6 = (unsigned)(-(long long)d.A.pad0 * d.A.unit * 4);
     R.bytes = (unsigned)(x6_a_extent(d.A) * 4);
   }
+  if (N <= 32 && d.B.split == 3 && !d.E.x3_out) {     // thin outputs: 128 x 32 tiles (gemm_x6n_kernel)
+    constexpr size_t smem_n = (128 + 32) * 208;
+    hipLaunchKernelGGL(gemm_x6n_kernel, dim3((M + 127) / 128), dim3(256), smem_n, st, d, M, N, K, R);
+    g_last_path = 4;
+    return f2g_check_launch();
+  }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
   if (d.B.split == 3) hipLaunchKernelGGL(gemm_x6f_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   else hipLaunchKernelGGL(gemm_x6f_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
@@ -2845,7 +2932,7 @@ extern "C" int32_t f2g_gemm_colsum_part_rows(const f2g_gemm_desc* dp) {
   if (!x6_wide(d)) return 0;
   const int M = d.A.rows;
   const int rows128 = 2 * ((M + 127) / 128), rows256 = 4 * ((M + 255) / 256);
-  if (x6f_ok(d)) return rows128;
+  if (x6f_ok(d)) return (d.B.rows <= 32 && d.B.split == 3 && !d.E.x3_out) ? 0 : rows128;   // (gemm_x6n_kernel: generic epilogue)
   if (d.A.split != 3 || d.B.split != 3 || !x6_shape_ok(d)) return 0;
   for (int taps = 5; taps >= 2; taps -= 3)
     if (x6_tap_ok(d, taps) && f2g_x6p_ok(d, taps)) return rows256;

@@ -493,6 +493,8 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
                 (Bm.rows >= X6F_MIN_N and ((A.rows + 127) // 128) * ((Bm.rows + 127) // 128) >= X6F_MIN_TILES)
                 or (A.rows >= X6F_TALL_ROWS and Bm.rows >= 128)):
             in_kernel = True      # (mid-length reductions on well-filled grids: see X6F)
+        if X6F == 2 and X6N and 128 <= A.cols < X6_MIN_K and A.rows >= X6F_TALL_ROWS and Bm.rows == 32:
+            in_kernel = True      # (tall GEMMs with 32 output columns: gemm_x6n_kernel)
         if X6F == 2 and X6_MIN_K <= A.cols < X6_NOPASS_K and A.P0 == 1 and A.P1 == 1 and not _is_const(A._keep[0]):
             in_kernel = True      # (a plain activation matrix has no producer-written image: no image pass)
         if form == 0 and A.split == 0 and Bm.split == 0 and A.rows >= X6_MIN_ROWS \
@@ -774,8 +776,13 @@ X6_WGRAD = opt("x6_wgrad", True)
 X6F = opt("x6f", 2)
 # (round 5: with the wide epilogue -- x6_epilogue.h -- the in-kernel-split kernel also wins on the generator's
 # short reductions: K >= 384, >= 384 columns, >= 180 tiles; same-box step 183.4 -> 178.2 ms, profiles/r05_x6_rules.txt)
-X6F_MIN_K = opt("x6f_min_k", 384)
+# (round 6: from K = 160 -- the second MPD layer, 341376 x 128 x 160, through its "tall GEMM" clause: 62.5 -> 83.5
+# TFLOP/s per launch, same-box step 164.24 -> 163.51 ms over three interleaved pairs)
+X6F_MIN_K = opt("x6f_min_k", 160)
 X6F_MIN_N = opt("x6f_min_n", 384)
+# (round 6) tall GEMMs with 32 output columns -- the data gradients that land on the 32-channel MPD map -- on the
+# 128 x 32 instance of the in-kernel-split kernel (gemm_x6n_kernel) instead of the generic fp32 kernel
+X6N = opt("x6n", True)
 X6F_TALL_ROWS = opt("x6f_tall_rows", 50000)     # (round 5: the G-step halves of the MPD layer-3 data gradients too)
 X6F_MIN_TILES = opt("x6f_min_tiles", 180)
 # long reductions over a PLAIN activation matrix (the generator's K = 2304 GEMMs): below this K the in-kernel
