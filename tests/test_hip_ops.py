@@ -1617,3 +1617,42 @@ def test_batched_rebuild_of_derived_weight_images(ops, monkeypatch):
     ops.transposed(w)                             # the only copy used in this "step"
     ops.bump_weight_epoch([w])
     assert ops.rebuild_derived([w]) == 1
+
+
+@pytest.mark.parametrize("S,Hp,Cout,nt", [(37, 40, 128, 2), (5, 300, 64, 2), (3, 500, 128, 1)])
+def test_fp32_class_gemm_with_32_output_columns(ops, S, Hp, Cout, nt, monkeypatch):
+    """Round 6: gemm_x6n_kernel -- the in-kernel-split fp32-class kernel on 128 x 32 tiles, for the data gradients
+    that land on a 32-channel map (MPD layer 2's stride residues): windowed A operand over a halo map, cached
+    weight image, row-mapped stores (residue interleave) with the leaky-ReLU mask of the layer below and column
+    sums, against float64; ragged row counts."""
+    monkeypatch.setattr(ops, "X6F_TALL_ROWS", 1000)
+    monkeypatch.setattr(ops, "X6_MIN_ROWS", 1)
+    gen = torch.Generator().manual_seed(S + Hp)
+    Lq = Hp - nt + 1                                        # output positions per sequence
+    gmap = torch.randn(S, Hp, Cout, generator=gen)
+    w = torch.randn(32, nt * Cout, generator=gen) * 0.05    # [n][k], k = tap-major, channel-minor
+    cols = torch.stack([gmap[:, i:i + Lq] for i in range(nt)], 2).reshape(S * Lq, nt * Cout)
+    ref = cols.double() @ w.double().t()
+    # row map: output row (s, q) -> row 2 + 3 q of a (S, 3 Lq + 4, 32) map (stride-3 residue 2 with a halo of 2... )
+    Hin = 3 * Lq + 4
+    ymask = torch.randn(S * Hin, 32, generator=gen)
+    out = torch.full((S * Hin, 32), 7.0, device=DEV)
+    cs = torch.zeros(32, device=DEV)
+    wd = torch.nn.Parameter(g(w))
+    was = ops.GEMM_PRECISION
+    try:
+        ops.set_gemm_precision("bf16x6")
+        A = ops.win1d(g(gmap.reshape(S * Hp, Cout)), S, Hp, Cout, Lq, 1, 0, nt)
+        ops.gemm(A, ops.mat(wd), out, rowmap=(Lq, Hin * 32, 3 * 32, 2 * 32), mask=(g(ymask), 0, 0.1), colsum=cs)
+        assert ops.L.lib.f2g_gemm_last_path() == 4, "the 32-column launch did not take the fp32-class kernel"
+    finally:
+        ops.GEMM_PRECISION = was
+    o = out.cpu().reshape(S, Hin, 32)
+    rows = 2 + 3 * torch.arange(Lq)
+    m = ymask.reshape(S, Hin, 32)[:, rows]
+    want = ref.reshape(S, Lq, 32) * torch.where(m > 0, 1.0, 0.1).double()
+    close(o[:, rows].double(), want, rtol=2e-5, name="x6n rowmapped masked output")
+    untouched = torch.ones(Hin, dtype=torch.bool)
+    untouched[rows] = False
+    assert bool((o[:, untouched] == 7.0).all())
+    close(cs.cpu().double(), want.sum((0, 1)), rtol=1e-4, name="x6n column sums")
