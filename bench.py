@@ -321,7 +321,7 @@ def main():
         def family_peak(name):
             if mode == "bf16":
                 return PEAK_BF16_MFMA_TFLOPS
-            if mode == "bf16x6" and (name == "x6" or (name == "direct-conv" and ops.CONV32_X6)):
+            if mode == "bf16x6" and (name in ("x6", "x6-thin") or (name == "direct-conv" and ops.CONV32_X6)):
                 return PEAK_BF16_MFMA_TFLOPS / 6.0
             if mode == "bf16x3":
                 return PEAK_BF16_MFMA_TFLOPS / 3.0
@@ -342,6 +342,7 @@ def main():
                            "lean-streamk": "gemm_lean_kernel (stream-K)",
                            "x6": "gemm_x6p / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
                                  "pieces per operand, six MFMAs per product)",
+                           "x6-thin": "gemm_x6n_kernel (fp32 class on the bf16 pipe, 128 x 32 tiles: <= 32 output columns)",
                            "narrow": "narrow VALU kernels"}.get(dn, dn),
                 # algorithmic FLOPs of the kernel's launches / their summed HIP-event durations
                 "achieved": round(dfl / dsec / 1e12, 2), "peak": round(peak, 1),

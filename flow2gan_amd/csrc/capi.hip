@@ -34,7 +34,7 @@ struct Opt { const char* name; int value; };
 Opt g_opts[F2G_OPT_COUNT] = {
     {"lean", 1}, {"lean_tall", 1}, {"lean_tap", 1}, {"lean_wgrad", 1}, {"x6_tap", 1}, {"x6_wide", 1}, {"x6p", 1},
     {"w6t", 1}, {"deterministic", 0}, {"streamk", 1}, {"conv2ch_v2", 1}, {"conv32_v2", 1}, {"conv32_wgrad_v2", 1},
-    {"mlp_rt", 0}, {"mlp_split", 0}, {"multi_rt384", 4}, {"multi_rt512", 3}};
+    {"mlp_rt", 0}, {"mlp_split", 0}, {"multi_rt384", 4}, {"multi_rt512", 3}, {"streamk_min", 4}};
 std::once_flag g_opts_once;
 
 int opt_index(const char* name, size_t len) {

@@ -29,6 +29,7 @@ enum f2g_opt_id {
   F2G_OPT_MLP_SPLIT,        // fused MLP: parts of the hidden dimension (0 / 1: never split)
   F2G_OPT_MULTI_RT384,      // multi-branch launch: rows / 32 per tile of the 384-channel entries
   F2G_OPT_MULTI_RT512,      // ... of the 512-channel entries
+  F2G_OPT_STREAMK_MIN,      // lean stream-K: fewest K slabs a block takes (prologue / epilogue amortisation)
   F2G_OPT_COUNT
 };
 int f2g_opt(int id);

@@ -2399,7 +2399,8 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
     if (eff > 0.9) return 0;                     // the tile grid already fills its rounds
   }
   long long upb = (total + 511) / 512;
-  if (upb < 8) upb = 8;                          // at least 8 slabs per block (prologue / epilogue)
+  const int min_slabs = f2g_opt(F2G_OPT_STREAMK_MIN);      // (default 4; 8 until round 6: 64-row time-path GEMMs 54 -> 44 us)
+  if (upb < min_slabs) upb = min_slabs;
   return (int)upb;
 }
 
@@ -2407,7 +2408,7 @@ inline int lean_stream_k(int M, int N, int K, bool all_grids) {
 
 // Which kernel family the last f2g_gemm call of this process dispatched to (diagnostics for the
 // benchmark's per-kernel roofline; not thread safe): 0 generic MFMA kernels, 1 lean kernel,
-// 2 lean kernel in stream-K mode, 3 narrow (VALU) kernels.
+// 2 lean kernel in stream-K mode, 3 narrow (VALU) kernels, 4 the precision-3 kernels, 5 their 32-column instance.
 // ---- fp32-class GEMM on the bf16 matrix pipe (precision 3; round 3) -------------------------------
 // Every fp32 operand is split into THREE bf16 pieces x = p0 + p1 + p2 (24 mantissa bits) and a product
 // is the six MFMAs with i + j <= 2 (a0b0, a0b1, a1b0, a0b2, a1b1, a2b0; fp32 accumulation, smallest
@@ -2902,7 +2903,7 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
   if (N <= 32 && d.B.split == 3 && !d.E.x3_out) {     // thin outputs: 128 x 32 tiles (gemm_x6n_kernel)
     constexpr size_t smem_n = (128 + 32) * 208;
     hipLaunchKernelGGL(gemm_x6n_kernel, dim3((M + 127) / 128), dim3(256), smem_n, st, d, M, N, K, R);
-    g_last_path = 4;
+    g_last_path = 5;      // (its own family in the benchmark's tables: a different kernel on 128 x 32 tiles)
     return f2g_check_launch();
   }
   dim3 grid((M + 127) / 128, (N + 127) / 128);

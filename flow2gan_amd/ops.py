@@ -1128,7 +1128,7 @@ class GemmTimer:
         call("f2g_gemm", C.byref(d))
         e.record()
         self.records.append((s, e, flops))
-        self.paths.append(("generic", "lean", "lean-streamk", "narrow", "x6")[L.lib.f2g_gemm_last_path()])
+        self.paths.append(("generic", "lean", "lean-streamk", "narrow", "x6", "x6-thin")[L.lib.f2g_gemm_last_path()])
         if self.paths[-1] == "x6" and form == 0 and d.A.split == 3 and (L.lib.f2g_gemm_x6_ok(C.byref(d)) & 2):
             self.x6_tap = getattr(self, "x6_tap", 0) + 1      # (launches on the tap-walking instance)
         self.shapes.append((form, mm, nn, kk))

@@ -42,7 +42,7 @@ const char* f2g_last_error(void);
  * F2G_OPTS="name=value,..." and F2G_DETERMINISTIC from the environment -- and changed afterwards only through
  * this setter; nothing reads the environment on a launch path.  Names: lean, lean_tall, lean_tap, lean_wgrad,
  * x6_tap, x6_wide, x6p, w6t, deterministic, streamk, conv2ch_v2, conv32_v2, conv32_wgrad_v2, mlp_rt, mlp_split,
- * multi_rt384, multi_rt512 (meanings: csrc/common.h).  Unknown name: F2G_EINVAL.  Not thread safe against
+ * multi_rt384, multi_rt512, streamk_min (meanings: csrc/common.h).  Unknown name: F2G_EINVAL.  Not thread safe against
  * concurrent launches. */
 int f2g_set_option(const char* name, int32_t value);
 int f2g_get_option(const char* name, int32_t* value);
@@ -221,7 +221,7 @@ int32_t f2g_gemm_colsum_part_rows(const f2g_gemm_desc* d);
 
 /* Kernel family the last f2g_gemm call dispatched to (benchmark diagnostics, not thread safe):
  * 0 generic MFMA kernels, 1 lean kernel, 2 lean kernel in stream-K mode, 3 narrow VALU kernels,
- * 4 the precision-3 kernels. */
+ * 4 the precision-3 kernels, 5 the precision-3 kernel for <= 32 output columns (gemm_x6n_kernel). */
 int f2g_gemm_last_path(void);
 
 /* ------------------------------------------------------------------------------------------

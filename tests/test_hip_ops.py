@@ -1644,7 +1644,7 @@ def test_fp32_class_gemm_with_32_output_columns(ops, S, Hp, Cout, nt, monkeypatc
         ops.set_gemm_precision("bf16x6")
         A = ops.win1d(g(gmap.reshape(S * Hp, Cout)), S, Hp, Cout, Lq, 1, 0, nt)
         ops.gemm(A, ops.mat(wd), out, rowmap=(Lq, Hin * 32, 3 * 32, 2 * 32), mask=(g(ymask), 0, 0.1), colsum=cs)
-        assert ops.L.lib.f2g_gemm_last_path() == 4, "the 32-column launch did not take the fp32-class kernel"
+        assert ops.L.lib.f2g_gemm_last_path() == 5, "the 32-column launch did not take gemm_x6n_kernel"
     finally:
         ops.GEMM_PRECISION = was
     o = out.cpu().reshape(S, Hin, 32)

@@ -450,7 +450,7 @@ def test_library_options_and_python_tunables(monkeypatch):
     from flow2gan_amd import _lib, _opts
     names = ("lean", "lean_tall", "lean_tap", "lean_wgrad", "x6_tap", "x6_wide", "x6p", "w6t", "deterministic",
              "streamk", "conv2ch_v2", "conv32_v2", "conv32_wgrad_v2", "mlp_rt", "mlp_split", "multi_rt384",
-             "multi_rt512")
+             "multi_rt512", "streamk_min")
     for n in names:
         v = _lib.get_option(n)
         assert _lib.set_option(n, v + 5) == v and _lib.get_option(n) == v + 5
