@@ -1232,6 +1232,10 @@ def test_gemm_fp32_class_on_the_bf16_pipe(ops, M, N, K, kernel, monkeypatch):
     ad, wd = g(a), torch.nn.Parameter(g(w))
     # gemm_x6_kernel over f2g_split_bf16x3 images / gemm_x6f_kernel over the fp32 operands themselves
     monkeypatch.setattr(ops, "X6F", 0 if kernel == "images" else 1)
+    # (recorded by monkeypatch BEFORE the direct assignments below: its teardown restores what it saw first, and
+    # used to leave X6_MIN_K = 32 behind for the rest of the module)
+    monkeypatch.setattr(ops, "X6_MIN_K", ops.X6_MIN_K)
+    monkeypatch.setattr(ops, "X6F_MIN_K", ops.X6F_MIN_K)
     was = ops.GEMM_PRECISION, ops.X6_MIN_K, ops.X6_MIN_ROWS
     try:
         ops.set_gemm_precision("bf16x6")

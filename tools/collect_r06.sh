@@ -9,6 +9,19 @@ rm -rf $O; mkdir -p $O
 cd $R
 python tools/hbm_kernel_bench.py $O/hbm_class_isolated.json > $O/hbm_kernels.txt 2>/dev/null
 cp $O/hbm_class_isolated.json profiles/hbm_class_isolated.json      # (so that the default line below carries it)
+# HBM traffic of the dominant kernel families (PMC passes) FIRST: the default line below reports it as
+# roofline.traffic only when profiles/ holds a json of THIS library version
+cd /tmp && export TMPDIR=/tmp
+B1="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode"
+for set in FETCH_SIZE WRITE_SIZE; do
+  F2G_STREAMS=0 timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcb_x6_$set -o p -- $B1 > /dev/null 2>&1
+  F2G_STREAMS=0 timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcb_$set -o p -- $B1 --gemm fp32 > /dev/null 2>&1
+done
+for d in pmcb_FETCH_SIZE pmcb_WRITE_SIZE pmcb_x6_FETCH_SIZE pmcb_x6_WRITE_SIZE; do find $O/$d -type f ! -name "p_counter_collection.csv" -delete; done
+cd $R
+G=gpurun_out/r06 MODE=bf16x6 python3 tools/pmc_traffic_json.py $O/pmc_x6_traffic.json
+G=gpurun_out/r06 MODE=fp32 python3 tools/pmc_traffic_json.py $O/pmc_gemm_traffic.json
+cp $O/pmc_x6_traffic.json profiles/r06_pmc_x6_traffic.json; cp $O/pmc_gemm_traffic.json profiles/r06_pmc_gemm_traffic.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 F2G_GEMM_REPORT=90 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode 2> $O/shapes_x6.txt > /dev/null
 F2G_GEMM_REPORT=90 python bench.py --gemm fp32 --steps 3 --warmup 2 --no-cpu-baseline --no-fast-mode 2> $O/shapes_fp32.txt > /dev/null
@@ -32,15 +45,6 @@ F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_se
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lanes -o p -- $B > /dev/null 2>&1
 F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fp32 -o p -- $B --gemm fp32 > /dev/null 2>&1
 for d in prof_serial prof_lanes prof_fp32; do find $O/$d -type f ! -name "p_kernel_stats.csv" -delete; done
-B1="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-fast-mode"
-for set in FETCH_SIZE WRITE_SIZE; do
-  F2G_STREAMS=0 timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcb_x6_$set -o p -- $B1 > /dev/null 2>&1
-  F2G_STREAMS=0 timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmcb_$set -o p -- $B1 --gemm fp32 > /dev/null 2>&1
-done
-for d in pmcb_FETCH_SIZE pmcb_WRITE_SIZE pmcb_x6_FETCH_SIZE pmcb_x6_WRITE_SIZE; do find $O/$d -type f ! -name "p_counter_collection.csv" -delete; done
-cd $R
-G=gpurun_out/r06 MODE=bf16x6 python3 tools/pmc_traffic_json.py $O/pmc_x6_traffic.json
-G=gpurun_out/r06 MODE=fp32 python3 tools/pmc_traffic_json.py $O/pmc_gemm_traffic.json
 bash tools/pmc_busy.sh r06_x6 > /dev/null 2>&1; cp gpurun_out/pmc_busy_r06_x6.txt $O/pmc_busy_x6.txt
 bash tools/pmc_busy.sh r06_fp32 --gemm fp32 > /dev/null 2>&1; cp gpurun_out/pmc_busy_r06_fp32.txt $O/pmc_busy_fp32.txt
 tail -1 $O/bench_default.json | cut -c1-200
