@@ -2793,7 +2793,57 @@ __global__ __launch_bounds__(256, 2) void gemm_x6n_kernel(const f2g_gemm_desc d,
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[0][0], 0, 0, 0);
         }
   }
-  gemm_epilogue<1, 1>(d.E, acc, M, N, m0, n0, wave, 0, li, h, true);
+  // Epilogue.  The row map of a stride residue costs the generic epilogue one 64-bit division per ELEMENT (16 per
+  // lane and tile, ~35 VALU instructions each beside 96 MFMAs); here the 128 output-row offsets of the tile are
+  // computed once, one division per ROW, into the (now free) operand buffer, and the elements look them up.
+  const f2g_epilogue& E = d.E;
+  if (E.aux || E.res || E.prelu_slope || E.atomic || E.accumulate || E.scale != 0.f) {
+    gemm_epilogue<1, 1>(E, acc, M, N, m0, n0, wave, 0, li, h, true);
+    return;
+  }
+  __syncthreads();                                   // every wave is through its last fragment reads
+  long long* rowoff = reinterpret_cast<long long*>(smem6);
+  if (tid < 128) {
+    const int row = m0 + tid;
+    long long off = -1;
+    if (row < M) {
+      if (E.P0o > 0) {
+        const int sq = row / E.P0o;
+        off = (long long)sq * E.seq_stride_o + (long long)(row - sq * E.P0o) * E.row_stride_o + E.off_o;
+      } else {
+        off = (long long)row * E.ldc;
+      }
+    }
+    rowoff[tid] = off;
+  }
+  __syncthreads();
+  const int col = li;
+  if (col >= N) return;
+  const float bias = E.bias ? E.bias[col] : 0.f;
+  const float fmw = E.fm_ref ? E.fm_w * (E.fm_wdev ? E.fm_wdev[0] : 1.f) : 0.f;
+  float cs = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const long long ro = rowoff[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+    if (ro < 0) continue;
+    const long long off = ro + col;
+    float v = acc[0][0][e] + bias;
+    if (E.lrelu_slope != 0.f) v = v > 0.f ? v : E.lrelu_slope * v;
+    if (E.mask_src) {   // leaky-ReLU backward of the layer below (+ feature-matching term)
+      const float y = E.mask_src[off];
+      if (E.fm_ref) {
+        const float dl = y - E.fm_ref[off];
+        v += fmw * (dl > 0.f ? 1.f : (dl < 0.f ? -1.f : 0.f));
+      }
+      v *= y > 0.f ? 1.f : E.mask_slope;
+    }
+    cs += v;
+    E.C[off] = v;
+  }
+  if (E.colsum) {
+    cs += __shfl_xor(cs, 32);
+    if (h == 0) atomicAdd(E.colsum + col, cs);
+  }
 }
 
 // 1 if a form-0 descriptor over fp32 tensors could run as precision 3 once both operands are handed
