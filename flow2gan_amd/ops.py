@@ -209,24 +209,28 @@ class WeightBatch:
         self.ranges = {}       # start -> (end, level)
         self.rstarts = []      # ... of read ranges (write-after-read ordering when memory is reused)
         self.rranges = {}
+        self.longest = 0       # bytes of the longest recorded range
 
-    @staticmethod
-    def _level_over(starts, ranges, lo, hi):
+    def _level_over(self, starts, ranges, lo, hi):
+        """Highest level among the recorded ranges that overlap [lo, hi), -1 if none.  Ranges are looked up by
+        start address; the scan to the left stops as soon as a start lies further below `lo` than the longest
+        range recorded so far (a few steps: the operations' buffers are separate allocations)."""
         import bisect
         lvl = -1
         i = bisect.bisect_left(starts, hi)
         while i > 0:
             i -= 1
             st = starts[i]
+            if lo - st >= self.longest:
+                break
             end, l = ranges[st]
             if end > lo:
                 lvl = max(lvl, l)
-            elif lo - st > (1 << 31):      # (no range is longer than 2 GB: nothing further left can reach lo)
-                break
         return lvl
 
     def add(self, kind, out_ptr, out_bytes, rd_ptr, rd_bytes, n, s, items, tensors, in_ptr=None, reads_out=False):
         import bisect
+        self.longest = max(self.longest, out_bytes, rd_bytes or 0)
         lvl = self._level_over(self.starts, self.ranges, out_ptr, out_ptr + out_bytes)           # write after write
         lvl = max(lvl, self._level_over(self.rstarts, self.rranges, out_ptr, out_ptr + out_bytes))   # ... after read
         if rd_ptr is not None:
@@ -267,7 +271,7 @@ class WeightBatch:
             call("f2g_multi", C.byref(d))
             launches += 1
         self.keep = []
-        self.starts, self.ranges, self.rstarts, self.rranges = [], {}, [], {}
+        self.starts, self.ranges, self.rstarts, self.rranges, self.longest = [], {}, [], {}, 0
         return launches
 
 
