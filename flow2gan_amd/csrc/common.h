@@ -65,6 +65,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Three bf16 pieces of TWO floats, round to nearest even at every step (as f2g_split_bf16x3): x = p0 + p1 + p2 to
+// ~2^-25 relative.  On pairs one v_cvt_pk_bf16_f32 yields the packed piece (low half = x0), two bit operations
+// widen it again and one v_pk_add_f32 takes the remainder: 9 VALU instructions per pair (the element-wise
+// formulation the in-kernel splits used until round 6 compiled to 14.5).
+typedef float f2g_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 f2g_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void f2g_split3_pair(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const f2g_f32x2 x = {x0, x1};
+  p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f2g_bf16x2));
+  const f2g_f32x2 r1 = x - f2g_f32x2{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, f2g_bf16x2));
+  const f2g_f32x2 r2 = r1 - f2g_f32x2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, f2g_bf16x2));
+}
+
 // n / d for 0 <= n < 2^31 with a per-kernel magic number (gfx950 has no integer divide: the
 // compiler's expansion costs ~35 VALU instructions, and the windowed loaders divide once per
 // K slab / per chunk): magic = ceil(2^32 / d) over-estimates the quotient by at most one.

@@ -33,23 +33,14 @@ constexpr int WCH = C * 12;        // 16-byte chunks of one weight tile in the i
 
 __device__ __attribute__((aligned(16))) float c6_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
-// three bf16 pieces of four floats (round to nearest even at every step, as f2g_split_bf16x3)
+// three bf16 pieces of four floats (common.h: f2g_split3_pair, round to nearest even at every step)
 __device__ __forceinline__ void split3(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  unsigned short q[3][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 a = (__bf16)x[e];
-    const float r1 = x[e] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const __bf16 c = (__bf16)(r1 - (float)b);
-    q[0][e] = __builtin_bit_cast(unsigned short, a);
-    q[1][e] = __builtin_bit_cast(unsigned short, b);
-    q[2][e] = __builtin_bit_cast(unsigned short, c);
-  }
-  p0 = u32x2{q[0][0] | ((unsigned)q[0][1] << 16), q[0][2] | ((unsigned)q[0][3] << 16)};
-  p1 = u32x2{q[1][0] | ((unsigned)q[1][1] << 16), q[1][2] | ((unsigned)q[1][3] << 16)};
-  p2 = u32x2{q[2][0] | ((unsigned)q[2][1] << 16), q[2][2] | ((unsigned)q[2][3] << 16)};
+  unsigned a0, a1, a2, b0, b1, b2;
+  f2g_split3_pair(v.x, v.y, a0, a1, a2);
+  f2g_split3_pair(v.z, v.w, b0, b1, b2);
+  p0 = u32x2{a0, b0};
+  p1 = u32x2{a1, b1};
+  p2 = u32x2{a2, b2};
 }
 
 __device__ __forceinline__ void store_px3(unsigned char* p, const f32x4 v) {   // p = piece 0 of the chunk

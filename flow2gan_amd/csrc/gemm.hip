@@ -1944,6 +1944,33 @@ void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
 #else
 #define X6LAB_EPI
 #endif
+// bits 8 ... 64 (gemm_x6f_kernel, gemm_leanw6_kernel): 8 = only the first slab is loaded from memory, 16 = no split
+// arithmetic (the pieces are raw bit fields), 32 = 4 of the 48 MFMAs of a slab, 64 = fragments read once
+#define X6LAB_KEEP(v) asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
+// bit 512: gemm_x6f_kernel stages without LDS stores.
+// bit 256: gemm_x6f_kernel times the three intervals of its slab loop with s_memtime (wave 0 of every block; the
+// stamps' results are collected by the loop's own lgkmcnt(0) waits, nothing is added to the critical path) and
+// adds them to g_x6prof: [0] MFMA chain with the staging between, [1] wait for the block at the "stores visible"
+// barrier, [2] fragment reads + "fragments read" barrier, [3] iterations, [4] kernel entry -> first chain (prologue),
+// [5] the last slab's chain (12 x 4 MFMAs issued), [6] epilogue, [7] blocks; f2g_lab_x6prof reads and clears them
+#if F2G_X6LAB & 256
+__device__ unsigned long long g_x6prof[8];
+extern "C" int f2g_lab_x6prof(unsigned long long* out8) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x6prof), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_x6prof), z, sizeof(z)) != hipSuccess;
+}
+#define X6PROF_STAMP(t) asm volatile("s_memtime %0" : "=s"(t) : : "memory")
+#define X6PROF_ACC(sum, t1, t0)                                                                              \
+  {                                                                                                          \
+    unsigned dt_;                                                                                            \
+    asm volatile("s_sub_u32 %0, %1, %2" : "=s"(dt_) : "s"((unsigned)(t1)), "s"((unsigned)(t0)) : "memory"); \
+    sum += dt_;                                                                                              \
+  }
+#else
+#define X6PROF_STAMP(t)
+#define X6PROF_ACC(sum, t1, t0)
+#endif
 #if F2G_X6LAB & 2
 #define X6LAB_X3 acc[0][0][1] == 1.2345e30f &&
 #else
@@ -1957,24 +1984,20 @@ void gemm_leanw3_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
 #else
 #define X6_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+// three bf16 pieces of four floats (common.h: f2g_split3_pair -- 18 VALU instructions per chunk)
 __device__ __forceinline__ void split3x4(const u32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
+#if F2G_X6LAB & 16
+  p0 = u32x2{v.x, v.y}; p1 = u32x2{v.z, v.w}; p2 = u32x2{v.x, v.w};
+  return;
+#endif
   // (by value first: __builtin_bit_cast applied to a vector-element expression reads element 0)
   const unsigned u0 = v.x, u1 = v.y, u2 = v.z, u3 = v.w;
-  const float x[4] = {__uint_as_float(u0), __uint_as_float(u1), __uint_as_float(u2), __uint_as_float(u3)};
-  unsigned short q[3][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 a = (__bf16)x[e];
-    const float r1 = x[e] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const __bf16 c = (__bf16)(r1 - (float)b);
-    q[0][e] = __builtin_bit_cast(unsigned short, a);
-    q[1][e] = __builtin_bit_cast(unsigned short, b);
-    q[2][e] = __builtin_bit_cast(unsigned short, c);
-  }
-  p0 = u32x2{q[0][0] | ((unsigned)q[0][1] << 16), q[0][2] | ((unsigned)q[0][3] << 16)};
-  p1 = u32x2{q[1][0] | ((unsigned)q[1][1] << 16), q[1][2] | ((unsigned)q[1][3] << 16)};
-  p2 = u32x2{q[2][0] | ((unsigned)q[2][1] << 16), q[2][2] | ((unsigned)q[2][3] << 16)};
+  unsigned a0, a1, a2, b0, b1, b2;
+  f2g_split3_pair(__uint_as_float(u0), __uint_as_float(u1), a0, a1, a2);
+  f2g_split3_pair(__uint_as_float(u2), __uint_as_float(u3), b0, b1, b2);
+  p0 = u32x2{a0, b0};
+  p1 = u32x2{a1, b1};
+  p2 = u32x2{a2, b2};
 }
 
 template <bool BWIN>
@@ -2007,6 +2030,7 @@ void gemm_leanw6_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
   }
   const int stepA = (int)(BK * d.A.seq_stride * 4), stepB = (int)(BK * d.B.seq_stride * 4);
   const unsigned mgP0 = BWIN ? magic_of(d.B.P0) : 0u;
+  const int p0one = BWIN && d.B.P0 == 1 ? -1 : 0;
   const int colB = (n0 + 4 * c) * 4;
   int wofs[4];
 #pragma unroll
@@ -2030,47 +2054,45 @@ void gemm_leanw6_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  int ka = (int)((long long)kbeg * d.A.seq_stride * 4), kb = (int)((long long)kbeg * d.B.seq_stride * 4);
-  const int ka0 = ka, kb0 = kb;
-  int srow = kbeg;   // first row of the slab being loaded (window operands)
+  const int ka0 = (int)((long long)kbeg * d.A.seq_stride * 4), kb0 = (int)((long long)kbeg * d.B.seq_stride * 4);
   u32x4 xa[4], xb[4];
-  auto gload = [&](bool valid) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // rows past K pair with nothing: zeros (the resource ends at K rows for A; B is tested)
-      const int r = (valid ? srow : kbeg) + rid + 8 * q;
-      xa[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, r < K ? offA[q] : 0x80000000u, valid ? ka : ka0, 0);
-      if constexpr (BWIN) {
-        const int sq = fast_div(r, d.B.P0, mgP0), pp = r - sq * d.B.P0;
-        const long long off = ((long long)sq * d.B.seq_stride + (long long)(pp * d.B.step0 - d.B.pad0) * d.B.unit) * 4 + colB;
-        const unsigned vo = (r < K && off >= 0 && off < b_bytes) ? (unsigned)off : 0x80000000u;
-        xb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, vo, 0, 0);
-      } else {
-        xb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, r < K ? offB[q] : 0x80000000u, valid ? kb : kb0, 0);
-      }
+  // chunk q (rows rid + 8 q) of slab s of this block's K range; s >= nt: the first slab again (never used)
+  auto gload1 = [&](int q, int s) {
+    const bool valid = s < nt;
+    const int s_ = valid ? s : 0;
+    // rows past K pair with nothing: zeros (the resource ends at K rows for A; B is tested)
+    const int r = kbeg + s_ * BK + rid + 8 * q;
+    // (an offset with bit 31 set lies behind every resource: the load returns zeros.  Written as arithmetic: as a
+    // select the compiler turned it into two loads under complementary exec masks -- a branch inside the chain)
+    const unsigned past = (unsigned)(r >= K) << 31;
+    xa[q] = __builtin_amdgcn_raw_buffer_load_b128(ra, offA[q] | past, ka0 + s_ * stepA, 0);
+    if constexpr (BWIN) {
+      // (fast_div without its d == 1 branch: control flow would cut the MFMA chain's scheduling region)
+      int sq = (int)__umulhi((unsigned)r, mgP0);
+      sq -= (sq * d.B.P0 > r) ? 1 : 0;
+      sq += (r - sq) & p0one;
+      const int pp = r - sq * d.B.P0;
+      const long long off = ((long long)sq * d.B.seq_stride + (long long)(pp * d.B.step0 - d.B.pad0) * d.B.unit) * 4 + colB;
+      const unsigned vo = (unsigned)off | ((unsigned)!(r < K && off >= 0 && off < b_bytes) << 31);
+      xb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, vo, 0, 0);
+    } else {
+      xb[q] = __builtin_amdgcn_raw_buffer_load_b128(rb, offB[q] | past, kb0 + s_ * stepB, 0);
     }
   };
-  for (int t = 0; t < nt; ++t) {
-    if (t == 0) gload(true);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      u32x2 p0, p1, p2;
-      unsigned char* pa = sm + wofs[q];
-      split3x4(xa[q], p0, p1, p2);
-      *reinterpret_cast<u32x2*>(pa) = p0;
-      *reinterpret_cast<u32x2*>(pa + PL) = p1;
-      *reinterpret_cast<u32x2*>(pa + 2 * PL) = p2;
-      split3x4(xb[q], p0, p1, p2);
-      *reinterpret_cast<u32x2*>(pa + 3 * PL) = p0;
-      *reinterpret_cast<u32x2*>(pa + 4 * PL) = p1;
-      *reinterpret_cast<u32x2*>(pa + 5 * PL) = p2;
-    }
-    ka += stepA;
-    kb += stepB;
-    srow += BK;
-    gload(t + 1 < nt);           // (past the end: the first slab again, never used)
-    X6_LDS_BARRIER();
-    bf16x8 fa[2][3][2], fb[2][3][2];
+  auto stage = [&](int q) {      // split chunk q of both operands into the K-major planes
+    u32x2 p0, p1, p2;
+    unsigned char* pa = sm + wofs[q];
+    split3x4(xa[q], p0, p1, p2);
+    *reinterpret_cast<u32x2*>(pa) = p0;
+    *reinterpret_cast<u32x2*>(pa + PL) = p1;
+    *reinterpret_cast<u32x2*>(pa + 2 * PL) = p2;
+    split3x4(xb[q], p0, p1, p2);
+    *reinterpret_cast<u32x2*>(pa + 3 * PL) = p0;
+    *reinterpret_cast<u32x2*>(pa + 4 * PL) = p1;
+    *reinterpret_cast<u32x2*>(pa + 5 * PL) = p2;
+  };
+  bf16x8 fa[2][3][2], fb[2][3][2];
+  auto frags = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -2080,22 +2102,57 @@ void gemm_leanw6_kernel(const f2g_gemm_desc d, int M, int N, int K, int kchunk) 
           fa[ks][pc][tt] = tr_frag(sm + ks * 16 * 256 + pc * PL + rofA[tt]);
           fb[ks][pc][tt] = tr_frag(sm + ks * 16 * 256 + (3 + pc) * PL + rofB[tt]);
         }
+  };
+  // the 48 MFMAs of a slab as 12 groups of four (one product term of one k step), smallest terms first
+  auto mf4 = [&](int g) {
+    const int ks = g / 6, r = g % 6;
+    const int i = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : r == 3 ? 0 : r == 4 ? 1 : 0;
+    const int j = r < 3 ? 2 - i : r < 5 ? 1 - i : 0;
+    if ((F2G_X6LAB & 32) && g != 0) return;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+  };
+  // Schedule (round 6; gemm_x6f_kernel has the measurements): the single operand buffer is dead once every wave
+  // holds its fragments, so slab t + 1 is split and stored BETWEEN the MFMAs of slab t, in the same wave's
+  // instruction stream -- one chunk of either operand per quarter of the chain, its registers requested again for
+  // slab t + 2 at once --, and only barrier, fragment reads, barrier stand between two MFMA chains.
+#pragma unroll
+  for (int q = 0; q < 4; ++q) gload1(q, 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) stage(q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) gload1(q, 1);
+  X6_LDS_BARRIER();
+  frags();
+  X6_LDS_BARRIER();
+  for (int t = 0; t + 1 < nt; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mf4(3 * q);
+      stage(q);
+      mf4(3 * q + 1);
+      gload1(q, t + 2);
+      mf4(3 * q + 2);
+#if !(F2G_X6LAB & 128)
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, BWIN ? 5 : 4, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
     X6_LDS_BARRIER();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int sdeg = 2; sdeg >= 0; --sdeg)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int j = sdeg - i;
-          if (j < 0 || j > 2) continue;
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
-        }
+    frags();
+    X6_LDS_BARRIER();
   }
+#pragma unroll
+  for (int g = 0; g < 12; ++g) mf4(g);
   gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, blockIdx.z == 0);
 }
 
@@ -2602,6 +2659,10 @@ template <bool WIMG>
 __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d, int M, int N, int K,
                                                           const x6_rows R, const int wide) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+#if F2G_X6LAB & 256
+  unsigned long long pe0, pe1, pe2, pe3;
+  X6PROF_STAMP(pe0);
+#endif
   // WIMG (round 5): the WEIGHT operand is its cached f2g_split_bf16x3 image (192 bytes per row and slab, stored
   // to LDS as it comes) -- every one of the M / 128 row tiles used to split the same weight slab again; only
   // the activation rows (read once per column tile) are still split here
@@ -2655,31 +2716,42 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
   const unsigned char* rA = smem6 + (wm * 64 + li) * PITCH + h * 16;
   const unsigned char* rB = smem6 + OPER + (wn * 64 + li) * PITCH + h * 16;
   const int nt = K / 32;
-  gload(0);
-  for (int t = 0; t < nt; ++t) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+  bf16x8 fa[2][3][2], fb[2][3][2];
+  // Schedule (round 6).  The slab loop used to be phases -- split + store, barrier, fragments, barrier, 48 MFMAs --
+  // and relied on the CU's other block to fill the matrix pipe meanwhile; measured, the phases simply ADD
+  // (lab builds, tools/micro/x6lab_run.sh: without the split -32 us, without 44 of the 48 MFMAs -71 us of a 143 us
+  // launch), and tools/micro/mfma_valu_overlap.hip shows why: VALU work of ANOTHER wave hides only partly behind a
+  // wave's MFMAs, VALU work of the SAME wave's stream, issued between its MFMAs, hides completely.  The operand
+  // buffer is dead once every wave holds its fragments, so the staging of slab t + 1 -- the split of the
+  // activation chunks, the LDS stores of both operands, the requests for slab t + 2 -- now sits between the MFMAs
+  // of slab t, one chunk per quarter of the chain, and only the fragment reads stand between two MFMA chains.
+  auto stage_a = [&](int j) {
+    u32x2 p0, p1, p2;
+    split3x4(xa[j], p0, p1, p2);
+#if F2G_X6LAB & 512      // (lab: the split without its LDS stores)
+    asm volatile("" : : "v"(p0.x), "v"(p0.y), "v"(p1.x), "v"(p1.y), "v"(p2.x), "v"(p2.y));
+    return;
+#endif
+    *reinterpret_cast<u32x2*>(smem6 + lo[j]) = p0;
+    *reinterpret_cast<u32x2*>(smem6 + lo[j] + 64) = p1;
+    *reinterpret_cast<u32x2*>(smem6 + lo[j] + 128) = p2;
+  };
+  auto stage_w = [&](int j) {
+#if F2G_X6LAB & 512
+    asm volatile("" : : "v"(xw[j].x), "v"(xw[j].y), "v"(xw[j].z), "v"(xw[j].w));
+    return;
+#endif
+    if (WIMG) {
+      *reinterpret_cast<u32x4*>(smem6 + OPER + loW[j]) = xw[j];
+    } else {
       u32x2 p0, p1, p2;
-      split3x4(xa[j], p0, p1, p2);
-      *reinterpret_cast<u32x2*>(smem6 + lo[j]) = p0;
-      *reinterpret_cast<u32x2*>(smem6 + lo[j] + 64) = p1;
-      *reinterpret_cast<u32x2*>(smem6 + lo[j] + 128) = p2;
+      split3x4(xw[j], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j]) = p0;
+      *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j] + 64) = p1;
+      *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j] + 128) = p2;
     }
-#pragma unroll
-    for (int j = 0; j < NJW; ++j) {
-      if (WIMG) {
-        *reinterpret_cast<u32x4*>(smem6 + OPER + loW[j]) = xw[j];
-      } else {
-        u32x2 p0, p1, p2;
-        split3x4(xw[j], p0, p1, p2);
-        *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j]) = p0;
-        *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j] + 64) = p1;
-        *reinterpret_cast<u32x2*>(smem6 + OPER + loW[j] + 128) = p2;
-      }
-    }
-    gload(t + 1 < nt ? t + 1 : 0);       // (past the end: re-read, never used)
-    X6_LDS_BARRIER();
-    bf16x8 fa[2][3][2], fb[2][3][2];
+  };
+  auto frags = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -2689,30 +2761,257 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
           fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + i * 32 * PITCH + ks * 32);
           fb[ks][p][i] = *reinterpret_cast<const bf16x8*>(rB + p * 64 + i * 32 * PITCH + ks * 32);
         }
-    X6_LDS_BARRIER();
+  };
+  // the 48 MFMAs of a slab as 12 groups of four (one product term of one k step), smallest terms first
+  auto mf4 = [&](int g) {
+    const int ks = g / 6, r = g % 6;
+    const int i = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : r == 3 ? 0 : r == 4 ? 1 : 0;
+    const int j = r < 3 ? 2 - i : r < 5 ? 1 - i : 0;
+    if ((F2G_X6LAB & 32) && g != 0) return;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int sdeg = 2; sdeg >= 0; --sdeg)
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+  };
+  gload(0);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int j = sdeg - i;
-          if (j < 0 || j > 2) continue;
+  for (int j = 0; j < NJ; ++j) stage_a(j);
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+  for (int j = 0; j < NJW; ++j) stage_w(j);
+  gload(nt > 1 ? 1 : 0);
+  X6_LDS_BARRIER();
+  frags();
+  X6_LDS_BARRIER();
+#if F2G_X6LAB & 256
+  unsigned long long pt0, pt1, pt2;
+  unsigned long long ps0 = 0, ps1 = 0, ps2 = 0;
+  X6PROF_STAMP(pt0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pt2 = pt0;
+  pe1 = pt0;
+#endif
+  for (int t = 0; t + 1 < nt; ++t) {
+    const int t2 = t + 2 < nt ? t + 2 : 0;       // (past the end: re-read, never used)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      // quarter q: MFMA groups 3 q ... 3 q + 2 with the staging of activation chunk q (and its share of the
+      // weight chunks) between them; the chunk's registers are requested again for slab t + 2 right away
+      mf4(3 * q);
+      if (WIMG) {
+        if (q < 3) {
+          stage_w(2 * q);
+          stage_w(2 * q + 1);
+          xw[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[2 * q], t2 * 192, 0);
+          xw[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[2 * q + 1], t2 * 192, 0);
         }
+      } else {
+        stage_w(q);
+        xw[q] = __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[q], t2 * 128, 0);
+      }
+      mf4(3 * q + 1);
+      stage_a(q);
+      xa[q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[q], t2 * 128, 0);
+      mf4(3 * q + 2);
+#if !(F2G_X6LAB & 128)
+      // one MFMA, then its share of the quarter's VALU work; the LDS stores and the requests close the quarter
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, WIMG ? 3 : 5, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    X6PROF_STAMP(pt1);
+    X6_LDS_BARRIER();
+    X6PROF_ACC(ps0, pt1, pt0);
+    X6PROF_ACC(ps2, pt0, pt2);      // (the previous iteration's fragment interval)
+    X6PROF_STAMP(pt2);
+    frags();
+    X6_LDS_BARRIER();
+    X6PROF_ACC(ps1, pt2, pt1);
+    X6PROF_STAMP(pt0);
   }
+#if F2G_X6LAB & 256
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  X6PROF_ACC(ps2, pt0, pt2);
+  if (tid == 0 && nt > 1) {
+    atomicAdd(&g_x6prof[0], ps0);
+    atomicAdd(&g_x6prof[1], ps1);
+    atomicAdd(&g_x6prof[2], ps2);
+    atomicAdd(&g_x6prof[3], (unsigned long long)(nt - 1));
+  }
+#endif
+  X6PROF_STAMP(pe2);
+#pragma unroll
+  for (int g = 0; g < 12; ++g) mf4(g);
+  X6PROF_STAMP(pe3);
   if (wide) {
     // (every fragment read of the main loop lies before its last barrier: a wave that is through its MFMAs
     // may overlay the operand buffers with its private patch)
     X6LAB_EPI x6e::wide_epilogue(d.E, acc, M, N, m0 + wm * 64, n0 + wn * 64, lane, smem6 + wave * x6e::ESZ);
+#if F2G_X6LAB & 256
+    unsigned long long pe4;
+    X6PROF_STAMP(pe4);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      atomicAdd(&g_x6prof[4], pe1 - pe0);
+      atomicAdd(&g_x6prof[5], pe3 - pe2);
+      atomicAdd(&g_x6prof[6], pe4 - pe3);
+      atomicAdd(&g_x6prof[7], 1ull);
+    }
+#endif
     return;
   }
   X6LAB_EPI gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
   if (X6LAB_X3 d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
+}
+
+// gemm_x6f_kernel<true> with the WEIGHT fragments straight from memory (round 6).  Measured on the kernel above
+// (tools/micro/x6prof.py: s_memtime stamps inside the slab loop): with the staging between the MFMAs a chain of 48
+// MFMAs (1536 clocks) takes 2420 clocks alone on its CU, 1800 without the LDS stores -- a store moves its address
+// and data registers to the LDS at 2 clocks per source dword (MI355X_MICROARCH.md, LDS), ~600 clocks per slab
+// and block, and the wave's MFMAs wait behind it.  Half of those stores put the weight image into LDS only to read
+// it back in MFMA fragment order.  Here the cached weight image is FRAGMENT-MAJOR (B.split = 4: [N / 32][K / 32]
+// [piece][k step][lane][16 bytes] -- a permutation of the f2g_split_bf16x3 image, flow2gan_amd/ops.py), so a
+// wave's B fragment is one coalesced 1 KB load into the registers the MFMAs read: no LDS store, no LDS read, no
+// staging registers for the weights; the two k-step halves of the fragment set are requested again for slab
+// t + 1 as soon as the MFMAs of slab t have consumed them.  LDS carries the activation tile only (half the
+// stores, half the fragment reads of gemm_x6f_kernel).
+__global__ __launch_bounds__(256, 2) void gemm_x6g_kernel(const f2g_gemm_desc d, int M, int N, int K,
+                                                          const x6_rows R, const int wide) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+  constexpr int PITCH = 208, NJ = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, h = lane >> 5;
+  int m0, n0;
+  tile_of_block(128, 128, m0, n0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int nt = K / 32;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)d.A.base, 0, R.bytes, 0x00020000);
+  // (the image ends with the last whole 32-row group: groups of a ragged last tile read zeros)
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)d.B.base, 0, (unsigned)((long long)N * K * 6), 0x00020000);
+  unsigned voA[NJ];
+  int lo[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int id = tid + 256 * j, row = id >> 3, c = id & 7;
+    const int r = m0 + row, sq = r / R.P0;
+    voA[j] = r < M ? (unsigned)sq * R.seq6 + (unsigned)(r - sq * R.P0) * R.step6 + R.off6 + c * 16 : 0xf0000000u;
+    lo[j] = row * PITCH + c * 8;
+  }
+  // fragment (i, piece p, k step ks) of slab t: 1 KB at (((n0 / 32 + 2 wn + i) nt + t) 12 + 4 p + 2 ks) * 512 bytes
+  unsigned voB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) voB[i] = (unsigned)((n0 >> 5) + 2 * wn + i) * (unsigned)nt * 6144u + lane * 16;
+  u32x4 xa[NJ];
+  u32x2 pa[NJ][3];      // the pieces of slab t + 1, split during the chain of slab t, stored behind it
+  bf16x8 fa[2][3][2], fb[2][3][2];
+  auto load_b = [&](int ks, int t) {        // the six fragments of k step ks
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fb[ks][p][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voB[i] + (4 * p + 2 * ks) * 512, t * 6144, 0));
+  };
+  auto stage_a = [&](int j) {
+    u32x2 p0, p1, p2;
+    split3x4(xa[j], p0, p1, p2);
+    *reinterpret_cast<u32x2*>(smem6 + lo[j]) = p0;
+    *reinterpret_cast<u32x2*>(smem6 + lo[j] + 64) = p1;
+    *reinterpret_cast<u32x2*>(smem6 + lo[j] + 128) = p2;
+  };
+  const unsigned char* rA = smem6 + (wm * 64 + li) * PITCH + h * 16;
+  auto frags_a = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          fa[ks][p][i] = *reinterpret_cast<const bf16x8*>(rA + p * 64 + i * 32 * PITCH + ks * 32);
+  };
+  // the 48 MFMAs of a slab as 12 groups of four (one product term of one k step), smallest terms first
+  auto mf4 = [&](int g) {
+    const int ks = g / 6, r = g % 6;
+    const int i = r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : r == 3 ? 0 : r == 4 ? 1 : 0;
+    const int j = r < 3 ? 2 - i : r < 5 ? 1 - i : 0;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i][mi], fb[ks][j][ni], acc[mi][ni], 0, 0, 0);
+  };
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], 0, 0);
+  load_b(0, 0);
+  load_b(1, 0);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) stage_a(j);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j], nt > 1 ? 128 : 0, 0);
+  X6_LDS_BARRIER();
+  frags_a();
+  X6_LDS_BARRIER();
+  for (int t = 0; t + 1 < nt; ++t) {
+    const int t2 = t + 2 < nt ? t + 2 : 0;       // (past the end: re-read, never used)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // quarter q: MFMA groups 3 q ... 3 q + 2 with the staging of activation chunk q of slab t + 1 between them;
+      // the chunk's registers are requested again for slab t + 2 right away.  Groups 0-5 are k step 0, 6-11 k step
+      // 1: quarter 2 opens with the requests for k step 0 of slab t + 1, quarter 3 closes with those for k step 1.
+      if (q == 2) load_b(0, t + 1);
+      mf4(3 * q);
+      mf4(3 * q + 1);
+#if F2G_X6LAB & 1024      // (lab: the stores inside the chain, quarter by quarter)
+      stage_a(q);
+#else
+      split3x4(xa[q], pa[q][0], pa[q][1], pa[q][2]);
+#endif
+      xa[q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[q], t2 * 128, 0);
+      mf4(3 * q + 2);
+      if (q == 3) load_b(1, t + 1);
+      if (q == 2) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 7, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#if !(F2G_X6LAB & 1024)
+    // the twelve LDS stores of the slab BEHIND the chain: a store moves its address and data registers to the LDS
+    // over the path the MFMAs read their operands through -- between the MFMAs they cost the chain ~50 clocks each
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<u32x2*>(smem6 + lo[q]) = pa[q][0];
+      *reinterpret_cast<u32x2*>(smem6 + lo[q] + 64) = pa[q][1];
+      *reinterpret_cast<u32x2*>(smem6 + lo[q] + 128) = pa[q][2];
+    }
+#endif
+    X6_LDS_BARRIER();
+    frags_a();
+    X6_LDS_BARRIER();
+  }
+#pragma unroll
+  for (int g = 0; g < 12; ++g) mf4(g);
+  if (wide) {
+    x6e::wide_epilogue(d.E, acc, M, N, m0 + wm * 64, n0 + wn * 64, lane, smem6 + wave * x6e::ESZ);
+    return;
+  }
+  gemm_epilogue<2, 2>(d.E, acc, M, N, m0, n0, wm, wn, li, h, true);
+  if (d.E.x3_out) x3_tile_readback(d.E, M, N, m0, n0, tid);
 }
 
 // The in-kernel-split kernel for N <= 32 output columns (round 6): the data gradients that land on a 32-channel
@@ -2924,7 +3223,9 @@ static int launch_x6(const f2g_gemm_desc& d, hipStream_t st) {
 // the same descriptor over the fp32 tensors themselves (split = 0): gemm_x6f_kernel
 // (B.split = 3: the weight operand as its cached image -- gemm_x6f_kernel<true>; the activation stays fp32)
 static bool x6f_ok(const f2g_gemm_desc& d) {
-  if (d.A.split || (d.B.split != 0 && d.B.split != 3) || !x6_shape_ok(d)) return false;
+  if (d.A.split || (d.B.split != 0 && d.B.split != 3 && d.B.split != 4) || !x6_shape_ok(d)) return false;
+  // (the fragment-major weight image: whole 32-row groups, plain matrix)
+  if (d.B.split == 4 && ((d.B.rows & 31) || d.B.rows <= 32 || d.B.P0 != 1 || d.B.P1 != 1)) return false;
   if (!al16(d.A.base) || !al16(d.B.base) || (d.A.seq_stride & 3) || (d.B.split == 0 && (d.B.seq_stride & 3))) return false;
   const long long ext = host_plain(d.A) ? (long long)d.A.rows * d.A.seq_stride : x6_a_extent(d.A);
   return ext * 4 < 0xe0000000ll && (long long)d.B.rows * (d.B.split ? d.B.cols * 6ll : d.B.seq_stride * 4) < 0xe0000000ll;
@@ -2957,6 +3258,12 @@ static int launch_x6f(const f2g_gemm_desc& d, hipStream_t st) {
     return f2g_check_launch();
   }
   dim3 grid((M + 127) / 128, (N + 127) / 128);
+  if (d.B.split == 4) {
+    constexpr size_t smem_g = 4 * x6e::ESZ > 128 * 208 ? 4 * x6e::ESZ : 128 * 208;
+    hipLaunchKernelGGL(gemm_x6g_kernel, grid, dim3(256), smem_g, st, d, M, N, K, R, x6_wide(d));
+    g_last_path = 4;
+    return f2g_check_launch();
+  }
   if (d.B.split == 3) hipLaunchKernelGGL(gemm_x6f_kernel<true>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   else hipLaunchKernelGGL(gemm_x6f_kernel<false>, grid, dim3(256), smem, st, d, M, N, K, R, x6_wide(d));
   g_last_path = 4;

@@ -202,26 +202,17 @@ __global__ __launch_bounds__(512, 1) void gemm_x6p_kernel(const f2g_gemm_desc d,
 // windows -- was measured no faster than two free-running 128 x 128 blocks in round 5, 188 : 190 and 147 : 149
 // TFLOP/s equivalent, and removed in round 6.)
 
-// three bf16 pieces of four floats (as gemm.hip's split3x4: round to nearest even at every step)
+// three bf16 pieces of four floats (common.h: f2g_split3_pair, round to nearest even at every step)
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3x4(const u32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
   // (by value first: __builtin_bit_cast applied to a vector-element expression reads element 0)
   const unsigned u0 = v.x, u1 = v.y, u2 = v.z, u3 = v.w;
-  const float x[4] = {__uint_as_float(u0), __uint_as_float(u1), __uint_as_float(u2), __uint_as_float(u3)};
-  unsigned short q[3][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 a = (__bf16)x[e];
-    const float r1 = x[e] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const __bf16 c = (__bf16)(r1 - (float)b);
-    q[0][e] = __builtin_bit_cast(unsigned short, a);
-    q[1][e] = __builtin_bit_cast(unsigned short, b);
-    q[2][e] = __builtin_bit_cast(unsigned short, c);
-  }
-  p0 = u32x2{q[0][0] | ((unsigned)q[0][1] << 16), q[0][2] | ((unsigned)q[0][3] << 16)};
-  p1 = u32x2{q[1][0] | ((unsigned)q[1][1] << 16), q[1][2] | ((unsigned)q[1][3] << 16)};
-  p2 = u32x2{q[2][0] | ((unsigned)q[2][1] << 16), q[2][2] | ((unsigned)q[2][3] << 16)};
+  unsigned a0, a1, a2, b0, b1, b2;
+  f2g_split3_pair(__uint_as_float(u0), __uint_as_float(u1), a0, a1, a2);
+  f2g_split3_pair(__uint_as_float(u2), __uint_as_float(u3), b0, b1, b2);
+  p0 = u32x2{a0, b0};
+  p1 = u32x2{a1, b1};
+  p2 = u32x2{a2, b2};
 }
 
 // ---- tap-walking weight gradient of a stride-1 conv layer over halo maps (round 5) ----------------------

@@ -527,8 +527,9 @@ def gemm(A: Operand, Bm: Operand, out, form: int = 0, ldc: Optional[int] = None,
                         d.A, d.B = _x3_operand(A), _x3_operand(Bm)
                     elif X6F_WIMG and Bm.P0 == 1 and Bm.P1 == 1 and _is_const(Bm._keep[0]):
                         # the WEIGHT operand as its cached image: every row tile used to split the same weight
-                        # slab again (M / 128 times); only the activation is split in the kernel
-                        d.B = _x3_operand(Bm)
+                        # slab again (M / 128 times); only the activation is split in the kernel.  Whole 32-row
+                        # groups: the FRAGMENT-MAJOR image, read straight into MFMA registers (gemm_x6g_kernel)
+                        d.B = _x3_operand(Bm, frag_major=X6G and Bm.rows % 32 == 0 and Bm.rows > 32)
                     d.precision = 3
             if d.precision != 3:
                 d.E.x3_out = None
@@ -705,9 +706,21 @@ X6_MIN_ROWS = opt("x6_min_rows", 1024)
 X6_MIN_K = opt("x6_min_k", 2048)
 
 
-def _x3_operand(o: Operand) -> Operand:
+def _x3_frag_major(img, rows: int, K: int):
+    """The f2g_split_bf16x3 image [row][K / 32][piece][32] of a (rows, K) matrix, rows % 32 == 0, in MFMA fragment
+    order (f2g_operand.split = 4): [rows / 32][K / 32][piece][k step][lane half][row in group][8 bf16] -- for one
+    32-row group, slab, piece and 16-element k step the 64 lanes' 16-byte operands of v_mfma_f32_32x32x16_bf16
+    are 1 KB contiguous.  A permutation of 16-byte units: one permute4 over the image read as floats."""
+    T = K // 32
+    out = torch.empty_like(img)
+    permute4(out.view(torch.float32), img.view(torch.float32), (rows // 32, 12 * T, 32, 4), (32 * T * 48, 4, T * 48, 1))
+    return out
+
+
+def _x3_operand(o: Operand, frag_major: bool = False) -> Operand:
     """Copy of a plain fp32 matrix operand over its three-piece image (f2g_split_bf16x3): cached for
-    weights (and cached re-layouts of weights), written here for activations."""
+    weights (and cached re-layouts of weights), written here for activations.  frag_major (cached weights only):
+    the image in MFMA fragment order (split = 4, gemm_x6g_kernel)."""
     t = o._keep[0]
     rows, K, ld = o.rows, o.cols, o.seq_stride
     off = o.base - ptr(t)
@@ -718,6 +731,15 @@ def _x3_operand(o: Operand) -> Operand:
             return img
         img = derived(t, ("x3", off, rows, K, ld), build) if _is_const(t) else build(t)
         shift = 0
+        if frag_major:
+            assert _is_const(t) and rows % 32 == 0
+            imgf = derived(img, ("x3g", rows, K), lambda im: _x3_frag_major(im, rows, K))
+            n = Operand()
+            C.memmove(C.byref(n), C.byref(o), C.sizeof(Operand))
+            n.base = ptr(imgf)
+            n.split = 4
+            n._keep = (imgf, img) + tuple(o._keep)
+            return n
     else:
         # windows over a contiguous map (halo layouts): the flat image of the whole buffer -- element e
         # at (e / 32) * 192 bytes whatever the row length -- addressed by the same window geometry
@@ -793,6 +815,7 @@ X6F_MIN_TILES = opt("x6f_min_tiles", 180)
 # split instead of an image pass (f2g_split_bf16x3: 10 bytes per element) in front of the image kernel
 X6_NOPASS_K = opt("x6_nopass_k", 4096)
 X6F_WIMG = opt("x6f_wimg", True)     # in-kernel-split kernel: weights from their cached image
+X6G = opt("x6g", True)               # ... in MFMA fragment order, straight into registers (gemm_x6g_kernel)
 
 
 def _x3_window_ok(o: Operand) -> bool:

@@ -74,6 +74,11 @@ typedef struct {
    *    contiguous buffer the windows address, `base` moved to the image of the same element (element e of
    *    a contiguous buffer sits at (e / 32) * 192 + piece * 64 + (e % 32) * 2 bytes of its image; every
    *    stride / offset of the descriptor stays in elements and must be a multiple of 32);
+   * 4: (operand B of a precision-3, form-0 launch whose A is fp32; rows % 32 == 0, rows > 32, plain matrix) the
+   *    f2g_split_bf16x3 image in MFMA FRAGMENT order: unit u = (((g * (cols / 32) + slab) * 3 + piece) * 2 +
+   *    k step) * 64 + (k half) * 32 + (row % 32) of 16 bytes holds the 8 bf16 of row 32 g + (row % 32), columns
+   *    32 slab + 16 (k step) + 8 (k half) ... + 8 of that piece -- 1 KB per (group, slab, piece, k step), read
+   *    straight into the operand registers of v_mfma_f32_32x32x16_bf16 (gemm_x6g_kernel);
    * 1: `base` holds the split-bf16 image written by f2g_split_bf16 (same addressing);
    * 2: `base` is a TRUE bf16 tensor (f2g_to_bf16 or a bf16 producer): strides / offsets stay in
    *    elements, the reduction needs whole 64-element slabs (precision 2, lean kernel only) */

@@ -1660,3 +1660,40 @@ def test_fp32_class_gemm_with_32_output_columns(ops, S, Hp, Cout, nt, monkeypatc
     untouched[rows] = False
     assert bool((o[:, untouched] == 7.0).all())
     close(cs.cpu().double(), want.sum((0, 1)), rtol=1e-4, name="x6n column sums")
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (777, 384, 160), (2050, 32, 384), (128, 2304, 96)])
+def test_fp32_class_gemm_with_fragment_major_weights(ops, M, K, N, monkeypatch):
+    """Round 6: gemm_x6g_kernel -- the in-kernel-split fp32-class kernel whose WEIGHT fragments come straight from
+    the cached fragment-major image (f2g_operand.split = 4: no LDS staging of the weights): plain and ragged row
+    counts, one and many slabs, a ragged last column tile (N = 160, 96), bias + residual epilogue and the plain
+    one, against float64 at the fp32-class bound; the same launch over the row-major image (x6g off) must give
+    the SAME bits (same products in the same order)."""
+    monkeypatch.setattr(ops, "X6_MIN_ROWS", 1)
+    monkeypatch.setattr(ops, "X6F", 1)              # every eligible launch on the in-kernel-split kernels
+    gen = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) * 0.05
+    b = torch.randn(N, generator=gen)
+    res = torch.randn(M, N, generator=gen)
+    ref = a.double() @ w.double().t()
+    wd = torch.nn.Parameter(g(w))
+    was = ops.GEMM_PRECISION
+    outs = {}
+    try:
+        ops.set_gemm_precision("bf16x6")
+        for frag in (True, False):
+            monkeypatch.setattr(ops, "X6G", frag)
+            o1 = torch.empty(M, N, device=DEV)
+            o2 = torch.empty(M, N, device=DEV)
+            ops.gemm(ops.mat(g(a)), ops.mat(wd), o1)
+            assert ops.L.lib.f2g_gemm_last_path() == 4
+            ops.gemm(ops.mat(g(a)), ops.mat(wd), o2, bias=g(b), res=g(res))
+            outs[frag] = (o1.cpu(), o2.cpu())
+    finally:
+        ops.GEMM_PRECISION = was
+    scale = float(ref.abs().max())
+    assert float((outs[True][0].double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (K / 256) ** 0.5)
+    close(outs[True][1].double(), ref + b.double() + res.double(), rtol=2e-5, name="x6g bias + residual")
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1]), \
+        "fragment-major and row-major weight images gave different bits"
