@@ -340,7 +340,7 @@ def main():
                            "generic": "gemm_kernel (fp32 MFMA implicit GEMM, generic loaders)",
                            "direct-conv": "conv32 direct kernels (the 32 -> 32 channel MRD band layers)",
                            "lean-streamk": "gemm_lean_kernel (stream-K)",
-                           "x6": "gemm_x6p / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
+                           "x6": "gemm_x6p / x6 / x6g / x6f / leanw6 kernels (fp32 class on the bf16 pipe: three bf16 "
                                  "pieces per operand, six MFMAs per product)",
                            "x6-thin": "gemm_x6n_kernel (fp32 class on the bf16 pipe, 128 x 32 tiles: <= 32 output columns)",
                            "narrow": "narrow VALU kernels"}.get(dn, dn),

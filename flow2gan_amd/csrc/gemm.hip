@@ -2876,7 +2876,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6f_kernel(const f2g_gemm_desc d,
 // and data registers to the LDS at 2 clocks per source dword (MI355X_MICROARCH.md, LDS), ~600 clocks per slab
 // and block, and the wave's MFMAs wait behind it.  Half of those stores put the weight image into LDS only to read
 // it back in MFMA fragment order.  Here the cached weight image is FRAGMENT-MAJOR (B.split = 4: [N / 32][K / 32]
-// [piece][k step][lane][16 bytes] -- a permutation of the f2g_split_bf16x3 image, flow2gan_amd/ops.py), so a
+// [piece][k step][lane][16 bytes] -- the pieces of f2g_split_bf16x3 in another order: F2G_MULTI_SPLIT3G), so a
 // wave's B fragment is one coalesced 1 KB load into the registers the MFMAs read: no LDS store, no LDS read, no
 // staging registers for the weights; the two k-step halves of the fragment set are requested again for slab
 // t + 1 as soon as the MFMAs of slab t have consumed them.  LDS carries the activation tile only (half the

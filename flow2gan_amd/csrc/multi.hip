@@ -47,7 +47,9 @@ __device__ __forceinline__ void run_copy3(const f2g_multi_entry& e, long long b,
   }
 }
 
-// f2g_split_bf16x3: dst [row][K / 32][piece][32] bf16, src (rows, K) fp32 with row stride ld
+// f2g_split_bf16x3: dst [row][K / 32][piece][32] bf16, src (rows, K) fp32 with row stride ld.  FRAG: the same
+// pieces in MFMA fragment order (f2g_operand.split = 4): [row / 32][K / 32][piece][k step][k half][row % 32][8]
+template <bool FRAG>
 __device__ __forceinline__ void run_split3(const f2g_multi_entry& e, long long b, long long nb) {
   __bf16* dst = reinterpret_cast<__bf16*>(e.out);
   const float* src = reinterpret_cast<const float*>(e.in);
@@ -69,10 +71,13 @@ __device__ __forceinline__ void run_split3(const f2g_multi_entry& e, long long b
       p[1][q] = __builtin_bit_cast(unsigned short, c);
       p[2][q] = __builtin_bit_cast(unsigned short, d);
     }
-    __bf16* o = dst + (r * (K / 32) + k4 / 32) * 96 + (k4 & 31);
+    // row-major: pieces 32 bf16 apart inside the row's 96-element slab block; fragment-major: unit (16 bytes) index
+    // (((group * slabs + slab) * 3 + piece) * 4 + (k % 32) / 8) * 32 + row % 32, pieces 4 * 32 units apart
+    __bf16* o = FRAG ? dst + ((((r >> 5) * (K / 32) + k4 / 32) * 12 + ((k4 & 31) >> 3)) * 32 + (r & 31)) * 8 + (k4 & 7)
+                     : dst + (r * (K / 32) + k4 / 32) * 96 + (k4 & 31);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      *reinterpret_cast<uint2*>(o + 32 * q) =
+      *reinterpret_cast<uint2*>(o + (FRAG ? 4 * 32 * 8 : 32) * q) =
           make_uint2(p[q][0] | ((unsigned)p[q][1] << 16), p[q][2] | ((unsigned)p[q][3] << 16));
   }
 }
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(256) void multi_kernel(const f2g_multi_desc d) {
     case F2G_MULTI_FILL: run_fill(e, b, nb); break;
     case F2G_MULTI_PERMUTE4: run_permute4(e, b, nb); break;
     case F2G_MULTI_COPY3: run_copy3(e, b, nb); break;
-    default: run_split3(e, b, nb); break;
+    case F2G_MULTI_SPLIT3: run_split3<false>(e, b, nb); break;
+    default: run_split3<true>(e, b, nb); break;
   }
 }
 
@@ -98,9 +104,10 @@ extern "C" int f2g_multi(const f2g_multi_desc* d, f2g_stream_t stream) {
   long long grid = 0;
   for (int i = 0; i < d->n; ++i) {
     const f2g_multi_entry& e = d->e[i];
-    if (!e.out || (e.kind != F2G_MULTI_FILL && !e.in) || e.blocks < 1 || e.kind < 0 || e.kind > F2G_MULTI_SPLIT3)
+    if (!e.out || (e.kind != F2G_MULTI_FILL && !e.in) || e.blocks < 1 || e.kind < 0 || e.kind > F2G_MULTI_SPLIT3G)
       return F2G_EINVAL;
-    if (e.kind == F2G_MULTI_SPLIT3 &&
+    if (e.kind == F2G_MULTI_SPLIT3G && (e.n[0] & 31)) return F2G_EINVAL;
+    if ((e.kind == F2G_MULTI_SPLIT3 || e.kind == F2G_MULTI_SPLIT3G) &&
         (e.n[1] < 32 || (e.n[1] % 32) || e.s[0] < e.n[1] || (e.s[0] & 3) || (((uintptr_t)e.in) & 15) ||
          (((uintptr_t)e.out) & 15)))
       return F2G_EINVAL;

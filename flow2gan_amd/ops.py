@@ -607,6 +607,24 @@ def split3(img, src, src_off_bytes: int, ld: int, rows: int, K: int):
     return img
 
 
+def split3g(img, src, src_off_bytes: int, ld: int, rows: int, K: int):
+    """The pieces of f2g_split_bf16x3 in MFMA FRAGMENT order (f2g_operand.split = 4; rows % 32 == 0): an
+    F2G_MULTI_SPLIT3G entry -- recorded into an open WeightBatch, else launched as a one-entry f2g_multi table."""
+    assert rows % 32 == 0 and K % 32 == 0
+    if BATCH is not None and rows > 0:
+        BATCH.add(4, ptr(img), rows * K * 6, ptr(src) + src_off_bytes, 4 * ((rows - 1) * ld + K), (rows, K, 0, 0),
+                  (ld, 0, 0, 0), rows * (K // 4), (img, src))
+        return img
+    d = L.MultiDesc()
+    e = d.e[0]
+    e.out, e.inp, e.kind = ptr(img), ptr(src) + src_off_bytes, 4
+    e.blocks = max(1, min(WeightBatch.MAX_BLOCKS, (rows * (K // 4) + 255) // 256))
+    e.n[0], e.n[1], e.s[0] = rows, K, ld
+    d.n = 1
+    call("f2g_multi", C.byref(d))
+    return img
+
+
 def split_bf16(t):
     """Split-bf16 image of a contiguous fp32 tensor (f2g_split_bf16): same shape, same bytes per
     element, every aligned group of four floats = four bf16 high parts + four bf16 remainders."""
@@ -706,17 +724,6 @@ X6_MIN_ROWS = opt("x6_min_rows", 1024)
 X6_MIN_K = opt("x6_min_k", 2048)
 
 
-def _x3_frag_major(img, rows: int, K: int):
-    """The f2g_split_bf16x3 image [row][K / 32][piece][32] of a (rows, K) matrix, rows % 32 == 0, in MFMA fragment
-    order (f2g_operand.split = 4): [rows / 32][K / 32][piece][k step][lane half][row in group][8 bf16] -- for one
-    32-row group, slab, piece and 16-element k step the 64 lanes' 16-byte operands of v_mfma_f32_32x32x16_bf16
-    are 1 KB contiguous.  A permutation of 16-byte units: one permute4 over the image read as floats."""
-    T = K // 32
-    out = torch.empty_like(img)
-    permute4(out.view(torch.float32), img.view(torch.float32), (rows // 32, 12 * T, 32, 4), (32 * T * 48, 4, T * 48, 1))
-    return out
-
-
 def _x3_operand(o: Operand, frag_major: bool = False) -> Operand:
     """Copy of a plain fp32 matrix operand over its three-piece image (f2g_split_bf16x3): cached for
     weights (and cached re-layouts of weights), written here for activations.  frag_major (cached weights only):
@@ -729,17 +736,24 @@ def _x3_operand(o: Operand, frag_major: bool = False) -> Operand:
             img = torch.empty(rows * K * 3, device=tt.device, dtype=torch.bfloat16)
             split3(img, tt, off, ld, rows, K)
             return img
-        img = derived(t, ("x3", off, rows, K, ld), build) if _is_const(t) else build(t)
-        shift = 0
         if frag_major:
+            # [rows / 32][K / 32][piece][k step][k half][row % 32][8 bf16]: for one 32-row group, slab, piece and
+            # 16-element k step the 64 lanes' 16-byte operands of v_mfma_f32_32x32x16_bf16 are 1 KB contiguous
             assert _is_const(t) and rows % 32 == 0
-            imgf = derived(img, ("x3g", rows, K), lambda im: _x3_frag_major(im, rows, K))
+
+            def build_g(tt):
+                imgf = torch.empty(rows * K * 3, device=tt.device, dtype=torch.bfloat16)
+                split3g(imgf, tt, off, ld, rows, K)
+                return imgf
+            imgf = derived(t, ("x3g", off, rows, K, ld), build_g)
             n = Operand()
             C.memmove(C.byref(n), C.byref(o), C.sizeof(Operand))
             n.base = ptr(imgf)
             n.split = 4
-            n._keep = (imgf, img) + tuple(o._keep)
+            n._keep = (imgf,) + tuple(o._keep)
             return n
+        img = derived(t, ("x3", off, rows, K, ld), build) if _is_const(t) else build(t)
+        shift = 0
     else:
         # windows over a contiguous map (halo layouts): the flat image of the whole buffer -- element e
         # at (e / 32) * 192 bytes whatever the row length -- addressed by the same window geometry

@@ -510,8 +510,10 @@ int f2g_fill(float* x, float v, int64_t n, f2g_stream_t stream);
  *                          F2G_MULTI_COPY3    f2g_copy3                n = {n0, n1, n2, accumulate},
  *                                                                      s = {so0, so1, si0, si1}
  *                          F2G_MULTI_SPLIT3   f2g_split_bf16x3         n = {rows, K}, s[0] = ld
+ *                          F2G_MULTI_SPLIT3G  the same pieces in MFMA FRAGMENT order (f2g_operand.split = 4;
+ *                                             rows % 32 == 0)                  n = {rows, K}, s[0] = ld
  * `blocks` = blocks of 256 threads the entry gets (>= 1; its elements are walked grid-stride). */
-enum { F2G_MULTI_FILL = 0, F2G_MULTI_PERMUTE4 = 1, F2G_MULTI_COPY3 = 2, F2G_MULTI_SPLIT3 = 3 };
+enum { F2G_MULTI_FILL = 0, F2G_MULTI_PERMUTE4 = 1, F2G_MULTI_COPY3 = 2, F2G_MULTI_SPLIT3 = 3, F2G_MULTI_SPLIT3G = 4 };
 #define F2G_MULTI_MAX 48
 typedef struct {
   void* out;

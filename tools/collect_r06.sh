@@ -45,6 +45,6 @@ F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_se
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lanes -o p -- $B > /dev/null 2>&1
 F2G_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fp32 -o p -- $B --gemm fp32 > /dev/null 2>&1
 for d in prof_serial prof_lanes prof_fp32; do find $O/$d -type f ! -name "p_kernel_stats.csv" -delete; done
-bash tools/pmc_busy.sh r06_x6 > /dev/null 2>&1; cp gpurun_out/pmc_busy_r06_x6.txt $O/pmc_busy_x6.txt
-bash tools/pmc_busy.sh r06_fp32 --gemm fp32 > /dev/null 2>&1; cp gpurun_out/pmc_busy_r06_fp32.txt $O/pmc_busy_fp32.txt
+bash $R/tools/pmc_busy.sh r06_x6 > /dev/null 2>&1; cp $R/gpurun_out/pmc_busy_r06_x6.txt $O/pmc_busy_x6.txt
+bash $R/tools/pmc_busy.sh r06_fp32 --gemm fp32 > /dev/null 2>&1; cp $R/gpurun_out/pmc_busy_r06_fp32.txt $O/pmc_busy_fp32.txt
 tail -1 $O/bench_default.json | cut -c1-200

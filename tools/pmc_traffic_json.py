@@ -6,8 +6,8 @@ sys.path.insert(0, os.getcwd())
 G = os.environ.get("G", "gpurun_out")
 MODE = os.environ.get("MODE", "fp32")
 if MODE == "bf16x6":
-    pat, sub, gemm, family = r"gemm_(x6pr|x6p|x6t8|x6t|x6f|x6|leanw6)_kernel", "pmcb_x6", " --gemm bf16x6", "x6"
-    label = "gemm_x6p / x6pr / x6t8 / x6t / x6 / x6f / leanw6 kernels (fp32 class on the bf16 pipe, the `x6` family of bench.py)"
+    pat, sub, gemm, family = r"gemm_(x6p|x6g|x6f|x6|leanw6t|leanw6s|leanw6)_kernel", "pmcb_x6", " --gemm bf16x6", "x6"
+    label = "gemm_x6p / x6 / x6g / x6f / leanw6 / leanw6t / leanw6s kernels (fp32 class on the bf16 pipe, the `x6` family of bench.py)"
 else:
     pat, sub, gemm, family = r"gemm_lean_kernel<(false|0), \d, 0[,>]", "pmcb", " --gemm fp32", "lean"
     label = "gemm_lean_kernel<0, EP, 0> (exact fp32, all epilogue instances)"
