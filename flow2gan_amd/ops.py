@@ -311,6 +311,8 @@ def rebuild_derived(params) -> int:
     for p_ in params:
         o = p_._base if p_._base is not None else p_
         roots[id(o)] = o
+    import time
+    t_host = time.perf_counter()
     _REPLAYING = True
     try:
         with torch.no_grad(), weight_batch():
@@ -333,7 +335,12 @@ def rebuild_derived(params) -> int:
                     n += 1
     finally:
         _REPLAYING = False
+        REBUILD_STATS[0] += time.perf_counter() - t_host
+        REBUILD_STATS[1] += n
     return n
+
+
+REBUILD_STATS = [0.0, 0]       # host seconds spent in rebuild_derived, chains replayed (bench.py reports them)
 
 
 def transposed(w2d):
