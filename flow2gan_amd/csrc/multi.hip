@@ -47,9 +47,7 @@ __device__ __forceinline__ void run_copy3(const f2g_multi_entry& e, long long b,
   }
 }
 
-// f2g_split_bf16x3: dst [row][K / 32][piece][32] bf16, src (rows, K) fp32 with row stride ld.  FRAG: the same
-// pieces in MFMA fragment order (f2g_operand.split = 4): [row / 32][K / 32][piece][k step][k half][row % 32][8]
-template <bool FRAG>
+// f2g_split_bf16x3: dst [row][K / 32][piece][32] bf16, src (rows, K) fp32 with row stride ld
 __device__ __forceinline__ void run_split3(const f2g_multi_entry& e, long long b, long long nb) {
   __bf16* dst = reinterpret_cast<__bf16*>(e.out);
   const float* src = reinterpret_cast<const float*>(e.in);
@@ -71,14 +69,42 @@ __device__ __forceinline__ void run_split3(const f2g_multi_entry& e, long long b
       p[1][q] = __builtin_bit_cast(unsigned short, c);
       p[2][q] = __builtin_bit_cast(unsigned short, d);
     }
-    // row-major: pieces 32 bf16 apart inside the row's 96-element slab block; fragment-major: unit (16 bytes) index
-    // (((group * slabs + slab) * 3 + piece) * 4 + (k % 32) / 8) * 32 + row % 32, pieces 4 * 32 units apart
-    __bf16* o = FRAG ? dst + ((((r >> 5) * (K / 32) + k4 / 32) * 12 + ((k4 & 31) >> 3)) * 32 + (r & 31)) * 8 + (k4 & 7)
-                     : dst + (r * (K / 32) + k4 / 32) * 96 + (k4 & 31);
+    __bf16* o = dst + (r * (K / 32) + k4 / 32) * 96 + (k4 & 31);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      *reinterpret_cast<uint2*>(o + (FRAG ? 4 * 32 * 8 : 32) * q) =
+      *reinterpret_cast<uint2*>(o + 32 * q) =
           make_uint2(p[q][0] | ((unsigned)p[q][1] << 16), p[q][2] | ((unsigned)p[q][3] << 16));
+  }
+}
+
+// F2G_MULTI_SPLIT3G: the same pieces in MFMA fragment order (f2g_operand.split = 4): [row / 32][K / 32][piece]
+// [k step][k half][row % 32][8 bf16].  One thread = 8 consecutive k of one row (two 16-byte loads; lanes l and
+// l + 32 of a wave take the two halves of a row's 64 bytes) -> one 16-byte unit per piece; consecutive lanes =
+// consecutive rows of a 32-row group = consecutive units of the image: 512 contiguous bytes per piece and wave
+// half.  (With run_split3's thread map -- 8-byte stores 512 bytes apart, a quarter of every 64-byte sector -- the
+// images' launches were 30 % slower than the row-major ones and cost gemm_x6g_kernel its gain in the laned step.)
+__device__ __forceinline__ void run_split3g(const f2g_multi_entry& e, long long b, long long nb) {
+  unsigned char* dst = reinterpret_cast<unsigned char*>(e.out);
+  const float* src = reinterpret_cast<const float*>(e.in);
+  const int K = e.n[1], K8 = K / 8, T = K / 32;
+  const long long rows = e.n[0], ld = e.s[0], total = rows * K8;
+  for (long long i = b * 256 + threadIdx.x; i < total; i += nb * 256) {
+    const int li = (int)(i & 31);
+    const long long q = i >> 5;
+    const int c8 = (int)(q % K8);
+    const long long j = q / K8;
+    const float* p = src + (j * 32 + li) * ld + c8 * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
+    unsigned a[3], bq[3], c[3], dq[3];
+    f2g_split3_pair(v0.x, v0.y, a[0], a[1], a[2]);
+    f2g_split3_pair(v0.z, v0.w, bq[0], bq[1], bq[2]);
+    f2g_split3_pair(v1.x, v1.y, c[0], c[1], c[2]);
+    f2g_split3_pair(v1.z, v1.w, dq[0], dq[1], dq[2]);
+    // unit (((j T + slab) 3 + piece) 4 + k-chunk of the slab) 32 + row % 32
+    unsigned char* o = dst + ((((j * T + (c8 >> 2)) * 12 + (c8 & 3)) * 32) + li) * 16;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      *reinterpret_cast<uint4*>(o + pc * (4 * 32 * 16)) = make_uint4(a[pc], bq[pc], c[pc], dq[pc]);
   }
 }
 
@@ -92,8 +118,8 @@ __global__ __launch_bounds__(256) void multi_kernel(const f2g_multi_desc d) {
     case F2G_MULTI_FILL: run_fill(e, b, nb); break;
     case F2G_MULTI_PERMUTE4: run_permute4(e, b, nb); break;
     case F2G_MULTI_COPY3: run_copy3(e, b, nb); break;
-    case F2G_MULTI_SPLIT3: run_split3<false>(e, b, nb); break;
-    default: run_split3<true>(e, b, nb); break;
+    case F2G_MULTI_SPLIT3: run_split3(e, b, nb); break;
+    default: run_split3g(e, b, nb); break;
   }
 }
 

@@ -196,6 +196,9 @@ _RECIPES: dict = {}          # id(root parameter) -> {chain key: [weakref(root),
 _REPLAYING = False
 
 
+MULTI_CAP = min(L.MULTI_MAX, max(1, opt("multi_cap", L.MULTI_MAX)))     # operations per f2g_multi table (1: lab, one launch each)
+
+
 class WeightBatch:
     """Records fill / permute4 / copy3 / split3 operations (ops.fill_, permute4, copy3, split3 while
     ops.BATCH is this object) and launches them as f2g_multi tables, dependency level by level."""
@@ -258,7 +261,7 @@ class WeightBatch:
             lvl = ops_[i][0]
             d = L.MultiDesc()
             k = 0
-            while i < len(ops_) and ops_[i][0] == lvl and k < L.MULTI_MAX:
+            while i < len(ops_) and ops_[i][0] == lvl and k < MULTI_CAP:
                 _, kind, out_ptr, in_ptr, n, s, items = ops_[i]
                 e = d.e[k]
                 e.out, e.inp, e.kind = out_ptr, in_ptr, kind
@@ -620,12 +623,12 @@ def split3g(img, src, src_off_bytes: int, ld: int, rows: int, K: int):
     assert rows % 32 == 0 and K % 32 == 0
     if BATCH is not None and rows > 0:
         BATCH.add(4, ptr(img), rows * K * 6, ptr(src) + src_off_bytes, 4 * ((rows - 1) * ld + K), (rows, K, 0, 0),
-                  (ld, 0, 0, 0), rows * (K // 4), (img, src))
+                  (ld, 0, 0, 0), rows * (K // 8), (img, src))
         return img
     d = L.MultiDesc()
     e = d.e[0]
     e.out, e.inp, e.kind = ptr(img), ptr(src) + src_off_bytes, 4
-    e.blocks = max(1, min(WeightBatch.MAX_BLOCKS, (rows * (K // 4) + 255) // 256))
+    e.blocks = max(1, min(WeightBatch.MAX_BLOCKS, (rows * (K // 8) + 255) // 256))
     e.n[0], e.n[1], e.s[0] = rows, K, ld
     d.n = 1
     call("f2g_multi", C.byref(d))
